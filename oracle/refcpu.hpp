@@ -1,0 +1,133 @@
+// oracle/refcpu.hpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement ("refcpu") of the VGS / SVGS hot path of Yusheng-Xu/VGS-SVGS-Segmentation.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+// the product (vgs-svgs-segmentation_amd/, include/) never includes, links or calls it.
+//
+// PARITY UNPINNED: the reference ships no tests, fixtures or golden outputs and cannot be
+// compiled here (PCL/Eigen/FLANN/Boost absent; sources are MSVC-only), so this
+// restatement is checked against (a) hand-derived known-answer values and
+// (b) its own two arithmetic modes.  Third-party behaviour (PCL 1.8.1 octree growth/leaf order,
+// FLANN radius rule, pcl::eigen33, VCCS) is restated from the published algorithms.
+//
+// Two arithmetic modes:
+//   RefMath (math=0): libm + the C++ promotion rules the reference's expressions imply
+//                     (pow(float,int)->double, acos(float)->float overload, exp(double) ...).
+//   DevMath (math=1): the all-float specification in csrc/vgs_math.h, shared with the HIP
+//                     kernels so that GPU-vs-oracle can be compared bit for bit.
+// Two data-flow flavours of the local graph step:
+//   faithful (flavour=0): by-value std::vector traffic, full n x n matrix, std::sort of n^2
+//                         entries -- "the reference single-thread CPU path" that is timed.
+//   lean     (flavour=1): unique pairs, used nodes only, deterministic tie order (w desc, k asc).
+#ifndef REFCPU_HPP_
+#define REFCPU_HPP_
+
+#include <cstdint>
+#include <vector>
+
+namespace refcpu {
+
+struct Params {
+  // Task_File_VGS.txt surface (test:25-37)
+  float voxel_size = 0.15f;
+  float graph_size = 0.5f;
+  float sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f, sig_w = 2.0f;
+  float cut_thred = 0.3f;
+  int points_min = 10, adjacency_min = 3, voxels_min = 3;
+  // Task_File_SVGS.txt extras (test:108-125)
+  float seed_size = 0.25f;
+  float color_impt = 0.0f, spatial_impt = 0.25f, normal_impt = 0.75f;
+  // oracle switches
+  int math = 0;      // 0 RefMath, 1 DevMath
+  int flavour = 1;   // 0 faithful, 1 lean
+  int q7_count_as_index = 1;  // closestCheck scans the leading neighbour count as a voxel id (VS:2243)
+};
+
+struct Node {  // one graph node's attributes
+  float c[3] = {0, 0, 0};
+  float n[3] = {0, 0, 0};
+  float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int nf = 1;        // length of the eigen vector: 1 ({0}, VS:1453) or 8
+  bool used = false;
+};
+
+struct StageTimes { double voxelize = 0, features = 0, adjacency = 0, graph = 0, merge = 0, labels = 0, total = 0; };
+
+// ------------------------------ octree / voxel table ---------------------
+struct VoxelTable {
+  double min[3] = {0, 0, 0}, max[3] = {0, 0, 0};  // octree bounding box after growth
+  double resolution = 0;
+  int depth = 0;
+  std::vector<uint32_t> key;        // 3*V (x,y,z), leaf order
+  std::vector<int> start;           // V+1 offsets into point_idx
+  std::vector<int> point_idx;       // N' point indices grouped by leaf, ascending inside a leaf
+  std::vector<int> point_voxel;     // N   voxel id per input point (-1 for non-finite points)
+  std::vector<float> center;        // 3*V
+  int V() const { return (int)start.size() - 1; }
+};
+
+void build_voxel_table(const float* xyz, int64_t n, int stride_floats, float voxel_size, VoxelTable& T);
+
+// ------------------------------ features (A.2) --------------------------------------------
+void compute_node(const float* xyz, int stride_floats, const int* idx, int count, int math, bool svgs, Node& out);
+
+void eigen33(const float* m9, int math, float* evecs9, float* evals3);
+void eigen_features(const float* ev3, bool svgs, int math, float* F8);
+
+// ------------------------------ pair arithmetic (A.3, A.6) --------------------------------
+void pair_distances(const Node& a, const Node& b, bool svgs, int math, float out[5]);
+float distance_weight(const float d[5], const Params& P, bool svgs);
+float pair_weight(const Node& a, const Node& b, const Params& P, bool svgs);
+
+// ------------------------------ local cut (A.4) -------------------------------------------
+// W: n*n row-major matrix adj(i,j); returns local vertex ids of the segment holding vertex 0
+std::vector<int> cut_graph_faithful(float cut, const std::vector<float>& W, int n);
+struct LeanEdge { float w; int a, b; };
+std::vector<int> cut_graph_lean(float cut, std::vector<LeanEdge>& edges, int n);
+
+// ------------------------------ whole pipelines --------------------------------------------
+struct GraphResult {
+  std::vector<std::vector<int>> adjacency;      // per node: neighbour ids in reference order (self first)
+  std::vector<std::vector<int>> connect_cut;    // L0(i): output of cutGraphSegmentation
+  std::vector<std::vector<int>> connect_cross;  // after crossValidation
+  std::vector<std::vector<int>> connect_final;  // after closestCheck
+  std::vector<std::vector<int>> clusters;       // node ids per cluster, reference DFS order
+  std::vector<int> node_cluster;                // cluster index per node
+  int64_t pair_evals = 0;
+  int q7_out_of_range = 0;
+};
+
+void segment_graph(const std::vector<Node>& nodes, const std::vector<std::vector<int>>& adjacency,
+                   const Params& P, bool svgs, GraphResult& R);
+
+struct VgsResult {
+  VoxelTable T;
+  std::vector<Node> nodes;
+  GraphResult G;
+  std::vector<int> point_label;                 // N, index into kept clusters, -1 dropped
+  std::vector<std::vector<int>> clusters_points;  // getClusterIdx()
+  int clusters_num = 0;                         // getClusterNum() (all clusters)
+  StageTimes t;
+};
+
+void run_vgs(const float* xyz, int64_t n, int stride_floats, const Params& P, VgsResult& R);
+
+// SVGS: supervoxel labels come from `sv_label` (one int per point, 0 = unassigned) -- produced
+// either by this oracle's VCCS-style restatement or by the caller.
+struct SvgsResult {
+  std::vector<int> sv_label;                    // N
+  int max_label = 0;
+  std::vector<std::vector<int>> sv_points;      // supervoxels_point_idx_
+  std::vector<Node> nodes;
+  GraphResult G;
+  std::vector<int> point_label;
+  std::vector<std::vector<int>> clusters_points;
+  int clusters_num = 0;
+  StageTimes t;
+};
+void run_svgs_from_labels(const float* xyz, int64_t n, int stride_floats, const int* sv_label, int max_label,
+                          const Params& P, SvgsResult& R);
+void vccs_supervoxels(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
+
+}  // namespace refcpu
+#endif

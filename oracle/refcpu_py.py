@@ -1,0 +1,248 @@
+"""oracle/refcpu_py.py -- TEST INFRASTRUCTURE: ctypes binding of the CPU oracle (oracle/librefcpu.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RefParams(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("graph_size", C.c_float),
+        ("sig_p", C.c_float), ("sig_n", C.c_float), ("sig_o", C.c_float), ("sig_e", C.c_float),
+        ("sig_c", C.c_float), ("sig_w", C.c_float), ("cut_thred", C.c_float),
+        ("points_min", C.c_int), ("adjacency_min", C.c_int), ("voxels_min", C.c_int),
+        ("seed_size", C.c_float), ("color_impt", C.c_float), ("spatial_impt", C.c_float), ("normal_impt", C.c_float),
+        ("math", C.c_int), ("flavour", C.c_int), ("q7_count_as_index", C.c_int),
+    ]
+
+
+def vgs_params(**kw):
+    """Task_File_VGS.txt defaults (TV:28-50); math=1 (DevMath), flavour=1 (lean) unless overridden."""
+    d = dict(voxel_size=0.15, graph_size=0.5, sig_p=0.2, sig_n=0.2, sig_o=0.2, sig_e=0.2, sig_c=0.2, sig_w=2.0,
+             cut_thred=0.3, points_min=10, adjacency_min=3, voxels_min=3, seed_size=0.25, color_impt=0.0,
+             spatial_impt=0.25, normal_impt=0.75, math=1, flavour=1, q7_count_as_index=1)
+    d.update(kw)
+    return RefParams(**d)
+
+
+def svgs_params(**kw):
+    """Task_File_SVGS.txt defaults (TS:28-60)."""
+    d = dict(voxel_size=0.05, seed_size=0.25, graph_size=0.5, sig_w=1.0, cut_thred=0.5)
+    d.update(kw)
+    return vgs_params(**d)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librefcpu.so")
+    srcs = [os.path.join(_HERE, f) for f in ("refcpu.cpp", "refcpu_capi.cpp", "refcpu.hpp")]
+    srcs.append(os.path.join(_HERE, "..", "vgs-svgs-segmentation_amd", "csrc", "vgs_math.h"))
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.ref_vgs_run.restype = C.c_void_p
+        L.ref_vgs_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams)]
+        L.ref_svgs_run_from_labels.restype = C.c_void_p
+        L.ref_svgs_run_from_labels.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.POINTER(RefParams)]
+        L.ref_voxelize.restype = C.c_void_p
+        L.ref_voxelize.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_vgs_bbox.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_vgs_voxel_table.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.ref_nodes.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ref_lists_size.restype = C.c_int64
+        L.ref_lists_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_lists.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_pair_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ref_distance_weight.restype = C.c_float
+        L.ref_distance_weight.argtypes = [C.c_void_p, C.POINTER(RefParams), C.c_int]
+        L.ref_pair_weight.restype = C.c_float
+        L.ref_pair_weight.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RefParams), C.c_int]
+        L.ref_cut_graph.restype = C.c_int
+        L.ref_cut_graph.argtypes = [C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ref_compute_node.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_eigen_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ref_eigen33.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_devmath.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _xyz(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    assert xyz.ndim == 2 and xyz.shape[1] in (3, 4)
+    return xyz
+
+
+class Result:
+    """Owns one oracle run; arrays are copied out lazily."""
+
+    LISTS = {"adjacency": 0, "connect_cut": 1, "connect_cross": 2, "connect_final": 3, "clusters": 4,
+             "clusters_points": 5, "sv_points": 6}
+
+    def __init__(self, handle, n, kind):
+        self._h = handle
+        self.n = n
+        self.kind = kind
+        c = np.zeros(9, dtype=np.int64)
+        lib().ref_counts(self._h, _p(c))
+        (self.V, self.E, self.clusters_num, self.kept_clusters, self.pair_evals, self.depth,
+         self.q7_out_of_range, self.n_finite, self.used_nodes) = (int(v) for v in c)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ref_free(self._h)
+            self._h = None
+
+    def bbox(self):
+        b = np.zeros(6, dtype=np.float64)
+        lib().ref_vgs_bbox(self._h, _p(b))
+        return b
+
+    def voxel_table(self):
+        key = np.zeros((self.V, 3), dtype=np.uint32)
+        start = np.zeros(self.V + 1, dtype=np.int32)
+        pidx = np.zeros(self.n_finite, dtype=np.int32)
+        pvox = np.zeros(self.n, dtype=np.int32)
+        center = np.zeros((self.V, 3), dtype=np.float32)
+        lib().ref_vgs_voxel_table(self._h, _p(key), _p(start), _p(pidx), _p(pvox), _p(center))
+        return dict(key=key, start=start, point_idx=pidx, point_voxel=pvox, center=center)
+
+    def nodes(self):
+        c = np.zeros((self.V, 3), dtype=np.float32)
+        nrm = np.zeros((self.V, 3), dtype=np.float32)
+        e = np.zeros((self.V, 8), dtype=np.float32)
+        u = np.zeros(self.V, dtype=np.uint8)
+        lib().ref_nodes(self._h, _p(c), _p(nrm), _p(e), _p(u))
+        return dict(centroid=c, normal=nrm, eigen=e, used=u)
+
+    def lists(self, which):
+        w = self.LISTS[which]
+        nl = C.c_int64(0)
+        tot = lib().ref_lists_size(self._h, w, C.byref(nl))
+        off = np.zeros(nl.value + 1, dtype=np.int64)
+        idx = np.zeros(max(tot, 1), dtype=np.int32)
+        lib().ref_lists(self._h, w, _p(off), _p(idx))
+        return off, idx[:tot]
+
+    def labels(self):
+        pl = np.zeros(self.n, dtype=np.int32)
+        nc = np.zeros(self.V, dtype=np.int32)
+        lib().ref_labels(self._h, _p(pl), _p(nc))
+        return pl, nc
+
+    def times(self):
+        t = np.zeros(7, dtype=np.float64)
+        lib().ref_times(self._h, _p(t))
+        return dict(zip(("voxelize", "features", "adjacency", "graph", "merge", "labels", "total"), t.tolist()))
+
+
+def run_vgs(xyz, params):
+    xyz = _xyz(xyz)
+    h = lib().ref_vgs_run(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params))
+    return Result(h, xyz.shape[0], 0)
+
+
+def run_svgs_from_labels(xyz, labels, max_label, params):
+    xyz = _xyz(xyz)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    h = lib().ref_svgs_run_from_labels(_p(xyz), xyz.shape[0], xyz.shape[1], _p(labels), int(max_label), C.byref(params))
+    return Result(h, xyz.shape[0], 1)
+
+
+def voxelize(xyz, voxel_size):
+    xyz = _xyz(xyz)
+    h = lib().ref_voxelize(_p(xyz), xyz.shape[0], xyz.shape[1], C.c_float(voxel_size))
+    return Result(h, xyz.shape[0], 0)
+
+
+def node16(c, n, f=None, used=True):
+    a = np.zeros(16, dtype=np.float32)
+    a[0:3] = c
+    a[3:6] = n
+    if f is not None:
+        a[6:14] = f
+        a[14] = 8
+    else:
+        a[14] = 1
+    a[15] = 1.0 if used else 0.0
+    return a
+
+
+def pair_distances(a16, b16, svgs=False, math=0):
+    out = np.zeros(5, dtype=np.float32)
+    lib().ref_pair_distances(_p(a16), _p(b16), int(svgs), math, _p(out))
+    return out
+
+
+def distance_weight(d5, params, svgs=False):
+    d5 = np.ascontiguousarray(d5, dtype=np.float32)
+    return float(lib().ref_distance_weight(_p(d5), C.byref(params), int(svgs)))
+
+
+def pair_weight(a16, b16, params, svgs=False):
+    return float(lib().ref_pair_weight(_p(a16), _p(b16), C.byref(params), int(svgs)))
+
+
+def cut_graph(W, cut, flavour=0):
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    n = W.shape[0]
+    out = np.zeros(n, dtype=np.int32)
+    k = lib().ref_cut_graph(C.c_float(cut), _p(W), n, flavour, _p(out))
+    return sorted(out[:k].tolist())
+
+
+def compute_node(xyz, idx, math=0, svgs=False):
+    xyz = _xyz(xyz)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros(16, dtype=np.float32)
+    lib().ref_compute_node(_p(xyz), xyz.shape[1], _p(idx), len(idx), math, int(svgs), _p(out))
+    return out
+
+
+def eigen_features(ev3, svgs=False, math=0):
+    ev3 = np.ascontiguousarray(ev3, dtype=np.float32)
+    out = np.zeros(8, dtype=np.float32)
+    lib().ref_eigen_features(_p(ev3), int(svgs), math, _p(out))
+    return out
+
+
+def eigen33(m, math=0):
+    m = np.ascontiguousarray(m, dtype=np.float32).reshape(9)
+    evecs = np.zeros(9, dtype=np.float32)
+    evals = np.zeros(3, dtype=np.float32)
+    lib().ref_eigen33(_p(m), math, _p(evecs), _p(evals))
+    return evals, evecs.reshape(3, 3)
+
+
+DEVMATH = {"acos": 0, "exp": 1, "log": 2, "atan2": 3, "sin": 4, "cos": 5}
+
+
+def devmath(fn, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().ref_devmath(DEVMATH[fn], _p(x), _p(y), _p(out), x.size)
+    return out
