@@ -1,0 +1,157 @@
+/* include/vgs.h -- C-ABI of the MI355X-native VGS / SVGS segmentation engine (libvgs_hip.so).
+ *
+ * Drop-in boundary for the hot path of Yusheng-Xu/VGS-SVGS-Segmentation.  The reference has no
+ * FFI layer: its boundary is the public surface of two header-only class templates plus the
+ * Task_File line indices.  Each entry point below names the reference member
+ * function(s) it replaces (paths under the reference repo):
+ *   VS: = voxel_segmentation.h   SS: = supervoxel_segmentation.h   T: = test   IOC: = point_clouds_IO.cpp
+ * include/vgs_segmentation.hpp re-creates the two classes (same method names and call order) on top
+ * of these functions; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; all outputs are caller-allocated (size query first);
+ * every function returns a vgs_status; a context owns one HIP stream and is not re-entrant.
+ * There is no CPU fallback: without a HIP device vgs_create fails with VGS_E_HIP.
+ */
+#ifndef VGS_H_
+#define VGS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  VGS_OK = 0,
+  VGS_E_ARG = 1,          /* bad argument */
+  VGS_E_STATE = 2,        /* call-order contract violated (getVoxelNum before attributes ...) */
+  VGS_E_HIP = 3,          /* HIP runtime error / no device */
+  VGS_E_NOMEM = 4,
+  VGS_E_UNSUPPORTED = 5,  /* configuration outside the built kernels' limits (message says which) */
+  VGS_E_IO = 6
+} vgs_status;
+
+/* Parameter surface = Task_File_VGS.txt / Task_File_SVGS.txt (T:25-37, T:108-125). */
+typedef struct {
+  int32_t method;        /* 2 = VGS, 3 = SVGS (task line 24) */
+  float voxel_size;      /* line 28 */
+  float graph_size;      /* VGS line 30, SVGS line 32 */
+  float sig_p, sig_n, sig_o, sig_e, sig_c, sig_w;
+  float cut_thred;
+  int32_t points_min, adjacency_min, voxels_min;
+  float seed_size;       /* SVGS line 30 */
+  float color_impt, spatial_impt, normal_impt; /* SVGS sig_a, sig_b, sig_c(2nd) lines 46,48,50 */
+  int32_t q7_count_as_index; /* 1 = reproduce closestCheck reading the neighbour count as a voxel id (VS:2243) */
+  int32_t device;        /* HIP device ordinal */
+} vgs_params;
+
+typedef struct vgs_ctx vgs_ctx;
+
+/* counts returned by vgs_get_counts */
+enum {
+  VGS_N_POINTS = 0,      /* getCloudPointNum()  VS:94 */
+  VGS_N_FINITE = 1,      /* points that entered the octree */
+  VGS_N_VOXELS = 2,      /* getVoxelNum()       VS:104 */
+  VGS_N_USED = 3,        /* voxels with > points_min points (VS:322) */
+  VGS_N_ADJ = 4,         /* sum of adjacency list lengths over used voxels */
+  VGS_N_CLUSTERS = 5,    /* getClusterNum()     VS:111 (all clusters, singletons included) */
+  VGS_N_KEPT = 6,        /* clusters with > voxels_min voxels = getClusterIdx().size()  VS:969 */
+  VGS_N_PAIRS = 7,       /* pair affinities evaluated by the local-graph kernel */
+  VGS_N_DEPTH = 8,       /* octree depth */
+  VGS_N_ISOLATED = 9,    /* closestCheck candidates */
+  VGS_N_REATTACHED = 10, /* closestCheck successes */
+  VGS_N_SUPERVOXELS = 11,
+  VGS_N_COUNTS = 16
+};
+
+/* stage timers (milliseconds, HIP events on the context's stream) */
+enum {
+  VGS_T_VOXELIZE = 0, VGS_T_FEATURES = 1, VGS_T_ADJACENCY = 2, VGS_T_LOCALCUT = 3, VGS_T_MERGE = 4,
+  VGS_T_LABELS = 5, VGS_T_TOTAL = 6, VGS_T_LOCALCUT_KERNEL = 7, VGS_T_SUPERVOXEL = 8, VGS_T_COUNT = 12
+};
+
+/* ---- parameters ------------------------------------------------------------------------ */
+vgs_status vgs_params_default_vgs(vgs_params* p);   /* Task_File_VGS.txt values  */
+vgs_status vgs_params_default_svgs(vgs_params* p);  /* Task_File_SVGS.txt values */
+/* inputTaskTxtFile + the fixed line indices of segmentationVGS/SVGS (IOC:148-169, T:25-37, T:108-125);
+ * strips CR; in_name/out_name (may be NULL) receive lines 15 and 21. */
+vgs_status vgs_parse_task_file(const char* path, vgs_params* p, char* in_name, char* out_name, int name_cap);
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* VoxelBasedSegmentation(res) / SuperVoxelBasedSegmentation(res) ctor + setVoxelSize (+ setSupervoxelSize,
+ * setGraphSize) (VS:84,124  SS:85,143-164) */
+vgs_status vgs_create(const vgs_params* p, vgs_ctx** out);
+void vgs_destroy(vgs_ctx* ctx);
+/* The reference passes parameters when a stage is called (setVoxelSize VS:124, findAllVoxelAdjacency(graph_size)
+ * VS:223, segmentVoxelCloudWithGraphModel(cut, sigmas) VS:372).  Replaces the context's parameters; stages whose
+ * inputs changed must be re-run (the context's stage state is rolled back accordingly). method/device are fixed. */
+vgs_status vgs_set_params(vgs_ctx* ctx, const vgs_params* p);
+const char* vgs_last_error_string(const vgs_ctx* ctx); /* ctx may be NULL: last create error */
+
+/* ---- input: setInputCloud + getCloudPointNum (T:52-53, VS:94) ---------------------------- */
+/* stride_bytes 12 (packed xyz) or 16 (pcl::PointXYZ).  Host variant copies once to HBM. */
+vgs_status vgs_set_points(vgs_ctx* ctx, const float* xyz_host, int64_t n, int32_t stride_bytes);
+/* device variant: no copy, the caller keeps the buffer alive and unchanged until results are read */
+vgs_status vgs_set_points_device(vgs_ctx* ctx, const float* xyz_dev, int64_t n, int32_t stride_bytes);
+
+/* ---- VGS stages, in the reference's call order (T:54-74) --------------------------------- */
+vgs_status vgs_voxelize(vgs_ctx* ctx);   /* addPointsFromInputCloud + getBoundingBox/setBoundingBox + setVoxelCenters + getVoxelNum (T:54-62, VS:146-189) */
+vgs_status vgs_features(vgs_ctx* ctx);   /* calcualteVoxelCloudAttributes (VS:290-369) */
+vgs_status vgs_adjacency(vgs_ctx* ctx);  /* findAllVoxelAdjacency(graph_size) (VS:223-265) */
+vgs_status vgs_segment(vgs_ctx* ctx);    /* segmentVoxelCloudWithGraphModel (VS:372-421) + drawColorMapofPointsinClusters' cluster filter (VS:963-1009) */
+vgs_status vgs_run(vgs_ctx* ctx);        /* all stages for ctx's method (segmentationVGS T:51-76 / segmentationSVGS T:138-160) */
+
+/* ---- SVGS ------------------------------------------------------------------------------- */
+/* segmentSupervoxelCloudWithGraphModel from a caller-supplied supervoxel labelling (what
+ * pcl::SupervoxelClustering::getLabeledCloud returns, SS:283): labels_dev/labels_host hold one int32 per
+ * point, 0 = unassigned; max_label = getMaxLabel().  (SS:279-421) */
+vgs_status svgs_set_supervoxel_labels(vgs_ctx* ctx, const int32_t* labels_host, int32_t max_label);
+vgs_status svgs_supervoxels(vgs_ctx* ctx);  /* createSupervoxels: VCCS-style clustering on the GPU (SS:245-331) */
+vgs_status svgs_segment(vgs_ctx* ctx);      /* attributes + neighbours + local cuts + merge (SS:362-421) */
+
+/* ---- results ---------------------------------------------------------------------------- */
+vgs_status vgs_get_counts(vgs_ctx* ctx, int64_t* counts /* VGS_N_COUNTS */);
+vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
+vgs_status vgs_get_bbox(vgs_ctx* ctx, double* min3_max3);                 /* getBoundingBox (T:56) */
+/* voxel table in leaf order: key 3*V, start V+1 (offsets into point_idx), point_idx N' ; any may be NULL */
+vgs_status vgs_get_voxel_table(vgs_ctx* ctx, uint32_t* key, int32_t* start, int32_t* point_idx);
+vgs_status vgs_get_voxel_centers(vgs_ctx* ctx, float* center3V);          /* getVoxelCenters (VS:191) */
+vgs_status vgs_get_point_voxel(vgs_ctx* ctx, int32_t* voxel_of_point /* N, -1 = not in octree */);
+/* per-node attributes (voxels for VGS, supervoxels for SVGS): centroid 3*V, normal 3*V, eigen 8*V, used V */
+vgs_status vgs_get_attributes(vgs_ctx* ctx, float* centroid, float* normal, float* eigen8, uint8_t* used);
+/* ragged lists, two-call protocol: pass idx == NULL to get offsets (n_nodes+1, int64) and the total first.
+ * which: 0 adjacency (getOneVoxelAdjacency order, VS:268; used nodes only), 1 connect lists after the local cut,
+ *        2 after crossValidation (VS:2111), 3 after closestCheck (VS:2181) */
+vgs_status vgs_get_lists(vgs_ctx* ctx, int32_t which, int64_t* offsets, int32_t* idx);
+vgs_status vgs_get_node_labels(vgs_ctx* ctx, int32_t* component_root /* V: smallest node id of its cluster */,
+                               int32_t* kept_label /* V: index into kept clusters or -1 */);
+vgs_status vgs_get_point_labels(vgs_ctx* ctx, int32_t* labels /* N host; -1 = dropped */);
+vgs_status vgs_get_point_labels_device(vgs_ctx* ctx, const int32_t** labels_dev /* N, valid until next run */);
+/* getClusterIdx (VS:117): offsets (kept+1, int64) and point indices grouped by cluster (cluster order =
+ * ascending smallest voxel id, as the reference; inside a cluster ascending voxel id then point index) */
+vgs_status vgs_get_clusters(vgs_ctx* ctx, int64_t* offsets, int32_t* point_idx);
+
+/* ---- multi-GPU support (spatial tiles) -------------------------------------- */
+/* Shared grid: every rank bins on the grid whose growth state is chained rank to rank. */
+typedef struct { double min[3]; uint64_t shift[3]; int32_t depth; int32_t defined; } vgs_grid_state;
+vgs_status vgs_grid_state_init(vgs_grid_state* g);
+/* advance g over this context's points (in index order), i.e. what inserting them after all earlier ranks'
+ * points does to the octree box; call on rank r after receiving g from rank r-1 */
+vgs_status vgs_grid_advance(vgs_ctx* ctx, vgs_grid_state* g);
+/* pin the final grid before vgs_voxelize (all ranks use the state after the last rank) */
+vgs_status vgs_set_grid(vgs_ctx* ctx, const vgs_grid_state* g);
+/* mark which voxels this rank owns: those whose centre lies in [lo, hi) in x and y */
+vgs_status vgs_set_owned_region(vgs_ctx* ctx, const double* lo_xy, const double* hi_xy);
+/* boundary records after vgs_segment: for every final connection (i,k) with i owned and k not owned:
+ * (global voxel code of i, local root of i, global voxel code of k); plus per owned root: (root, owned voxel count) */
+vgs_status vgs_get_boundary(vgs_ctx* ctx, int64_t* n_edges, uint64_t* edge_code_i, int32_t* edge_root_i, uint64_t* edge_code_k);
+vgs_status vgs_get_owned_roots(vgs_ctx* ctx, int64_t* n_roots, int32_t* root, int32_t* owned_voxels, uint64_t* root_code);
+vgs_status vgs_lookup_codes(vgs_ctx* ctx, const uint64_t* codes, int64_t n, int32_t* voxel_id /* -1 if absent */,
+                            int32_t* root_of, uint8_t* owned);
+/* relabel points with a caller-computed global label per local root (-1 = dropped) */
+vgs_status vgs_apply_root_labels(vgs_ctx* ctx, const int32_t* root, const int32_t* label, int64_t n_roots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGS_H_ */

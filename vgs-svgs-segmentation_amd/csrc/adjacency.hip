@@ -1,0 +1,168 @@
+// adjacency.hip -- stage a4: radius graph over voxel centres.
+// Replaces buildVoxelCentersKdtree + findAllVoxelAdjacency + getOneVoxelAdjacency
+// (voxel_segmentation.h:223-287, 1742-1747); FLANN radius-search semantics per SURVEY.md B.2:
+// float d2 = (dx*dx + dy*dy) + dz*dz between centres, keep d2 < float(r*r), order by (d2, id).
+//
+// Voxel centres lie on a lattice, so the kd-tree is replaced by a hash of the voxel codes and a fixed
+// ball of integer offsets: one wavefront per used voxel probes the ball (coalesced offset table,
+// L2-resident hash), keeps what the float predicate accepts, sorts the survivors in LDS (bitonic on
+// 64-bit keys d2bits<<32 | id) and writes one contiguous row of the adjacency table.
+// Lists are produced for used voxels only: nothing downstream reads an unused voxel's list
+// (local graphs VS:376-380, crossValidation VS:2117, closestCheck VS:2199 all start from used voxels).
+#include <algorithm>
+#include <vector>
+
+#include "vgs_context.hpp"
+
+__device__ __forceinline__ uint32_t hash_slot(uint64_t code, uint32_t hbits) {
+  return (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> (64 - hbits));
+}
+
+__global__ void k_hash_insert(const uint64_t* __restrict__ vox_code, int64_t V, unsigned long long* __restrict__ hkey,
+                              uint32_t* __restrict__ hval, uint32_t hbits) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const unsigned long long key = vox_code[v] + 1ull;  // 0 = empty
+  const uint32_t mask = (1u << hbits) - 1u;
+  uint32_t s = hash_slot(key, hbits);
+  while (true) {
+    unsigned long long prev = atomicCAS(&hkey[s], 0ull, key);
+    if (prev == 0ull) { hval[s] = (uint32_t)v; return; }
+    s = (s + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ int hash_find(const uint64_t* __restrict__ hkey, const uint32_t* __restrict__ hval, uint32_t hbits,
+                                         uint64_t code) {
+  const uint64_t key = code + 1ull;
+  const uint32_t mask = (1u << hbits) - 1u;
+  uint32_t s = hash_slot(key, hbits);
+  while (true) {
+    uint64_t k = hkey[s];
+    if (k == key) return (int)hval[s];
+    if (k == 0ull) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// one wavefront (64-thread workgroup) per used voxel
+template <int CAP>
+__global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids,
+                                                  int64_t U, const uint64_t* __restrict__ hkey, const uint32_t* __restrict__ hval,
+                                                  uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int depth,
+                                                  float res_f, float min_x, float min_y, float min_z, float r2,
+                                                  const NodeRec* __restrict__ node, int adj_stride,
+                                                  uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
+                                                  uint32_t* __restrict__ adj_mused) {
+  __shared__ uint64_t lst[CAP];
+  const int lane = threadIdx.x;
+  const int64_t u = blockIdx.x;
+  if (u >= U) return;
+  const uint32_t i = used_ids[u];
+  const uint64_t code = vox_code[i];
+  const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
+  const float cx = vm_voxel_center(kx, res_f, min_x), cy = vm_voxel_center(ky, res_f, min_y), cz = vm_voxel_center(kz, res_f, min_z);
+  const uint32_t lim = 1u << depth;
+  int cnt = 0, mused = 0;
+  for (int base = 0; base < n_off; base += 64) {
+    const int o = base + lane;
+    bool keep = false;
+    uint64_t key64 = 0;
+    bool is_used = false;
+    if (o < n_off) {
+      const int32_t pk = offsets[o];
+      const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
+      const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;  // wraps past 0 fail the range test
+      if (nx < lim && ny < lim && nz < lim) {
+        const int t = hash_find(hkey, hval, hbits, vm_morton(nx, ny, nz));
+        if (t >= 0) {
+          const float tx = cx - vm_voxel_center(nx, res_f, min_x);
+          const float ty = cy - vm_voxel_center(ny, res_f, min_y);
+          const float tz = cz - vm_voxel_center(nz, res_f, min_z);
+          const float d2 = (tx * tx + ty * ty) + tz * tz;
+          if (d2 < r2) {
+            keep = true;
+            key64 = ((uint64_t)vm_bits(d2) << 32) | (uint32_t)t;
+            is_used = (node[t].flags & VGS_F_EIG) != 0;
+          }
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    const unsigned long long mu = __ballot(keep && is_used);
+    if (keep) lst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key64;
+    cnt += __popcll(m);
+    mused += __popcll(mu);
+  }
+  // bitonic sort ascending on the next power of two >= cnt
+  int np = 64;
+  while (np < cnt) np <<= 1;
+  for (int k = cnt + lane; k < np; k += 64) lst[k] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1) {
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      for (int t = lane; t < (np >> 1); t += 64) {
+        const int lo = ((t / strd) * (strd << 1)) + (t % strd);
+        const int hi = lo + strd;
+        const bool up = ((lo & size) == 0);
+        const uint64_t a = lst[lo], b = lst[hi];
+        if ((a > b) == up) { lst[lo] = b; lst[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  for (int k = lane; k < cnt; k += 64) row[k] = lst[k];
+  if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
+}
+
+vgs_status vgs_stage_adjacency(vgs_ctx* c) {
+  const int64_t V = c->V, U = c->U;
+  c->counts[VGS_N_ADJ] = 0;
+  if (V == 0 || U == 0) return VGS_OK;
+  // ---- hash of voxel codes ----
+  uint32_t hbits = 4;
+  while ((1ull << hbits) < (uint64_t)(2 * V)) ++hbits;
+  c->hbits = hbits;
+  const size_t H = (size_t)1 << hbits;
+  VGS_HIP_TRY(c, c->hkey.ensure(H)); VGS_HIP_TRY(c, c->hval.ensure(H));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->hkey.p, 0, H * sizeof(uint64_t), c->stream));
+  hipLaunchKernelGGL(k_hash_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, V,
+                     (unsigned long long*)c->hkey.p, c->hval.p, hbits);
+  // ---- ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps) ----
+  const double r = (double)c->P.graph_size;
+  const double res = (double)c->P.voxel_size;
+  const float r2 = (float)(r * r);  // static_cast<float>(radius * radius) in pcl::KdTreeFLANN::radiusSearch
+  const int R = (int)std::ceil(r / res) + 1;
+  if (R > 127) { c->err = "graph_size / voxel_size > 126 voxels"; return VGS_E_UNSUPPORTED; }
+  std::vector<std::pair<int, int32_t>> offs;
+  const double lim2 = (r / res) * (r / res) * (1.0 + 1e-4) + 1e-3;  // margin over float rounding of centres
+  for (int dz = -R; dz <= R; ++dz)
+    for (int dy = -R; dy <= R; ++dy)
+      for (int dx = -R; dx <= R; ++dx) {
+        const int d2 = dx * dx + dy * dy + dz * dz;
+        if ((double)d2 <= lim2) offs.emplace_back(d2, (int32_t)((dx & 0xff) | ((dy & 0xff) << 8) | ((dz & 0xff) << 16)));
+      }
+  std::sort(offs.begin(), offs.end());
+  c->n_off = (int)offs.size();
+  std::vector<int32_t> packed(offs.size());
+  for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
+  VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
+  VGS_HIP_TRY(c, hipMemcpyAsync(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  c->adj_stride = c->n_off;
+  VGS_HIP_TRY(c, c->adj_key.ensure((size_t)U * c->adj_stride));
+  VGS_HIP_TRY(c, c->adj_cnt.ensure(U)); VGS_HIP_TRY(c, c->adj_mused.ensure(U));
+  const float res_f = c->P.voxel_size;
+  const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
+#define LAUNCH_ADJ(CAPV)                                                                                                   \
+  hipLaunchKernelGGL((k_adjacency<CAPV>), dim3((unsigned)U), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U, c->hkey.p, \
+                     c->hval.p, hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride,  \
+                     c->adj_key.p, c->adj_cnt.p, c->adj_mused.p)
+  if (c->n_off <= 1024) LAUNCH_ADJ(1024);
+  else if (c->n_off <= 8192) LAUNCH_ADJ(8192);
+  else { c->err = "neighbour ball larger than 8192 lattice offsets (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
+#undef LAUNCH_ADJ
+  VGS_HIP_TRY(c, hipGetLastError());
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vector `packed` must outlive the copy
+  return VGS_OK;
+}

@@ -1,0 +1,462 @@
+// capi.hip -- the C-ABI of include/vgs.h: parameter surface, context lifetime, stage drivers with the
+// reference's call-order contract turned into status codes, result getters (two-call size queries,
+// caller-allocated outputs).  Host code only; kernels live in the stage files.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "vgs_context.hpp"
+
+static thread_local std::string g_create_err;
+
+// time a stage with HIP events on the context's stream
+template <typename F>
+static vgs_status timed(vgs_ctx* c, int slot, F&& f) {
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  vgs_status s = f();
+  if (s != VGS_OK) return s;
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  VGS_HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+  float ms = 0.f;
+  VGS_HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->times[slot] = ms;
+  return VGS_OK;
+}
+
+extern "C" {
+
+vgs_status vgs_params_default_vgs(vgs_params* p) {
+  if (!p) return VGS_E_ARG;
+  std::memset(p, 0, sizeof(*p));
+  p->method = 2;
+  p->voxel_size = 0.15f; p->graph_size = 0.5f;
+  p->sig_p = p->sig_n = p->sig_o = p->sig_e = p->sig_c = 0.2f;
+  p->sig_w = 2.0f; p->cut_thred = 0.3f;
+  p->points_min = 10; p->adjacency_min = 3; p->voxels_min = 3;
+  p->seed_size = 0.25f; p->color_impt = 0.0f; p->spatial_impt = 0.25f; p->normal_impt = 0.75f;
+  p->q7_count_as_index = 1;
+  p->device = 0;
+  return VGS_OK;
+}
+
+vgs_status vgs_params_default_svgs(vgs_params* p) {
+  vgs_status s = vgs_params_default_vgs(p);
+  if (s != VGS_OK) return s;
+  p->method = 3;
+  p->voxel_size = 0.05f; p->seed_size = 0.25f; p->graph_size = 0.5f;
+  p->sig_w = 1.0f; p->cut_thred = 0.5f;
+  return VGS_OK;
+}
+
+// inputTaskTxtFile (IOC:148-169): every line into a vector; the drivers then index fixed line numbers.
+// Unlike the reference, CR is stripped (the shipped task files are CRLF).
+vgs_status vgs_parse_task_file(const char* path, vgs_params* p, char* in_name, char* out_name, int name_cap) {
+  if (!path || !p) return VGS_E_ARG;
+  std::ifstream f(path);
+  if (!f.is_open()) return VGS_E_IO;
+  std::vector<std::string> v;
+  std::string line;
+  while (std::getline(f, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+    v.push_back(line);
+  }
+  auto num = [&](size_t k) -> double { return k < v.size() ? std::atof(v[k].c_str()) : 0.0; };
+  auto inum = [&](size_t k) -> int { return k < v.size() ? std::atoi(v[k].c_str()) : 0; };
+  if (v.size() < 51) return VGS_E_IO;
+  const int method = inum(24);
+  if (method == 3) {
+    if (v.size() < 61) return VGS_E_IO;
+    vgs_params_default_svgs(p);
+    // T:108-125
+    p->voxel_size = (float)num(28); p->seed_size = (float)num(30); p->graph_size = (float)num(32);
+    p->sig_p = (float)num(34); p->sig_n = (float)num(36); p->sig_o = (float)num(38); p->sig_e = (float)num(40);
+    p->sig_c = (float)num(42); p->sig_w = (float)num(44);
+    p->color_impt = (float)num(46); p->spatial_impt = (float)num(48); p->normal_impt = (float)num(50);
+    p->cut_thred = (float)num(52);
+    p->points_min = (int)num(54); p->voxels_min = inum(58); p->adjacency_min = inum(60);
+  } else {
+    vgs_params_default_vgs(p);
+    // T:25-37
+    p->voxel_size = (float)num(28); p->graph_size = (float)num(30);
+    p->sig_p = (float)num(32); p->sig_n = (float)num(34); p->sig_o = (float)num(36); p->sig_e = (float)num(38);
+    p->sig_c = (float)num(40); p->sig_w = (float)num(42); p->cut_thred = (float)num(44);
+    p->points_min = inum(46); p->adjacency_min = inum(48); p->voxels_min = inum(50);
+    p->method = 2;
+  }
+  if (in_name && name_cap > 0) { std::strncpy(in_name, v[15].c_str(), name_cap - 1); in_name[name_cap - 1] = 0; }
+  if (out_name && name_cap > 0) { std::strncpy(out_name, v[21].c_str(), name_cap - 1); out_name[name_cap - 1] = 0; }
+  return VGS_OK;
+}
+
+vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
+  if (!p || !out) return VGS_E_ARG;
+  *out = nullptr;
+  if (!(p->voxel_size > 0.f) || !(p->graph_size > 0.f) || !(p->sig_w != 0.f) || (p->method != 2 && p->method != 3)) {
+    g_create_err = "vgs_create: voxel_size, graph_size must be > 0, sig_w != 0, method 2 or 3";
+    return VGS_E_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("vgs_create: no HIP device (") + hipGetErrorString(e) + "); this engine has no CPU path";
+    return VGS_E_HIP;
+  }
+  if (p->device < 0 || p->device >= ndev) { g_create_err = "vgs_create: bad device ordinal"; return VGS_E_ARG; }
+  vgs_ctx* c = new (std::nothrow) vgs_ctx();
+  if (!c) return VGS_E_NOMEM;
+  c->P = *p;
+  c->device = p->device;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_err = "vgs_create: hipSetDevice/hipStreamCreate failed";
+    delete c;
+    return VGS_E_HIP;
+  }
+  for (int i = 0; i < 8; ++i)
+    if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
+  *out = c;
+  return VGS_OK;
+}
+
+void vgs_destroy(vgs_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->owned_xyz.release(); c->d_epochs.release();
+  c->code_a.release(); c->code_b.release(); c->perm_a.release(); c->perm_b.release(); c->sort_tmp.release();
+  c->head_flag.release(); c->pt_vox.release(); c->vox_code.release(); c->vox_start.release();
+  c->xs.release(); c->ys.release(); c->zs.release();
+  c->node.release(); c->used_ids.release(); c->used_rank.release();
+  c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_key.release(); c->adj_cnt.release(); c->adj_mused.release();
+  c->conn.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
+  c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
+  for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+vgs_status vgs_set_params(vgs_ctx* c, const vgs_params* p) {
+  if (!c || !p) return VGS_E_ARG;
+  if (!(p->voxel_size > 0.f) || !(p->graph_size > 0.f) || !(p->sig_w != 0.f)) { c->err = "vgs_set_params: voxel_size, graph_size > 0, sig_w != 0"; return VGS_E_ARG; }
+  if (p->method != c->P.method || p->device != c->P.device) { c->err = "vgs_set_params: method and device are fixed at vgs_create"; return VGS_E_ARG; }
+  int keep = ST_SEGMENTED;
+  const vgs_params& o = c->P;
+  if (p->cut_thred != o.cut_thred || p->sig_p != o.sig_p || p->sig_n != o.sig_n || p->sig_o != o.sig_o || p->sig_e != o.sig_e ||
+      p->sig_c != o.sig_c || p->sig_w != o.sig_w || p->adjacency_min != o.adjacency_min || p->voxels_min != o.voxels_min ||
+      p->q7_count_as_index != o.q7_count_as_index)
+    keep = ST_ADJACENCY;
+  if (p->graph_size != o.graph_size) keep = ST_FEATURES;
+  if (p->points_min != o.points_min) keep = ST_VOXELS;
+  if (p->voxel_size != o.voxel_size || p->seed_size != o.seed_size || p->color_impt != o.color_impt ||
+      p->spatial_impt != o.spatial_impt || p->normal_impt != o.normal_impt)
+    keep = ST_POINTS;
+  if (c->stage > keep) c->stage = keep;
+  c->P = *p;
+  return VGS_OK;
+}
+
+const char* vgs_last_error_string(const vgs_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes) {
+  if (n < 0 || (stride_bytes != 12 && stride_bytes != 16)) { c->err = "set_points: n >= 0 and stride_bytes 12 or 16 required"; return VGS_E_ARG; }
+  if (n >= (int64_t)1 << 31) { c->err = "set_points: more than 2^31-1 points"; return VGS_E_UNSUPPORTED; }
+  c->N = n;
+  c->stride_f = stride_bytes / 4;
+  c->stage = ST_POINTS;
+  c->counts[VGS_N_POINTS] = n;
+  for (int i = 0; i < VGS_T_COUNT; ++i) c->times[i] = 0;
+  return VGS_OK;
+}
+
+vgs_status vgs_set_points(vgs_ctx* c, const float* xyz_host, int64_t n, int32_t stride_bytes) {
+  if (!c || (!xyz_host && n > 0)) return VGS_E_ARG;
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  vgs_status s = set_points_common(c, n, stride_bytes);
+  if (s != VGS_OK) return s;
+  VGS_HIP_TRY(c, c->owned_xyz.ensure((size_t)n * c->stride_f + 4));
+  if (n > 0) VGS_HIP_TRY(c, hipMemcpyAsync(c->owned_xyz.p, xyz_host, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->xyz = c->owned_xyz.p;
+  return VGS_OK;
+}
+
+vgs_status vgs_set_points_device(vgs_ctx* c, const float* xyz_dev, int64_t n, int32_t stride_bytes) {
+  if (!c || (!xyz_dev && n > 0)) return VGS_E_ARG;
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  vgs_status s = set_points_common(c, n, stride_bytes);
+  if (s != VGS_OK) return s;
+  c->xyz = xyz_dev;
+  return VGS_OK;
+}
+
+vgs_status vgs_voxelize(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_POINTS) { c->err = "vgs_voxelize: no input cloud (setInputCloud/getCloudPointNum first)"; return VGS_E_STATE; }
+  vgs_status s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_voxelize(c); });
+  if (s == VGS_OK) c->stage = ST_VOXELS;
+  return s;
+}
+
+vgs_status vgs_features(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_VOXELS) { c->err = "vgs_features: voxel table missing (setVoxelCenters/getVoxelNum must precede calcualteVoxelCloudAttributes)"; return VGS_E_STATE; }
+  vgs_status s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); });
+  if (s == VGS_OK) c->stage = ST_FEATURES;
+  return s;
+}
+
+vgs_status vgs_adjacency(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_FEATURES) { c->err = "vgs_adjacency: attributes missing"; return VGS_E_STATE; }
+  vgs_status s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); });
+  if (s == VGS_OK) c->stage = ST_ADJACENCY;
+  return s;
+}
+
+vgs_status vgs_segment(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_ADJACENCY) { c->err = "vgs_segment: adjacency missing (findAllVoxelAdjacency first)"; return VGS_E_STATE; }
+  vgs_status s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); });
+  if (s != VGS_OK) return s;
+  s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); });
+  if (s == VGS_OK) c->stage = ST_SEGMENTED;
+  return s;
+}
+
+vgs_status vgs_run(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->P.method == 3) {
+    vgs_status s = svgs_supervoxels(c);
+    if (s != VGS_OK) return s;
+    return svgs_segment(c);
+  }
+  vgs_status s;
+  if ((s = vgs_voxelize(c)) != VGS_OK) return s;
+  if ((s = vgs_features(c)) != VGS_OK) return s;
+  if ((s = vgs_adjacency(c)) != VGS_OK) return s;
+  if ((s = vgs_segment(c)) != VGS_OK) return s;
+  c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] +
+                          c->times[VGS_T_MERGE];
+  return VGS_OK;
+}
+
+// ---- SVGS (to be widened: SURVEY.md 8 rows a12-a15) ---------------------------------------
+vgs_status svgs_set_supervoxel_labels(vgs_ctx* c, const int32_t*, int32_t) {
+  if (!c) return VGS_E_ARG;
+  c->err = "SVGS path not built yet";
+  return VGS_E_UNSUPPORTED;
+}
+vgs_status svgs_supervoxels(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  c->err = "SVGS path not built yet";
+  return VGS_E_UNSUPPORTED;
+}
+vgs_status svgs_segment(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  c->err = "SVGS path not built yet";
+  return VGS_E_UNSUPPORTED;
+}
+
+// ---- results ------------------------------------------------------------------------------
+vgs_status vgs_get_counts(vgs_ctx* c, int64_t* counts) {
+  if (!c || !counts) return VGS_E_ARG;
+  if (c->stage >= ST_ADJACENCY && c->U > 0 && c->counts[VGS_N_ADJ] == 0) {
+    std::vector<uint32_t> cnt((size_t)c->U);
+    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    int64_t e = 0;
+    for (uint32_t x : cnt) e += x;
+    c->counts[VGS_N_ADJ] = e;
+  }
+  for (int i = 0; i < VGS_N_COUNTS; ++i) counts[i] = c->counts[i];
+  return VGS_OK;
+}
+
+vgs_status vgs_get_stage_times(vgs_ctx* c, double* ms) {
+  if (!c || !ms) return VGS_E_ARG;
+  for (int i = 0; i < VGS_T_COUNT; ++i) ms[i] = c->times[i];
+  return VGS_OK;
+}
+
+vgs_status vgs_get_bbox(vgs_ctx* c, double* b) {
+  if (!c || !b) return VGS_E_ARG;
+  if (c->stage < ST_VOXELS) { c->err = "vgs_get_bbox: voxelize first"; return VGS_E_STATE; }
+  for (int a = 0; a < 3; ++a) { b[a] = c->box.min[a]; b[3 + a] = c->box.max[a]; }
+  return VGS_OK;
+}
+
+vgs_status vgs_get_voxel_table(vgs_ctx* c, uint32_t* key, int32_t* start, int32_t* point_idx) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_VOXELS) { c->err = "vgs_get_voxel_table: voxelize first"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  if (key && c->V > 0) {
+    std::vector<uint64_t> code((size_t)c->V);
+    VGS_HIP_TRY(c, hipMemcpy(code.data(), c->vox_code.p, code.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t v = 0; v < c->V; ++v) {
+      key[3 * v + 0] = vm_compact21(code[v] >> 2);
+      key[3 * v + 1] = vm_compact21(code[v] >> 1);
+      key[3 * v + 2] = vm_compact21(code[v]);
+    }
+  }
+  if (start) {
+    if (c->V > 0) VGS_HIP_TRY(c, hipMemcpy(start, c->vox_start.p, (size_t)(c->V + 1) * 4, hipMemcpyDeviceToHost));
+    else start[0] = 0;
+  }
+  if (point_idx && c->Nf > 0) VGS_HIP_TRY(c, hipMemcpy(point_idx, c->perm_b.p, (size_t)c->Nf * 4, hipMemcpyDeviceToHost));
+  return VGS_OK;
+}
+
+vgs_status vgs_get_voxel_centers(vgs_ctx* c, float* center) {
+  if (!c || !center) return VGS_E_ARG;
+  if (c->stage < ST_VOXELS) { c->err = "vgs_get_voxel_centers: voxelize first"; return VGS_E_STATE; }
+  if (c->V == 0) return VGS_OK;
+  std::vector<uint64_t> code((size_t)c->V);
+  VGS_HIP_TRY(c, hipMemcpy(code.data(), c->vox_code.p, code.size() * 8, hipMemcpyDeviceToHost));
+  const float res_f = c->P.voxel_size;
+  const float mn[3] = {(float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2]};
+  for (int64_t v = 0; v < c->V; ++v) {
+    center[3 * v + 0] = vm_voxel_center(vm_compact21(code[v] >> 2), res_f, mn[0]);
+    center[3 * v + 1] = vm_voxel_center(vm_compact21(code[v] >> 1), res_f, mn[1]);
+    center[3 * v + 2] = vm_voxel_center(vm_compact21(code[v]), res_f, mn[2]);
+  }
+  return VGS_OK;
+}
+
+vgs_status vgs_get_point_voxel(vgs_ctx* c, int32_t* out) {
+  if (!c || !out) return VGS_E_ARG;
+  if (c->stage < ST_VOXELS) { c->err = "vgs_get_point_voxel: voxelize first"; return VGS_E_STATE; }
+  if (c->N == 0) return VGS_OK;
+  std::vector<uint32_t> perm((size_t)c->N), pv((size_t)c->N);
+  VGS_HIP_TRY(c, hipMemcpy(perm.data(), c->perm_b.p, perm.size() * 4, hipMemcpyDeviceToHost));
+  VGS_HIP_TRY(c, hipMemcpy(pv.data(), c->pt_vox.p, pv.size() * 4, hipMemcpyDeviceToHost));
+  for (int64_t j = 0; j < c->N; ++j) out[perm[j]] = (pv[j] == 0xffffffffu) ? -1 : (int32_t)pv[j];
+  return VGS_OK;
+}
+
+vgs_status vgs_get_attributes(vgs_ctx* c, float* centroid, float* normal, float* eigen8, uint8_t* used) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_FEATURES) { c->err = "vgs_get_attributes: features first"; return VGS_E_STATE; }
+  if (c->V == 0) return VGS_OK;
+  std::vector<NodeRec> nd((size_t)c->V);
+  VGS_HIP_TRY(c, hipMemcpy(nd.data(), c->node.p, nd.size() * sizeof(NodeRec), hipMemcpyDeviceToHost));
+  for (int64_t v = 0; v < c->V; ++v) {
+    for (int a = 0; a < 3; ++a) {
+      if (centroid) centroid[3 * v + a] = nd[v].c[a];
+      if (normal) normal[3 * v + a] = nd[v].n[a];
+    }
+    if (eigen8) for (int a = 0; a < 8; ++a) eigen8[8 * v + a] = nd[v].f[a];
+    if (used) used[v] = (nd[v].flags & VGS_F_EIG) ? 1 : 0;
+  }
+  return VGS_OK;
+}
+
+vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* idx) {
+  if (!c || !offsets || which < 0 || which > 3) return VGS_E_ARG;
+  const int need = which == 0 ? ST_ADJACENCY : ST_SEGMENTED;
+  if (c->stage < need) { c->err = "vgs_get_lists: stage not reached"; return VGS_E_STATE; }
+  const int64_t V = c->V, U = c->U;
+  std::vector<uint32_t> used_ids((size_t)U), cnt((size_t)U);
+  std::vector<uint64_t> keys;
+  std::vector<uint8_t> flag;
+  std::vector<int32_t> attach;
+  if (U > 0) {
+    VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    keys.resize((size_t)U * c->adj_stride);
+    VGS_HIP_TRY(c, hipMemcpy(keys.data(), c->adj_key.p, keys.size() * 8, hipMemcpyDeviceToHost));
+    if (which >= 1) {
+      flag.resize((size_t)U * c->adj_stride);
+      const uint8_t* src = c->conn.p + (which >= 2 ? (size_t)U * c->adj_stride : 0);
+      VGS_HIP_TRY(c, hipMemcpy(flag.data(), src, flag.size(), hipMemcpyDeviceToHost));
+    }
+    if (which == 3) {
+      attach.resize((size_t)V);
+      VGS_HIP_TRY(c, hipMemcpy(attach.data(), c->attach.p, (size_t)V * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  // per-voxel lists; closestCheck appends (VS:2293-2294): i gets its target, the target gets i, in voxel order
+  std::vector<std::vector<int32_t>> L((size_t)V);
+  for (int64_t u = 0; u < U; ++u) {
+    const uint32_t i = used_ids[u];
+    for (uint32_t k = 0; k < cnt[u]; ++k) {
+      const size_t s = (size_t)u * c->adj_stride + k;
+      if (which == 0 || flag[s]) L[i].push_back((int32_t)(uint32_t)keys[s]);
+    }
+  }
+  if (which == 3)
+    for (int64_t i = 0; i < V; ++i)
+      if (attach[i] >= 0) { L[i].push_back(attach[i]); L[attach[i]].push_back((int32_t)i); }
+  int64_t o = 0;
+  for (int64_t v = 0; v < V; ++v) {
+    offsets[v] = o;
+    if (idx) std::memcpy(idx + o, L[v].data(), L[v].size() * 4);
+    o += (int64_t)L[v].size();
+  }
+  offsets[V] = o;
+  return VGS_OK;
+}
+
+vgs_status vgs_get_node_labels(vgs_ctx* c, int32_t* root, int32_t* kept_label) {
+  if (!c) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_node_labels: segment first"; return VGS_E_STATE; }
+  if (c->V == 0) return VGS_OK;
+  if (root) VGS_HIP_TRY(c, hipMemcpy(root, c->parent.p, (size_t)c->V * 4, hipMemcpyDeviceToHost));
+  if (kept_label) VGS_HIP_TRY(c, hipMemcpy(kept_label, c->vox_label.p, (size_t)c->V * 4, hipMemcpyDeviceToHost));
+  return VGS_OK;
+}
+
+vgs_status vgs_get_point_labels(vgs_ctx* c, int32_t* labels) {
+  if (!c || !labels) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_point_labels: segment first"; return VGS_E_STATE; }
+  if (c->N > 0) VGS_HIP_TRY(c, hipMemcpy(labels, c->pt_label.p, (size_t)c->N * 4, hipMemcpyDeviceToHost));
+  return VGS_OK;
+}
+
+vgs_status vgs_get_point_labels_device(vgs_ctx* c, const int32_t** labels_dev) {
+  if (!c || !labels_dev) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_point_labels_device: segment first"; return VGS_E_STATE; }
+  *labels_dev = c->pt_label.p;
+  return VGS_OK;
+}
+
+vgs_status vgs_get_clusters(vgs_ctx* c, int64_t* offsets, int32_t* point_idx) {
+  if (!c || !offsets) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_clusters: segment first (drawColorMapofPointsinClusters precedes getClusterIdx, VS:1006)"; return VGS_E_STATE; }
+  const int64_t K = c->counts[VGS_N_KEPT];
+  std::vector<int64_t> cnt((size_t)K + 1, 0);
+  std::vector<uint32_t> perm((size_t)c->Nf), pv((size_t)c->Nf);
+  std::vector<int32_t> vl((size_t)c->V);
+  if (c->Nf > 0) {
+    VGS_HIP_TRY(c, hipMemcpy(perm.data(), c->perm_b.p, perm.size() * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(pv.data(), c->pt_vox.p, pv.size() * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(vl.data(), c->vox_label.p, vl.size() * 4, hipMemcpyDeviceToHost));
+  }
+  for (int64_t j = 0; j < c->Nf; ++j) { const int32_t l = vl[pv[j]]; if (l >= 0) cnt[l + 1]++; }
+  for (int64_t k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+  for (int64_t k = 0; k <= K; ++k) offsets[k] = cnt[k];
+  if (point_idx) {
+    std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+    // sorted positions run over voxels in ascending id and points in ascending index inside a voxel
+    for (int64_t j = 0; j < c->Nf; ++j) { const int32_t l = vl[pv[j]]; if (l >= 0) point_idx[cur[l]++] = (int32_t)perm[j]; }
+  }
+  return VGS_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------
+vgs_status vgs_grid_state_init(vgs_grid_state* g) {
+  if (!g) return VGS_E_ARG;
+  std::memset(g, 0, sizeof(*g));
+  return VGS_OK;
+}
+
+vgs_status vgs_grid_advance(vgs_ctx* c, vgs_grid_state*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_set_grid(vgs_ctx* c, const vgs_grid_state*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_set_owned_region(vgs_ctx* c, const double*, const double*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_get_boundary(vgs_ctx* c, int64_t*, uint64_t*, int32_t*, uint64_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_get_owned_roots(vgs_ctx* c, int64_t*, int32_t*, int32_t*, uint64_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_lookup_codes(vgs_ctx* c, const uint64_t*, int64_t, int32_t*, int32_t*, uint8_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t*, const int32_t*, int64_t) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
+
+}  // extern "C"

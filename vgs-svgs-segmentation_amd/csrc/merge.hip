@@ -1,0 +1,320 @@
+// merge.hip -- stages a8-a11: mutual-connection filter, isolated-voxel re-attachment, connected
+// components, cluster size filter and per-point labels.
+// Replaces crossValidation (voxel_segmentation.h:2111-2179), closestCheck (VS:2181-2303),
+// clusteringVoxels + recursionSearch (VS:2032-2099) and the cluster filter / point lists of
+// drawColorMapofPointsinClusters (VS:963-1009); SVGS twins SS:2142-2305, 2057-2130.
+//
+// The reference's sequential control flow becomes data-parallel:
+//   * crossValidation is the symmetric intersection of the connect lists, one lane per
+//     adjacency slot, the reverse slot found by binary search on the (d2, id) sort key (d2 is symmetric);
+//   * closestCheck mutates lists while scanning voxels in order; its only order dependence is that a
+//     re-attached voxel becomes an eligible target for LATER voxels.  "re-attachment succeeds" is therefore a
+//     monotone fixed point over ascending ids, iterated in parallel; each voxel then picks its target among
+//     the voxels eligible at its turn (ties: last in scan order, `>=` at VS:2281);
+//   * the recursive DFS becomes a lock-free union-find (hook larger root under smaller) over the mutual and
+//     re-attachment edges; the root of a component is its smallest voxel id, which is also the order in
+//     which the reference discovers clusters (VS:2064).
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "vgs_context.hpp"
+
+struct MgParams {
+  VgsWeightParams W;
+  int adjacency_min;
+  int q7;
+  int64_t V;
+};
+
+// ------------------------------------------------------------------ crossValidation
+__global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_ids, const uint32_t* __restrict__ used_rank, int64_t U,
+                                              const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
+                                              int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
+                                              uint32_t* __restrict__ csize) {
+  const int64_t u = blockIdx.x;
+  if (u >= U) return;
+  const int lane = threadIdx.x;
+  const uint32_t i = used_ids[u];
+  const int n = (int)adj_cnt[u];
+  const uint64_t* row = adj_key + u * adj_stride;
+  const uint8_t* crow = conn + u * adj_stride;
+  uint8_t* mrow = mutual + u * adj_stride;
+  // a list of length <= 1 is left alone (VS:2120): it is {self}
+  int len = 0;
+  for (int k = lane; k < n; k += 64) len += crow[k] ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+  int kept = 0;
+  for (int k = lane; k < n; k += 64) {
+    uint8_t mflag = 0;
+    if (crow[k]) {
+      const uint64_t key = row[k];
+      const uint32_t t = (uint32_t)key;
+      if (len <= 1 || t == i) {
+        mflag = 1;
+      } else {
+        const uint32_t ut = used_rank[t];
+        if (ut != 0xffffffffu) {
+          const uint64_t want = (key & 0xffffffff00000000ull) | (uint64_t)i;
+          const uint64_t* trow = adj_key + (int64_t)ut * adj_stride;
+          int lo = 0, hi = (int)adj_cnt[ut] - 1, found = -1;
+          while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint64_t kk = trow[mid];
+            if (kk == want) { found = mid; break; }
+            if (kk < want) lo = mid + 1; else hi = mid - 1;
+          }
+          if (found >= 0 && conn[(int64_t)ut * adj_stride + found]) mflag = 1;
+        }
+      }
+    }
+    mrow[k] = mflag;
+    kept += mflag;
+  }
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+  if (lane == 0) csize[i] = (uint32_t)kept;
+}
+
+// ------------------------------------------------------------------ closestCheck
+// flags: bit0 candidate (list == {self} and adjacency vector longer than adjacency_min), bit1 success
+__global__ void k_cc_candidates(const uint32_t* __restrict__ used_ids, int64_t U, const uint32_t* __restrict__ adj_cnt,
+                                const uint32_t* __restrict__ csize, int adjacency_min, uint8_t* __restrict__ flags,
+                                uint32_t* __restrict__ cand_list, unsigned int* __restrict__ n_cand) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  const uint32_t i = used_ids[u];
+  // voxels_adjacency_idx_[i] = [count, idx...]: its size is n + 1 (VS:2201)
+  const bool cand = (csize[i] == 1u) && ((int)adj_cnt[u] + 1 > adjacency_min);
+  if (cand) { flags[i] = 1; cand_list[atomicAdd(n_cand, 1u)] = (uint32_t)u; }
+}
+
+// scan entry j of voxel i's raw adjacency vector: j == 0 is the neighbour COUNT read as a voxel id (Q7, VS:2243)
+__device__ __forceinline__ int cc_entry(int j, int n, const uint64_t* row, const MgParams& P) {
+  if (j == 0) {
+    if (!P.q7 || (int64_t)n >= P.V) return -1;
+    return n;
+  }
+  return (int)(uint32_t)row[j - 1];
+}
+
+template <bool CHOOSE>
+__global__ __launch_bounds__(64) void k_cc_pass(const uint32_t* __restrict__ cand_list, int n_cand, const uint32_t* __restrict__ used_ids,
+                                                const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
+                                                int adj_stride, const NodeRec* __restrict__ node, const uint32_t* __restrict__ csize,
+                                                uint8_t* __restrict__ flags, MgParams P, int32_t* __restrict__ attach,
+                                                unsigned int* __restrict__ changed) {
+  if ((int)blockIdx.x >= n_cand) return;
+  const int lane = threadIdx.x;
+  const uint32_t u = cand_list[blockIdx.x];
+  const uint32_t i = used_ids[u];
+  if (!CHOOSE && (flags[i] & 2)) return;
+  if (CHOOSE && !(flags[i] & 2)) { if (lane == 0) attach[i] = -1; return; }
+  const int n = (int)adj_cnt[u];
+  const uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  const NodeRec me = node[i];
+  float best_w = -1.0f;
+  int best_j = -1, best_t = -1;
+  bool any = false;
+  for (int j = lane; j < n + 1; j += 64) {
+    const int t = cc_entry(j, n, row, P);
+    if (t < 0) continue;
+    // eligible at voxel i's turn: list longer than one after crossValidation, or an earlier candidate that succeeded
+    const bool elig = (csize[t] > 1u) || ((uint32_t)t < i && (flags[t] & 3) == 3);
+    if (!elig) continue;
+    const float w = vm_pair_weight(me, node[t], P.W);  // distanceProbability == distanceWeight (Q8)
+    if (w != w) continue;                               // NaN >= x is false (VS:2281)
+    any = true;
+    if (CHOOSE && w >= best_w) { best_w = w; best_j = j; best_t = t; }  // ascending j per lane: later equal weights win
+  }
+  if (!CHOOSE) {
+    if (__ballot(any) != 0ull && lane == 0) { flags[i] |= 2; atomicOr(changed, 1u); }
+  } else {
+    // wave arg-max on (w, j)
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ow = __shfl_xor(best_w, o, 64);
+      const int oj = __shfl_xor(best_j, o, 64);
+      const int ot = __shfl_xor(best_t, o, 64);
+      if (ow > best_w || (ow == best_w && oj > best_j)) { best_w = ow; best_j = oj; best_t = ot; }
+    }
+    if (lane == 0) attach[i] = best_t;
+  }
+}
+
+// ------------------------------------------------------------------ connected components
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+  while (true) {
+    const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    if (atomicCAS(&parent[hi], hi, lo) == hi) return;
+  }
+}
+
+__global__ void k_iota(uint32_t* p, int64_t n) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) p[v] = (uint32_t)v;
+}
+
+__global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
+                                                     const uint32_t* __restrict__ adj_cnt, int adj_stride,
+                                                     const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
+                                                     uint32_t* __restrict__ parent) {
+  const int64_t u = blockIdx.x;
+  if (u >= U) return;
+  const uint32_t i = used_ids[u];
+  const int n = (int)adj_cnt[u];
+  const uint64_t* row = adj_key + u * adj_stride;
+  const uint8_t* mrow = mutual + u * adj_stride;
+  for (int k = threadIdx.x; k < n; k += 64) {
+    if (!mrow[k]) continue;
+    const uint32_t t = (uint32_t)row[k];
+    if (t > i) uf_union(parent, i, t);  // each mutual edge appears in both rows: union once
+  }
+  if (threadIdx.x == 0) {
+    const int32_t t = attach[i];
+    if (t >= 0) uf_union(parent, i, (uint32_t)t);
+  }
+}
+
+__global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, uint32_t* __restrict__ csz) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint32_t r = uf_find(parent, (uint32_t)v);
+  parent[v] = r;   // only shortens paths: concurrent finds stay correct
+  atomicAdd(&csz[r], 1u);
+}
+
+__global__ void k_root_flags(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ csz, int64_t V, int voxels_min,
+                             uint32_t* __restrict__ keep_flag, unsigned int* __restrict__ n_roots) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool root = false;
+  if (v < V) {
+    root = parent[v] == (uint32_t)v;
+    keep_flag[v] = (root && (int)csz[v] > voxels_min) ? 1u : 0u;  // clusters_voxel_idx_[m].size() > cluster_voxels_min_ (VS:969)
+  }
+  const unsigned long long m = __ballot(root);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_roots, (unsigned int)__popcll(m));
+}
+
+__global__ void k_voxel_labels(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ keep_flag,
+                               const uint32_t* __restrict__ keep_rank, int64_t V, int32_t* __restrict__ vox_label) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint32_t r = parent[v];
+  vox_label[v] = keep_flag[r] ? (int32_t)keep_rank[r] : -1;
+}
+
+__global__ void k_point_labels(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, const int32_t* __restrict__ vox_label,
+                               int64_t N, int32_t* __restrict__ label) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const uint32_t v = pt_vox[j];
+  label[perm[j]] = (v == 0xffffffffu) ? -1 : vox_label[v];
+}
+
+static VgsWeightParams make_weight_params_m(const vgs_params& p) {
+  VgsWeightParams W;
+  W.inv_sig_p = 1.0f / p.sig_p; W.inv_sig_n = 1.0f / p.sig_n; W.inv_sig_o = 1.0f / p.sig_o;
+  W.inv_sig_e = 1.0f / p.sig_e; W.inv_sig_c = 1.0f / p.sig_c;
+  W.inv_sig_w2 = 1.0f / (p.sig_w * p.sig_w);
+  W.svgs = (p.method == 3) ? 1 : 0;
+  return W;
+}
+
+vgs_status vgs_stage_merge(vgs_ctx* c) {
+  const int64_t V = c->V, U = c->U, N = c->N;
+  c->counts[VGS_N_CLUSTERS] = 0; c->counts[VGS_N_KEPT] = 0; c->counts[VGS_N_ISOLATED] = 0; c->counts[VGS_N_REATTACHED] = 0;
+  VGS_HIP_TRY(c, c->pt_label.ensure(N > 0 ? N : 1));
+  if (V == 0) {
+    if (N > 0) VGS_HIP_TRY(c, hipMemsetAsync(c->pt_label.p, 0xff, N * sizeof(int32_t), c->stream));
+    return VGS_OK;
+  }
+  MgParams MP;
+  MP.W = make_weight_params_m(c->P);
+  MP.adjacency_min = c->P.adjacency_min;
+  MP.q7 = c->P.q7_count_as_index;
+  MP.V = V;
+  const int TB = 256;
+  const unsigned nbV = (unsigned)((V + TB - 1) / TB);
+  VGS_HIP_TRY(c, c->csize.ensure(V)); VGS_HIP_TRY(c, c->attach.ensure(V)); VGS_HIP_TRY(c, c->cc_flags.ensure(V));
+  VGS_HIP_TRY(c, c->parent.ensure(V)); VGS_HIP_TRY(c, c->csz.ensure(V)); VGS_HIP_TRY(c, c->kept_rank.ensure(V + 1));
+  VGS_HIP_TRY(c, c->vox_label.ensure(V));
+  VGS_HIP_TRY(c, c->counters.ensure(16));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint64_t), c->stream));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->csize.p, 0, V * sizeof(uint32_t), c->stream));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->attach.p, 0xff, V * sizeof(int32_t), c->stream));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->cc_flags.p, 0, V * sizeof(uint8_t), c->stream));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->csz.p, 0, V * sizeof(uint32_t), c->stream));
+  uint8_t* mutual = nullptr;
+  unsigned int n_cand = 0, n_succ = 0;
+  if (U > 0) {
+    if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
+    mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
+    hipLaunchKernelGGL(k_cross, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+                       c->adj_stride, c->conn.p, mutual, c->csize.p);
+    // closestCheck
+    VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
+    unsigned int* d_ncand = (unsigned int*)(c->counters.p + 0);
+    unsigned int* d_changed = (unsigned int*)(c->counters.p + 1);
+    hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_cnt.p,
+                       c->csize.p, MP.adjacency_min, c->cc_flags.p, c->work_ids.p, d_ncand);
+    VGS_HIP_TRY(c, hipMemcpyAsync(&n_cand, d_ncand, 4, hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_cand > 0) {
+      for (int it = 0; it < 1 << 20; ++it) {
+        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+        hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
+                           c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
+        unsigned int ch = 0;
+        VGS_HIP_TRY(c, hipMemcpyAsync(&ch, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+        VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!ch) break;
+      }
+      hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
+                         c->adj_cnt.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
+    }
+  } else {
+    VGS_HIP_TRY(c, c->conn.ensure(16));
+  }
+  // connected components
+  hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+  if (U > 0)
+    hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+                       c->adj_stride, mutual, c->attach.p, c->parent.p);
+  hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->csz.p);
+  // cluster filter + labels
+  uint32_t* keep_flag = c->head_flag.p;  // >= N >= V entries, free after features
+  VGS_HIP_TRY(c, c->head_flag.ensure(V + 1));
+  keep_flag = c->head_flag.p;
+  unsigned int* d_nroots = (unsigned int*)(c->counters.p + 2);
+  hipLaunchKernelGGL(k_root_flags, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, c->csz.p, V, c->P.method == 3 ? -1 : c->P.voxels_min,
+                     keep_flag, d_nroots);
+  size_t bytes = 0;
+  VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+  VGS_HIP_TRY(c, c->sort_tmp.ensure(bytes));
+  VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+  hipLaunchKernelGGL(k_voxel_labels, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, keep_flag, c->kept_rank.p, V, c->vox_label.p);
+  hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
+                     N, c->pt_label.p);
+  VGS_HIP_TRY(c, hipGetLastError());
+  unsigned int n_roots = 0;
+  uint32_t last_rank = 0, last_flag = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(&n_roots, d_nroots, 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(&last_rank, c->kept_rank.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(&last_flag, keep_flag + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)n_succ;
+  c->counts[VGS_N_CLUSTERS] = n_roots;
+  c->counts[VGS_N_KEPT] = (int64_t)last_rank + last_flag;
+  c->counts[VGS_N_ISOLATED] = n_cand;
+  return VGS_OK;
+}

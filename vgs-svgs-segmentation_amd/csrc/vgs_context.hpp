@@ -1,0 +1,153 @@
+// vgs_context.hpp -- internal state of one engine context (device buffers, stream, stage state).
+// Data model in HBM (SoA, grow-only buffers reused across runs; sized for 288 GB):
+//   points      xyz_in (caller stride) -> sort keys code[N] (u64), perm[N] (u32)        voxelize
+//   voxels      vox_code[V] (u64 Morton, x-major), vox_start[V+1], node[V] (64 B record) features
+//   hash        hkey[H] (u64), hval[H] (u32), H = pow2 >= 2V                             adjacency
+//   adjacency   adj_key[U * stride] (u64: float bits of d2 << 32 | voxel id), adj_cnt[U] adjacency
+//   connect     conn[U * stride] (u8 bit0 = in L0(i), bit1 = mutual)                     local cut / merge
+//   components  parent[V], vox_label[V], point label[N]                                  merge / labels
+#ifndef VGS_CONTEXT_HPP_
+#define VGS_CONTEXT_HPP_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vgs.h"
+#include "vgs_math.h"
+
+typedef VgsNode NodeRec;
+static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
+
+// grow-only device buffer
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// PCL OctreePointCloud bounding-box growth: product-side restatement used by the host
+// part of the voxelize stage (the oracle has its own copy; the two never share code).
+struct OctreeBox {
+  double min[3] = {0, 0, 0}, max[3] = {0, 0, 0};
+  double res = 0;
+  int depth = 0;
+  bool defined = false;
+  uint64_t shift[3] = {0, 0, 0};
+  bool contains(const float* p) const;
+  void adopt(const float* p);  // grows until p fits
+};
+
+struct Epoch {  // keys of points with index >= first use this box
+  int64_t first;
+  double min[3];
+  uint64_t shift[3];
+};
+
+#define VGS_MAX_EPOCHS 96
+
+struct EpochTable {
+  int n;
+  int64_t first[VGS_MAX_EPOCHS];
+  double min[VGS_MAX_EPOCHS][3];
+  uint32_t dshift[VGS_MAX_EPOCHS][3];  // final shift - shift at insertion
+};
+
+enum Stage { ST_NONE = 0, ST_POINTS = 1, ST_VOXELS = 2, ST_FEATURES = 3, ST_ADJACENCY = 4, ST_SEGMENTED = 5 };
+
+struct vgs_ctx {
+  vgs_params P;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int stage = ST_NONE;
+
+  // input
+  const float* xyz = nullptr;  // device pointer (owned_xyz or caller's)
+  DevBuf<float> owned_xyz;
+  int64_t N = 0;
+  int stride_f = 3;
+
+  // octree
+  OctreeBox box;
+  bool grid_pinned = false;
+  std::vector<Epoch> epochs;
+  DevBuf<EpochTable> d_epochs;
+
+  // voxelize
+  DevBuf<uint64_t> code_a, code_b;
+  DevBuf<uint32_t> perm_a, perm_b;
+  DevBuf<uint8_t> sort_tmp;
+  DevBuf<uint32_t> head_flag, pt_vox;  // per sorted position
+  DevBuf<uint64_t> vox_code;
+  DevBuf<uint32_t> vox_start;
+  DevBuf<float> xs, ys, zs;  // points in sorted order (SoA)
+  int64_t Nf = 0;            // finite points
+  int64_t V = 0;
+  int code_bits = 0;
+
+  // features
+  DevBuf<NodeRec> node;
+  DevBuf<uint32_t> used_ids, used_rank;
+  int64_t U = 0;
+
+  // adjacency
+  DevBuf<uint64_t> hkey;
+  DevBuf<uint32_t> hval;
+  uint32_t hbits = 0;
+  DevBuf<int32_t> offsets;  // packed dx,dy,dz
+  int n_off = 0;
+  int adj_stride = 0;
+  DevBuf<uint64_t> adj_key;
+  DevBuf<uint32_t> adj_cnt, adj_mused;
+
+  // local cut / merge
+  DevBuf<uint8_t> conn;
+  DevBuf<uint32_t> csize;      // per voxel: list length after crossValidation (0 for unused)
+  DevBuf<int32_t> attach;      // per voxel: closestCheck target or -1
+  DevBuf<uint8_t> cc_flags;    // per voxel: bit0 candidate, bit1 success
+  DevBuf<uint32_t> parent;
+  DevBuf<uint32_t> csz, kept_rank;
+  DevBuf<int32_t> vox_label;
+  DevBuf<int32_t> pt_label;
+  DevBuf<uint64_t> counters;   // device-side counters (pairs, flags)
+  DevBuf<uint32_t> work_ids;   // scratch index lists
+
+  int64_t counts[VGS_N_COUNTS] = {0};
+  double times[VGS_T_COUNT] = {0};
+  hipEvent_t ev[8] = {nullptr};
+
+  // multi-GPU
+  bool have_region = false;
+  double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
+};
+
+#define VGS_HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess) {                                                                          \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                \
+      return VGS_E_HIP;                                                                              \
+    }                                                                                                \
+  } while (0)
+
+// stage implementations (one .hip file each)
+vgs_status vgs_stage_voxelize(vgs_ctx* c);
+vgs_status vgs_stage_features(vgs_ctx* c);
+vgs_status vgs_stage_adjacency(vgs_ctx* c);
+vgs_status vgs_stage_localcut(vgs_ctx* c);
+vgs_status vgs_stage_merge(vgs_ctx* c);
+
+#endif

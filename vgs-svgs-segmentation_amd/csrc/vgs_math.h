@@ -374,11 +374,12 @@ VGS_HD void vm_eigen_features(const float* ev, int svgs_order, float* F) {
 #define VGS_F_NRM 2u
 #define VGS_F_EIG 4u
 
-struct VgsNode {
+struct alignas(16) VgsNode {  // 64 bytes: what the local-graph kernel gathers per neighbour
   float c[3];
   float n[3];
   float f[8];
   uint32_t flags;
+  uint32_t pad;
 };
 
 struct VgsWeightParams {

@@ -1,0 +1,267 @@
+// voxelize.hip -- stage a1/a2: points -> occupied voxels in PCL leaf order.
+// Replaces OctreePointCloud::addPointsFromInputCloud + setVoxelCenters + getVoxelNum
+// (reference test:54-62, voxel_segmentation.h:146-189; octree semantics SURVEY.md B.1).
+//
+// HBM-bound integer work: one 12/16-byte read per point for the code, one stable LSD radix sort
+// of (code, index) pairs, one run-length pass, one gather of the points into leaf order (SoA) so that
+// the PCA stage reads each voxel's points as one contiguous, ascending-index run.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "vgs_context.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// OctreePointCloud bounding box growth (host side; only record-setting points reach it)
+// ---------------------------------------------------------------------------------------------
+bool OctreeBox::contains(const float* p) const {
+  if (!defined) return false;
+  for (int a = 0; a < 3; ++a)
+    if ((double)p[a] < min[a] || (double)p[a] >= max[a]) return false;
+  return true;
+}
+
+void OctreeBox::adopt(const float* p) {
+  const double eps = (double)std::numeric_limits<float>::epsilon();
+  while (true) {
+    if (!defined) {
+      // first point: box of one voxel around it, padded symmetrically to depth 1 (getKeyBitSize)
+      for (int a = 0; a < 3; ++a) { min[a] = (double)p[a] - res / 2; max[a] = (double)p[a] + res / 2; }
+      unsigned mk = 2;
+      for (int a = 0; a < 3; ++a) mk = std::max(mk, (unsigned)((max[a] - min[a]) / res));
+      depth = (int)std::min(32u, (unsigned)std::ceil(std::log2((double)mk) - eps));
+      double side = (double)(1u << depth) * res - eps;
+      for (int a = 0; a < 3; ++a) {
+        double over = (side - (max[a] - min[a])) / 2.0;
+        min[a] -= over;
+        max[a] += over;
+      }
+      defined = true;
+      continue;
+    }
+    bool hi[3], any = false;
+    for (int a = 0; a < 3; ++a) {
+      hi[a] = (double)p[a] >= max[a];
+      any = any || hi[a] || ((double)p[a] < min[a]);
+    }
+    if (!any) return;
+    double side = (double)(1u << depth) * res;
+    for (int a = 0; a < 3; ++a)
+      if (!hi[a]) { min[a] -= side; shift[a] += (1ull << depth); }  // old root becomes the upper child
+    depth++;
+    side = (double)(1u << depth) * res - eps;
+    for (int a = 0; a < 3; ++a) max[a] = min[a] + side;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return (vm_bits(x) & 0x7f800000u) != 0x7f800000u && (vm_bits(y) & 0x7f800000u) != 0x7f800000u &&
+         (vm_bits(z) & 0x7f800000u) != 0x7f800000u;
+}
+
+struct BoxD { double min[3], max[3]; int defined; };
+
+// smallest index >= start of a finite point outside the box (or any finite point if the box is undefined)
+__global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t start, int64_t n, BoxD box,
+                                  unsigned long long* __restrict__ result) {
+  unsigned long long best = ~0ull;
+  for (int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if ((unsigned long long)i > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    const float* p = xyz + i * stride_f;
+    float x = p[0], y = p[1], z = p[2];
+    if (!finite3(x, y, z)) continue;
+    bool out = !box.defined || (double)x < box.min[0] || (double)x >= box.max[0] || (double)y < box.min[1] ||
+               (double)y >= box.max[1] || (double)z < box.min[2] || (double)z >= box.max[2];
+    if (out) { best = (unsigned long long)i; break; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_down(best, o, 64);
+    best = other < best ? other : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(result, best);
+}
+
+// code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
+__global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const EpochTable* __restrict__ ep,
+                             double res, int code_bits, uint64_t* __restrict__ code, uint32_t* __restrict__ perm) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = xyz + i * stride_f;
+  float x = p[0], y = p[1], z = p[2];
+  uint64_t c = 0;
+  if (finite3(x, y, z)) {
+    int e = ep->n - 1;
+    while (e > 0 && i < ep->first[e]) --e;
+    uint32_t kx = vm_axis_key(x, ep->min[e][0], res) + ep->dshift[e][0];
+    uint32_t ky = vm_axis_key(y, ep->min[e][1], res) + ep->dshift[e][1];
+    uint32_t kz = vm_axis_key(z, ep->min[e][2], res) + ep->dshift[e][2];
+    c = (1ull << code_bits) | vm_morton(kx, ky, kz);
+  }
+  code[i] = c;
+  perm[i] = (uint32_t)i;
+}
+
+// run heads in the sorted code array (invalid codes == 0 sit at the tail of the descending order)
+__global__ void k_heads(const uint64_t* __restrict__ code, int64_t n, uint32_t* __restrict__ head,
+                        unsigned long long* __restrict__ n_valid) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (j < n) {
+    uint64_t c = code[j];
+    valid = c != 0;
+    head[j] = (valid && (j == 0 || code[j - 1] != c)) ? 1u : 0u;
+  }
+  unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_valid, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_voxel_table(const uint64_t* __restrict__ code, const uint32_t* __restrict__ head,
+                              const uint32_t* __restrict__ scan, int64_t n, uint64_t mask, uint32_t* __restrict__ pt_vox,
+                              uint64_t* __restrict__ vox_code, uint32_t* __restrict__ vox_start) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint64_t c = code[j];
+  if (c == 0) { pt_vox[j] = 0xffffffffu; return; }
+  uint32_t v = scan[j] - 1u;
+  pt_vox[j] = v;
+  if (head[j]) { vox_code[v] = c & mask; vox_start[v] = (uint32_t)j; }
+}
+
+__global__ void k_gather_points(const float* __restrict__ xyz, int stride_f, const uint32_t* __restrict__ perm, int64_t nf,
+                                float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ zs) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const float* p = xyz + (int64_t)perm[j] * stride_f;
+  xs[j] = p[0]; ys[j] = p[1]; zs[j] = p[2];
+}
+
+__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+static vgs_status grow_box(vgs_ctx* c) {
+  // Sequential semantics, parallel execution: only points that fall outside the current box change it,
+  // so the device finds the next such point and the host replays PCL's growth rule for it.
+  c->epochs.clear();
+  OctreeBox& box = c->box;
+  if (c->grid_pinned) {
+    Epoch e; e.first = 0;
+    for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
+    c->epochs.push_back(e);
+  } else {
+    box = OctreeBox();
+    box.res = (double)c->P.voxel_size;
+  }
+  VGS_HIP_TRY(c, c->counters.ensure(16));
+  unsigned long long* d_res = (unsigned long long*)c->counters.p;
+  int64_t start = 0;
+  float pt[3];
+  for (int iter = 0; iter < 4096; ++iter) {
+    unsigned long long none = ~0ull;
+    VGS_HIP_TRY(c, hipMemcpyAsync(d_res, &none, sizeof(none), hipMemcpyHostToDevice, c->stream));
+    BoxD b;
+    for (int a = 0; a < 3; ++a) { b.min[a] = box.min[a]; b.max[a] = box.max[a]; }
+    b.defined = box.defined ? 1 : 0;
+    if (start < c->N) {
+      int64_t work = c->N - start;
+      int blocks = (int)std::min<int64_t>((work + 255) / 256, 2048);
+      hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, start, c->N, b, d_res);
+    }
+    unsigned long long idx = ~0ull;
+    VGS_HIP_TRY(c, hipMemcpyAsync(&idx, d_res, sizeof(idx), hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (idx == ~0ull) break;
+    if (c->grid_pinned) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
+    VGS_HIP_TRY(c, hipMemcpy(pt, c->xyz + (int64_t)idx * c->stride_f, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    box.adopt(pt);
+    Epoch e; e.first = (int64_t)idx;
+    for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
+    c->epochs.push_back(e);
+    if ((int)c->epochs.size() >= VGS_MAX_EPOCHS) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
+    start = (int64_t)idx + 1;
+  }
+  return VGS_OK;
+}
+
+vgs_status vgs_stage_voxelize(vgs_ctx* c) {
+  const int64_t N = c->N;
+  c->V = 0; c->Nf = 0; c->U = 0;
+  vgs_status st = grow_box(c);
+  if (st != VGS_OK) return st;
+  if (c->epochs.empty()) {  // no finite point at all
+    c->counts[VGS_N_FINITE] = 0; c->counts[VGS_N_VOXELS] = 0; c->counts[VGS_N_DEPTH] = 0;
+    return VGS_OK;
+  }
+  if (c->box.depth > 21) { c->err = "octree depth > 21 (64-bit voxel codes exhausted)"; return VGS_E_UNSUPPORTED; }
+  c->code_bits = 3 * c->box.depth;
+
+  EpochTable T;
+  T.n = (int)c->epochs.size();
+  for (int e = 0; e < T.n; ++e) {
+    T.first[e] = c->epochs[e].first;
+    for (int a = 0; a < 3; ++a) {
+      T.min[e][a] = c->epochs[e].min[a];
+      T.dshift[e][a] = (uint32_t)(c->box.shift[a] - c->epochs[e].shift[a]);
+    }
+  }
+  T.first[0] = 0;
+  VGS_HIP_TRY(c, c->d_epochs.ensure(1));
+  VGS_HIP_TRY(c, hipMemcpyAsync(c->d_epochs.p, &T, sizeof(T), hipMemcpyHostToDevice, c->stream));
+
+  VGS_HIP_TRY(c, c->code_a.ensure(N)); VGS_HIP_TRY(c, c->code_b.ensure(N));
+  VGS_HIP_TRY(c, c->perm_a.ensure(N)); VGS_HIP_TRY(c, c->perm_b.ensure(N));
+  VGS_HIP_TRY(c, c->head_flag.ensure(N)); VGS_HIP_TRY(c, c->pt_vox.ensure(N));
+  const int TB = 256;
+  const unsigned nb = (unsigned)((N + TB - 1) / TB);
+  hipLaunchKernelGGL(k_make_codes, dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, c->d_epochs.p, c->box.res,
+                     c->code_bits, c->code_a.p, c->perm_a.p);
+
+  // stable LSD radix sort, descending code (= PCL LeafNodeIterator order: children visited 7 -> 0),
+  // ascending point index inside a leaf (stability)
+  size_t tmp_bytes = 0;
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->code_a.p, c->code_b.p, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
+                                                (unsigned)(c->code_bits + 1), c->stream));
+  size_t scan_bytes = 0;
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->perm_a.p, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
+  VGS_HIP_TRY(c, c->sort_tmp.ensure(std::max(tmp_bytes, scan_bytes)));
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->sort_tmp.p, tmp_bytes, c->code_a.p, c->code_b.p, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
+                                                (unsigned)(c->code_bits + 1), c->stream));
+  // sorted: code_b, perm_b
+  unsigned long long* d_cnt = (unsigned long long*)c->counters.p;
+  VGS_HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, N, c->head_flag.p, d_cnt);
+  uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
+  unsigned long long nf = 0;
+  uint32_t v_total = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_cnt, sizeof(nf), hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(&v_total, scan + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->Nf = (int64_t)nf;
+  c->V = (int64_t)v_total;
+  VGS_HIP_TRY(c, c->vox_code.ensure(c->V + 1)); VGS_HIP_TRY(c, c->vox_start.ensure(c->V + 1));
+  const uint64_t mask = (c->code_bits >= 64) ? ~0ull : ((1ull << c->code_bits) - 1ull);
+  hipLaunchKernelGGL(k_voxel_table, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, c->head_flag.p, scan, N, mask, c->pt_vox.p,
+                     c->vox_code.p, c->vox_start.p);
+  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->vox_start.p + c->V, (uint32_t)c->Nf);
+  VGS_HIP_TRY(c, c->xs.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->ys.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->zs.ensure(c->Nf + 1));
+  if (c->Nf > 0) {
+    const unsigned nbf = (unsigned)((c->Nf + TB - 1) / TB);
+    hipLaunchKernelGGL(k_gather_points, dim3(nbf), dim3(TB), 0, c->stream, c->xyz, c->stride_f, c->perm_b.p, c->Nf, c->xs.p, c->ys.p,
+                       c->zs.p);
+  }
+  VGS_HIP_TRY(c, hipGetLastError());
+  c->counts[VGS_N_FINITE] = c->Nf;
+  c->counts[VGS_N_VOXELS] = c->V;
+  c->counts[VGS_N_DEPTH] = c->box.depth;
+  return VGS_OK;
+}
