@@ -20,6 +20,8 @@
 //     not-yet-examined candidate weights picks the heaviest <= CAP edges, which are collected, sorted and
 //     merged before the next round (weights are recomputed instead of stored: flops are cheaper than HBM).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "vgs_context.hpp"
 
@@ -299,15 +301,28 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   if (tid == 0 && s_err) atomicAdd(&counters[2], 1ull);
 }
 
-// split the used voxels by the number of used neighbours
+#include "localcut_wave.hpp"
+
+// split the used voxels into three classes by the number of used neighbours (one atomic per wavefront and class)
 __global__ void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
-                           int small_max, uint32_t* __restrict__ small_ids, uint32_t* __restrict__ large_ids,
-                           unsigned int* __restrict__ n_small, unsigned int* __restrict__ n_large) {
-  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= U) return;
-  const uint32_t m = prune ? adj_mused[u] : adj_cnt[u];
-  if ((int)m <= small_max) small_ids[atomicAdd(n_small, 1u)] = (uint32_t)u;
-  else large_ids[atomicAdd(n_large, 1u)] = (uint32_t)u;
+                           int max_a, int max_b, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
+                           uint32_t* __restrict__ ids_c, unsigned int* __restrict__ n_abc) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int cls = -1;
+  if (u < U) {
+    const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
+    cls = m <= max_a ? 0 : (m <= max_b ? 1 : 2);
+  }
+  uint32_t* const outs[3] = {ids_a, ids_b, ids_c};
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long mk = __ballot(cls == k);
+    if (mk == 0ull) continue;
+    unsigned int base = 0;
+    if (lane == (__ffsll((long long)mk) - 1)) base = atomicAdd(&n_abc[k], (unsigned int)__popcll(mk));
+    base = __shfl(base, __ffsll((long long)mk) - 1, 64);
+    if (cls == k) outs[k][base + __popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)u;
+  }
 }
 
 static VgsWeightParams make_weight_params(const vgs_params& p) {
@@ -338,46 +353,78 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.prune_unused = !(w_dead > vm_cut_threshold(1.0f, LP.cut, 1)) ? 1 : 0;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure(2 * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure(4 * (size_t)U + 16));
   VGS_HIP_TRY(c, c->counters.ensure(16));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint64_t), c->stream));
-  uint32_t* small_ids = c->work_ids.p;
-  uint32_t* large_ids = c->work_ids.p + U;
-  unsigned int* d_ns = (unsigned int*)(c->counters.p + 8);
-  unsigned int* d_nl = (unsigned int*)(c->counters.p + 9);
+  uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, small LDS footprint
+  uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel
+  uint32_t* ids_c = c->work_ids.p + 2 * U;    // the rest: one workgroup per voxel (k_localcut)
+  uint32_t* ids_f = c->work_ids.p + 3 * U;    // voxels the wave kernels handed over
+  unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);
+  unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
+  constexpr int WAVE_A = 96, WAVE_B = 256, WAVE_LCAP = 512;
   constexpr int SMALL_M = 160, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_mused.p, c->adj_cnt.p, U,
-                     LP.prune_unused, SMALL_M, small_ids, large_ids, d_ns, d_nl);
-  unsigned int ns = 0, nl = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&ns, d_ns, 4, hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipMemcpyAsync(&nl, d_nl, 4, hipMemcpyDeviceToHost, c->stream));
+                     LP.prune_unused, WAVE_A, WAVE_B, ids_a, ids_b, ids_c, d_nabc);
+  unsigned int nabc[3] = {0, 0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 12, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
+  LwParams WP;
+  WP.lc = LP;
+  WP.r2_graph = c->P.graph_size * c->P.graph_size;
+  {
+    // no two members of one neighbourhood are farther apart than this (centres within graph_size of the voxel,
+    // centroids within one voxel diagonal of their centres; SVGS: centroids within graph_size)
+    const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
+    WP.d2_all = reach * reach * 1.01f;
+  }
+  WP.shell0 = 8.0f;
+  WP.grow = 2.25f;
+  auto launch_block = [&](const uint32_t* ids, unsigned int nw) -> vgs_status {
+    // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond
+    if (nw == 0) return VGS_OK;
+    {
+      auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
+      const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
+      VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+                         c->node.p, LP, c->conn.p, cnt);
+    }
+    return VGS_OK;
+  };
+  (void)SMALL_M; (void)SMALL_CAP;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-  if (ns > 0) {
-    auto kern = k_localcut<SMALL_M, SMALL_CAP, true>;
-    const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, true>();
-    VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL(kern, dim3(ns), dim3(LC_TB), sm, c->stream, small_ids, (int)ns, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, c->node.p, LP, c->conn.p, cnt);
+  if (nabc[0] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(nabc[0]), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf);
+  if (nabc[1] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(nabc[1]), dim3(64), 0, c->stream, ids_b, (int)nabc[1], c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf);
+  {
+    vgs_status st = launch_block(ids_c, nabc[2]);
+    if (st != VGS_OK) return st;
   }
-  if (nl > 0) {
-    auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
-    const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
-    VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL(kern, dim3(nl), dim3(LC_TB), sm, c->stream, large_ids, (int)nl, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, c->node.p, LP, c->conn.p, cnt);
+  unsigned int nf = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (nf > 0) {
+    vgs_status st = launch_block(ids_f, nf);
+    if (st != VGS_OK) return st;
   }
+  c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
+  c->counts[13] = nabc[0]; c->counts[14] = nabc[1]; c->counts[15] = nabc[2];
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
-  unsigned long long h[3] = {0, 0, 0};
+  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
   c->counts[VGS_N_PAIRS] = (int64_t)h[0];
+  if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5]);
   if (h[1]) { c->err = "a voxel has more than 2048 used neighbours (local-graph kernel limit)"; return VGS_E_UNSUPPORTED; }
   if (h[2]) { c->err = "degenerate neighbourhood: more than 8192 pair weights inside one 2^-22 interval"; return VGS_E_UNSUPPORTED; }
   return VGS_OK;
