@@ -9,6 +9,10 @@
 // 64-bit keys d2bits<<32 | id) and writes one contiguous row of the adjacency table.
 // Lists are produced for used voxels only: nothing downstream reads an unused voxel's list
 // (local graphs VS:376-380, crossValidation VS:2117, closestCheck VS:2199 all start from used voxels).
+// When unused voxels are inert in the local graphs (their constant dead-edge weight cannot beat a singleton's
+// threshold, checked on the host) the hot-path rows keep only the USED neighbours, still in (d2, id) order, plus
+// the full neighbour count (closestCheck needs it: VS:2201, VS:2243).  The full lists of the reference's
+// getOneVoxelAdjacency are produced on demand by the FULL instantiation (vgs_get_lists).
 #include <algorithm>
 #include <vector>
 
@@ -46,7 +50,7 @@ __device__ __forceinline__ int hash_find(const uint64_t* __restrict__ hkey, cons
 }
 
 // one wavefront (64-thread workgroup) per used voxel
-template <int CAP>
+template <int CAP, bool FULL>
 __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids,
                                                   int64_t U, const uint64_t* __restrict__ hkey, const uint32_t* __restrict__ hval,
                                                   uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int depth,
@@ -88,11 +92,12 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
         }
       }
     }
-    const unsigned long long m = __ballot(keep);
-    const unsigned long long mu = __ballot(keep && is_used);
-    if (keep) lst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key64;
+    const unsigned long long mall = __ballot(keep);
+    const bool store = FULL ? keep : (keep && is_used);
+    const unsigned long long m = __ballot(store);
+    if (store) lst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key64;
     cnt += __popcll(m);
-    mused += __popcll(mu);
+    mused += __popcll(mall);
   }
   // bitonic sort ascending on the next power of two >= cnt
   int np = 64;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   for (int size = 2; size <= np; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
       for (int t = lane; t < (np >> 1); t += 64) {
-        const int lo = ((t / strd) * (strd << 1)) + (t % strd);
+        const int lo = ((t / strd) * (strd << 1)) + (t & (strd - 1));
         const int hi = lo + strd;
         const bool up = ((lo & size) == 0);
         const uint64_t a = lst[lo], b = lst[hi];
@@ -113,14 +118,24 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   }
   uint64_t* row = adj_key + (int64_t)u * adj_stride;
   for (int k = lane; k < cnt; k += 64) row[k] = lst[k];
-  if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
+  if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }  // stored entries, all neighbours
 }
 
-vgs_status vgs_stage_adjacency(vgs_ctx* c) {
-  const int64_t V = c->V, U = c->U;
-  c->counts[VGS_N_ADJ] = 0;
-  if (V == 0 || U == 0) return VGS_OK;
-  // ---- hash of voxel codes ----
+// an edge that touches an unused voxel carries the constant weight of five distances of 100 (VS:1602-1606);
+// if that cannot beat a singleton's threshold 1 - cut the unused voxels can never merge: they are inert (exact)
+bool vgs_unused_are_inert(const vgs_params& p) {
+  VgsWeightParams W;
+  W.inv_sig_p = 1.0f / p.sig_p; W.inv_sig_n = 1.0f / p.sig_n; W.inv_sig_o = 1.0f / p.sig_o;
+  W.inv_sig_e = 1.0f / p.sig_e; W.inv_sig_c = 1.0f / p.sig_c;
+  W.inv_sig_w2 = 1.0f / (p.sig_w * p.sig_w);
+  W.svgs = (p.method == 3) ? 1 : 0;
+  const float d100[5] = {100.f, 100.f, 100.f, 100.f, 100.f};
+  const float w_dead = vm_distance_weight(d100, W);
+  return !(w_dead > vm_cut_threshold(1.0f, p.cut_thred, 1));
+}
+
+static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
+  const int64_t V = c->V;
   uint32_t hbits = 4;
   while ((1ull << hbits) < (uint64_t)(2 * V)) ++hbits;
   c->hbits = hbits;
@@ -129,10 +144,10 @@ vgs_status vgs_stage_adjacency(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipMemsetAsync(c->hkey.p, 0, H * sizeof(uint64_t), c->stream));
   hipLaunchKernelGGL(k_hash_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, V,
                      (unsigned long long*)c->hkey.p, c->hval.p, hbits);
-  // ---- ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps) ----
+  // ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps)
   const double r = (double)c->P.graph_size;
   const double res = (double)c->P.voxel_size;
-  const float r2 = (float)(r * r);  // static_cast<float>(radius * radius) in pcl::KdTreeFLANN::radiusSearch
+  *r2_out = (float)(r * r);  // static_cast<float>(radius * radius) in pcl::KdTreeFLANN::radiusSearch
   const int R = (int)std::ceil(r / res) + 1;
   if (R > 127) { c->err = "graph_size / voxel_size > 126 voxels"; return VGS_E_UNSUPPORTED; }
   std::vector<std::pair<int, int32_t>> offs;
@@ -148,21 +163,40 @@ vgs_status vgs_stage_adjacency(vgs_ctx* c) {
   std::vector<int32_t> packed(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
-  VGS_HIP_TRY(c, hipMemcpyAsync(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  VGS_HIP_TRY(c, hipMemcpy(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   c->adj_stride = c->n_off;
-  VGS_HIP_TRY(c, c->adj_key.ensure((size_t)U * c->adj_stride));
-  VGS_HIP_TRY(c, c->adj_cnt.ensure(U)); VGS_HIP_TRY(c, c->adj_mused.ensure(U));
+  return VGS_OK;
+}
+
+// full = true: every neighbour (the reference's lists); false: used neighbours only (hot path)
+vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2) {
+  const int64_t U = c->U;
   const float res_f = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
-#define LAUNCH_ADJ(CAPV)                                                                                                   \
-  hipLaunchKernelGGL((k_adjacency<CAPV>), dim3((unsigned)U), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U, c->hkey.p, \
-                     c->hval.p, hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride,  \
-                     c->adj_key.p, c->adj_cnt.p, c->adj_mused.p)
-  if (c->n_off <= 1024) LAUNCH_ADJ(1024);
-  else if (c->n_off <= 8192) LAUNCH_ADJ(8192);
+#define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
+  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3((unsigned)U), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
+                     c->hkey.p, c->hval.p, c->hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
+                     c->adj_stride, out_key, out_cnt, out_nall)
+  if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }
+  else if (c->n_off <= 8192) { if (full) LAUNCH_ADJ(8192, true); else LAUNCH_ADJ(8192, false); }
   else { c->err = "neighbour ball larger than 8192 lattice offsets (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
 #undef LAUNCH_ADJ
   VGS_HIP_TRY(c, hipGetLastError());
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vector `packed` must outlive the copy
+  return VGS_OK;
+}
+
+vgs_status vgs_stage_adjacency(vgs_ctx* c) {
+  const int64_t V = c->V, U = c->U;
+  c->counts[VGS_N_ADJ] = 0;
+  if (V == 0 || U == 0) return VGS_OK;
+  float r2 = 0.f;
+  vgs_status st = build_hash_and_offsets(c, &r2);
+  if (st != VGS_OK) return st;
+  c->adj_r2 = r2;
+  c->adj_pruned = vgs_unused_are_inert(c->P);
+  VGS_HIP_TRY(c, c->adj_key.ensure((size_t)U * c->adj_stride));
+  VGS_HIP_TRY(c, c->adj_cnt.ensure(U)); VGS_HIP_TRY(c, c->adj_mused.ensure(U));
+  st = vgs_run_adjacency(c, !c->adj_pruned, c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, r2);
+  if (st != VGS_OK) return st;
   return VGS_OK;
 }

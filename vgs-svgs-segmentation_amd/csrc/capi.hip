@@ -219,6 +219,10 @@ vgs_status vgs_adjacency(vgs_ctx* c) {
 vgs_status vgs_segment(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
   if (c->stage < ST_ADJACENCY) { c->err = "vgs_segment: adjacency missing (findAllVoxelAdjacency first)"; return VGS_E_STATE; }
+  if (c->U > 0 && vgs_unused_are_inert(c->P) != c->adj_pruned) {  // sigma/cut changed what the rows must hold
+    vgs_status sa = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); });
+    if (sa != VGS_OK) return sa;
+  }
   vgs_status s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); });
   if (s != VGS_OK) return s;
   s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); });
@@ -265,7 +269,7 @@ vgs_status vgs_get_counts(vgs_ctx* c, int64_t* counts) {
   if (!c || !counts) return VGS_E_ARG;
   if (c->stage >= ST_ADJACENCY && c->U > 0 && c->counts[VGS_N_ADJ] == 0) {
     std::vector<uint32_t> cnt((size_t)c->U);
-    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_mused.p, cnt.size() * 4, hipMemcpyDeviceToHost));
     int64_t e = 0;
     for (uint32_t x : cnt) e += x;
     c->counts[VGS_N_ADJ] = e;
@@ -362,10 +366,23 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
   std::vector<uint8_t> flag;
   std::vector<int32_t> attach;
   if (U > 0) {
+    VGS_HIP_TRY(c, hipSetDevice(c->device));
     VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     keys.resize((size_t)U * c->adj_stride);
-    VGS_HIP_TRY(c, hipMemcpy(keys.data(), c->adj_key.p, keys.size() * 8, hipMemcpyDeviceToHost));
+    if (which == 0 && c->adj_pruned) {
+      // getOneVoxelAdjacency wants every neighbour: the hot-path rows keep the used ones only, so run the FULL pass
+      DevBuf<uint64_t> fk; DevBuf<uint32_t> fc, fn;
+      VGS_HIP_TRY(c, fk.ensure(keys.size())); VGS_HIP_TRY(c, fc.ensure(U)); VGS_HIP_TRY(c, fn.ensure(U));
+      vgs_status st = vgs_run_adjacency(c, true, fk.p, fc.p, fn.p, c->adj_r2);
+      if (st == VGS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = VGS_E_HIP;
+      if (st == VGS_OK && (hipMemcpy(cnt.data(), fc.p, (size_t)U * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(keys.data(), fk.p, keys.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) st = VGS_E_HIP;
+      fk.release(); fc.release(); fn.release();
+      if (st != VGS_OK) { if (st == VGS_E_HIP) c->err = "vgs_get_lists: full adjacency pass failed"; return st; }
+    } else {
+      VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+      VGS_HIP_TRY(c, hipMemcpy(keys.data(), c->adj_key.p, keys.size() * 8, hipMemcpyDeviceToHost));
+    }
     if (which >= 1) {
       flag.resize((size_t)U * c->adj_stride);
       const uint8_t* src = c->conn.p + (which >= 2 ? (size_t)U * c->adj_stride : 0);

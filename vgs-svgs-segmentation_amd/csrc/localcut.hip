@@ -20,6 +20,7 @@
 //     not-yet-examined candidate weights picks the heaviest <= CAP edges, which are collected, sorted and
 //     merged before the next round (weights are recomputed instead of stored: flops are cheaper than HBM).
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -60,7 +61,8 @@ template <int MAXM, int CAP, bool NODES_LDS>
 __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__ work, int n_work,
                                                     const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                     int adj_stride, const NodeRec* __restrict__ node, LcParams P,
-                                                    uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters) {
+                                                    uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
+                                                    uint32_t* __restrict__ evals_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* list = (uint64_t*)smem;                 // CAP keys, descending after the sort
   uint32_t* hist = (uint32_t*)smem;                 // aliases the list between rounds
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   uint8_t* crow = conn + (int64_t)u * adj_stride;
 
   // ---- gather the (used) neighbours in adjacency order ----
-  if (tid == 0) { s_m = 0; s_err = 0; s_rdone = LC_NBIN * LC_NBIN; }
+  if (tid == 0) { s_m = 0; s_err = 0; s_rdone = LC_NBIN * LC_NBIN; evals_out[u] = 0; }
   for (int k = tid; k < n; k += LC_TB) crow[k] = 0;
   __syncthreads();
   if (wave == 0) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
     for (int size = 2; size <= np; size <<= 1) {
       for (int strd = size >> 1; strd > 0; strd >>= 1) {
         for (int t = tid; t < (np >> 1); t += LC_TB) {
-          const int lo = ((t / strd) * (strd << 1)) + (t % strd);
+          const int lo = ((t / strd) * (strd << 1)) + (t & (strd - 1));
           const int hi = lo + strd;
           const bool dn = ((lo & size) == 0);
           const uint64_t x = list[lo], y = list[hi];
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
       if (seg[c] == s0) crow[loc[c]] = 1;
   }
   for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
-  if (lane == 0 && my_pairs) atomicAdd(&counters[0], my_pairs);
+  if (lane == 0 && my_pairs) atomicAdd(&evals_out[u], (uint32_t)my_pairs);  // 4 waves, one voxel-private word
   if (tid == 0 && s_err) atomicAdd(&counters[2], 1ull);
 }
 
@@ -348,14 +350,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.cut = c->P.cut_thred;
   // an edge that touches an unused voxel carries the constant weight of five distances of 100 (VS:1602-1606);
   // if that cannot beat a singleton's threshold the unused voxels are inert and are pruned (exact)
-  float d100[5] = {100.f, 100.f, 100.f, 100.f, 100.f};
-  const float w_dead = vm_distance_weight(d100, LP.W);
-  LP.prune_unused = !(w_dead > vm_cut_threshold(1.0f, LP.cut, 1)) ? 1 : 0;
+  // (the adjacency stage already dropped the unused neighbours from the rows when that is the case)
+  if (vgs_unused_are_inert(c->P) != c->adj_pruned) { c->err = "adjacency rows do not match the current sigma/cut parameters"; return VGS_E_STATE; }
+  LP.prune_unused = 0;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
   VGS_HIP_TRY(c, c->work_ids.ensure(4 * (size_t)U + 16));
-  VGS_HIP_TRY(c, c->counters.ensure(16));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint64_t), c->stream));
+  VGS_HIP_TRY(c, c->csize.ensure((size_t)(c->V > U ? c->V : U)));  // used here as per-voxel evaluation counters (index u)
+  VGS_HIP_TRY(c, c->counters.ensure(64));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
   uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, small LDS footprint
   uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel
   uint32_t* ids_c = c->work_ids.p + 2 * U;    // the rest: one workgroup per voxel (k_localcut)
@@ -365,8 +368,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr int WAVE_A = 96, WAVE_B = 256, WAVE_LCAP = 512;
   constexpr int SMALL_M = 160, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
-  hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_mused.p, c->adj_cnt.p, U,
-                     LP.prune_unused, WAVE_A, WAVE_B, ids_a, ids_b, ids_c, d_nabc);
+  hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
+                     0, WAVE_A, WAVE_B, ids_a, ids_b, ids_c, d_nabc);
   unsigned int nabc[3] = {0, 0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 12, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -390,18 +393,19 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt);
+                         c->node.p, LP, c->conn.p, cnt, c->csize.p);
     }
     return VGS_OK;
   };
   (void)SMALL_M; (void)SMALL_CAP;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->conn.p, 0, (size_t)U * c->adj_stride, c->stream));  // connect flags start at 0
   if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(nabc[0]), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf);
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p);
   if (nabc[1] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(nabc[1]), dim3(64), 0, c->stream, ids_b, (int)nabc[1], c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf);
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_b, (int)nabc[1], c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p);
   {
     vgs_status st = launch_block(ids_c, nabc[2]);
     if (st != VGS_OK) return st;
@@ -417,14 +421,31 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   c->counts[13] = nabc[0]; c->counts[14] = nabc[1]; c->counts[15] = nabc[2];
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
-  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
-  c->counts[VGS_N_PAIRS] = (int64_t)h[0];
-  if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5]);
+  c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts live in csize until the merge stage reuses it; summed below
+  {
+    std::vector<uint32_t> ev((size_t)U);
+    VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->csize.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    long long tot = 0;
+    for (uint32_t x : ev) tot += x;
+    c->counts[VGS_N_PAIRS] = tot;
+  }
+  if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
+#ifdef VGS_PROF
+  {
+    unsigned long long pr[16];
+    VGS_HIP_TRY(c, hipMemcpy(pr, cnt + 16, sizeof(pr), hipMemcpyDeviceToHost));
+    const char* nm[16] = {"gather", "enumerate", "evaluate", "sort", "merge", "carry", "phaseB", "g_records", "rounds", "sorted_keys", "phaseB_voxels", "voxels", "merges", "sum_m", "g_row", "g_sync"};
+    fprintf(stderr, "[vgs-prof]");
+    for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.3g", nm[k], (double)pr[k]);
+    fprintf(stderr, "\n");
+  }
+#endif
   if (h[1]) { c->err = "a voxel has more than 2048 used neighbours (local-graph kernel limit)"; return VGS_E_UNSUPPORTED; }
   if (h[2]) { c->err = "degenerate neighbourhood: more than 8192 pair weights inside one 2^-22 interval"; return VGS_E_UNSUPPORTED; }
   return VGS_OK;

@@ -4,20 +4,37 @@
 // Same sequential semantics as k_localcut, different schedule.  The reference evaluates all
 // n^2 weights and sorts them, yet on a surface the cut is decided by the few hundred heaviest edges: the
 // descending scan merges the neighbourhood along its nearest-neighbour edges and then nothing can merge any more.
-// The weight is bounded by proximity alone:  D >= dist_space / sig_p  =>  w <= ub(d) = exp(-0.5 * d / sig_p / sig_w^2)
-// (VS:1736-1737; the float evaluation is monotone step by step), so pairs are evaluated in
-// shells of increasing centroid distance and the scan is advanced only down to the level ub(shell radius):
-// every edge not yet evaluated is provably lighter than that level.  Each round:
-//   1. enumerate the candidate pairs (different segments) whose squared centroid distance falls in the shell
-//      [cut_lo, cut_hi) -- 6 LDS reads and ~10 VALU per pair, no transcendental;
-//   2. evaluate the full weight only for those (one pair per lane, all lanes busy);
-//   3. bitonic-sort the edge list (new + carried over) in LDS: <= 512 keys instead of n^2;
-//   4. merge sequentially down to the level, 64 edges per step, with the segment ids / thresholds / sizes of
-//      the 64 edges held in registers: after a merge every lane patches its own copy (a handful of VALU ops,
-//      no LDS round trip), the vertex->segment table is fixed up once per step through a representative chain;
-//   5. edges lighter than the level are carried to the next round; stop when < 2 segments can still merge.
+//
+// Three facts make a lazy schedule exact:
+//  (U) proximity bounds the weight:  D >= dist_space / sig_p  =>  w <= ub(d) = exp(-0.5 * d / sig_p / sig_w^2)
+//      (VS:1736-1737; every float step of the evaluation is monotone).  Pairs are therefore evaluated
+//      in shells of increasing centroid distance and the scan only advances down to level = ub(shell radius):
+//      every edge not yet evaluated is provably lighter than the level.
+//  (F) a segment's threshold seg_int - cut/size moves only when the segment merges, and a merge needs an edge
+//      heavier than the threshold.  Once the scan is at `level`, a segment with threshold >= level is frozen for
+//      ever: its vertices leave the pair enumeration and its edges are dropped.
+//  (S) a singleton's threshold is the constant 1 - cut, so an edge with w <= 1 - cut can only ever join two
+//      NON-singleton segments.  Phase A handles all edges heavier than 1 - cut (shell by shell) and does not even
+//      store lighter ones; afterwards every singleton is frozen, and phase B re-evaluates the (few) pairs between
+//      the non-singleton segments that are still below their thresholds and finishes the scan on them.
+//
+// Per shell: (1) enumerate candidate pairs by squared centroid distance (2 LDS reads, ~10 VALU per pair, no
+// transcendental); (2) full weight only for the shell's pairs, one per lane; (3) LDS bitonic sort of <= 512 keys
+// instead of n^2; (4) sequential merge, 64 edges per step, segment ids / thresholds / sizes of the step held in
+// registers and patched in place after every merge (no LDS round trip on the critical path).
 #ifndef LOCALCUT_WAVE_HPP_
 #define LOCALCUT_WAVE_HPP_
+
+// VGS_PROF=1 builds accumulate per-phase shader cycles (s_memtime) into counters[16..31] (diagnostics only)
+#ifdef VGS_PROF
+#define LW_T0() long long _t0 = clock64()
+#define LW_ACC(slot) do { long long _t1 = clock64(); if (lane == 0) prof[slot] += (unsigned long long)(_t1 - _t0); _t0 = _t1; } while (0)
+#define LW_CNT(slot, v) do { if (lane == 0) prof[slot] += (unsigned long long)(v); } while (0)
+#else
+#define LW_T0() do {} while (0)
+#define LW_ACC(slot) do {} while (0)
+#define LW_CNT(slot, v) do {} while (0)
+#endif
 
 struct LwParams {
   LcParams lc;
@@ -46,25 +63,41 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
-                                                      uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback) {
+                                                      uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
+                                                      uint32_t* __restrict__ evals_out) {
   __shared__ __attribute__((aligned(16))) NodeRec rec[MAXM];
   __shared__ __attribute__((aligned(16))) uint64_t list[LCAP];
+  __shared__ __attribute__((aligned(16))) float4 cpos[MAXM];  // centroid + position-valid flag (w != 0)
   __shared__ float thr[MAXM];
   __shared__ uint16_t seg[MAXM], rep[MAXM], ssz[MAXM], loc[MAXM];
-  __shared__ uint16_t alist[MAXM];  // vertices whose segment can still merge (ascending), see step 5
+  __shared__ uint16_t alist[MAXM];  // vertices whose segment can still merge (ascending)
 
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= n_work) return;
-  const uint32_t u = work[blockIdx.x];
+  // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
+  // Morton-ordered work list so that neighbouring voxels share their L2
+  const int per_xcd = (n_work + 7) >> 3;
+  const int widx = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+  if (widx >= n_work) return;
+  const uint32_t u = work[widx];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + (int64_t)u * adj_stride;
   uint8_t* crow = conn + (int64_t)u * adj_stride;
   const float cut = P.lc.cut;
   const VgsWeightParams& W = P.lc.W;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#ifdef VGS_PROF
+  unsigned long long prof[16] = {0};
+#endif
+  LW_T0();
 
   // ---- gather the used neighbours in adjacency order; their global ids go through the list area ----
   uint32_t* gid = (uint32_t*)list;
-  for (int k = lane; k < n; k += 64) crow[k] = 0;
+#ifdef VGS_PROF
+  if (n == 0x7fffffff) return;  // force the dependent loads to complete before the timestamp
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  LW_ACC(10);  // work + adj_cnt loads
+  LW_ACC(6);   // (the connect flags were zeroed by one memset before the launch)
   int m = 0;
   for (int base = 0; base < n; base += 64) {
     const int k = base + lane;
@@ -75,7 +108,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       keep = P.lc.prune_unused ? ((node[t].flags & VGS_F_EIG) != 0) : true;
     }
     const unsigned long long mk = __ballot(keep);
-    const int pos = m + __popcll(mk & ((1ull << lane) - 1ull));
+    const int pos = m + __popcll(mk & lt_mask);
     if (keep && pos < MAXM) { gid[pos] = t; loc[pos] = (uint16_t)k; }
     m += __popcll(mk);
   }
@@ -83,59 +116,166 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     if (lane == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
     return;
   }
+  LW_ACC(14);  // gather: row read + compaction
   wave_sync();
+  LW_ACC(15);  // gather: first sync (waits for the row zeroing stores)
   {
     const float4* src = (const float4*)node;
     float4* dst = (float4*)rec;
     for (int e = lane; e < m * 4; e += 64) dst[e] = src[(size_t)gid[e >> 2] * 4 + (e & 3)];
   }
-  const float thr0 = vm_cut_threshold(1.0f, cut, 1);
-  for (int c = lane; c < m; c += 64) { seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (uint16_t)c; }
+  const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
+  wave_sync();
+  LW_ACC(7);  // gather: record loads
+  for (int c = lane; c < m; c += 64) {
+    seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (uint16_t)c;
+    cpos[c] = make_float4(rec[c].c[0], rec[c].c[1], rec[c].c[2], (rec[c].flags & VGS_F_POS) ? 1.0f : 0.0f);
+  }
   wave_sync();
 
+  LW_ACC(0);  // gather
   unsigned long long n_evals = 0;
-  int n_list = 0;      // edges carried in the list (sorted, all lighter than the level of the previous round)
   int merges = 0;
   bool bail = false;
+
+  // descending bitonic sort of list[0, cnt) (keys 0 = dropped edges fall off the end)
+  auto sort_list = [&](int cnt) {
+    int np = 64;
+    while (np < cnt) np <<= 1;
+    for (int k = cnt + lane; k < np; k += 64) list[k] = 0ull;
+    wave_sync();
+    for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
+      for (int sl = sbit - 1; sl >= 0; --sl) {
+        const int strd = 1 << sl;
+        for (int t = lane; t < (np >> 1); t += 64) {
+          const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
+          const int hi = lo + strd;
+          const bool dn = ((lo & size) == 0);
+          const uint64_t x = list[lo], y = list[hi];
+          if ((x < y) == dn) { list[lo] = y; list[hi] = x; }
+        }
+        wave_sync();
+      }
+    }
+  };
+
+  // sequential merge of the sorted list[0, cnt) down to (not including) weights <= level; returns the position
+  // of the first unprocessed edge; afterwards seg[] maps every vertex to its live representative
+  auto merge_list = [&](int cnt, float level) -> int {
+    int pos = 0;
+    bool reached = false;
+    while (pos < cnt && !reached) {
+      const int e = pos + lane;
+      float w = 0.f;
+      int sa = 0, sb = 0;
+      bool proc = false;
+      if (e < cnt) {
+        const uint64_t key = list[e];
+        w = vm_from_bits((uint32_t)(key >> 32));
+        proc = w > level;
+        const uint32_t pid = 0xffffffffu - (uint32_t)key;
+        sa = seg[pid >> 16];
+        sb = seg[pid & 0xffffu];
+        while (rep[sa] != sa) sa = rep[sa];
+        while (rep[sb] != sb) sb = rep[sb];
+      }
+      const int nproc = __popcll(__ballot(proc));  // sorted: the processable edges are a prefix of the step
+      float ta = thr[sa], tb = thr[sb];
+      int za = ssz[sa], zb = ssz[sb];
+      bool alive = proc;
+      while (true) {
+        const bool pass = alive && (sa != sb) && (w > ta) && (w > tb);
+        const unsigned long long mk = __ballot(pass);
+        if (mk == 0ull) break;   // nothing in this step can merge in the current state
+        // the first mergeable edge in order does merge: the state has not changed since the edges before it failed
+        const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
+        const float wf = lw_readlane_f(w, f);
+        const int s1 = __builtin_amdgcn_readlane(sa, f), s2 = __builtin_amdgcn_readlane(sb, f);
+        const float t1 = lw_readlane_f(ta, f), t2 = lw_readlane_f(tb, f);
+        const int z1 = __builtin_amdgcn_readlane(za, f), z2 = __builtin_amdgcn_readlane(zb, f);
+        const int keep = (t1 >= t2) ? s1 : s2;   // VS:1972-1983: the segment with the larger threshold survives
+        const int gone = (t1 >= t2) ? s2 : s1;
+        const int nsz = z1 + z2;
+        const float nthr = vm_cut_threshold(wf, cut, nsz);  // seg_int = w (VS:1988)
+        if (sa == gone) sa = keep;
+        if (sb == gone) sb = keep;
+        if (sa == keep) { ta = nthr; za = nsz; }
+        if (sb == keep) { tb = nthr; zb = nsz; }
+        alive = alive && (lane > f);
+        if (lane == 0) { rep[gone] = (uint16_t)keep; thr[keep] = nthr; ssz[keep] = (uint16_t)nsz; ssz[gone] = 0; }
+        ++merges;
+      }
+      wave_sync();
+      if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
+      if (merges >= m - 1) break;  // one segment left
+    }
+    for (int c = lane; c < m; c += 64) {
+      int s = seg[c];
+      while (rep[s] != s) s = rep[s];
+      seg[c] = (uint16_t)s;
+    }
+    wave_sync();
+    return pos;
+  };
+
   if (m >= 2) {
+    // =========================== phase A: edges heavier than a singleton's threshold ===========================
+    int n_list = 0;      // edges carried in the list (sorted, all lighter than the previous level, heavier than thr0)
     int n_act = m;       // vertices still able to merge; pairs are enumerated among them only
     float cut_lo = 0.0f;
     float cut_hi = P.shell0 * P.r2_graph / (float)m;
     int shrink = 0;
-    for (int round = 0; round < 4096; ++round) {
-      bool final_round = !(cut_hi < P.d2_all);
+    bool phase_a_complete = false;
+    while (true) {
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
       const int Pact = n_act * (n_act - 1) / 2;
+      // once every pair between the still-active vertices fits in the list there is no point in further shells
+      const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
       int count = 0;
       {
+        // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
+        // LDS reads of a trip are issued together
+        const bool ident = (n_act == m);  // alist is still the identity
         int ia = 0, qq = lane;
-        for (int base = 0; base < Pact; base += 64) {
-          while (ia < n_act - 1 && qq >= n_act - 1 - ia) { qq -= (n_act - 1 - ia); ++ia; }
-          const bool valid = ia < n_act - 1;
-          bool inr = false;
-          uint32_t pid = 0;
-          if (valid) {
-            const int a = alist[ia], b = alist[ia + 1 + qq];  // a < b: alist is ascending
-            if (merges == 0 || seg[a] != seg[b]) {
-              float d2 = 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
-              if ((rec[a].flags & VGS_F_POS) && (rec[b].flags & VGS_F_POS)) {
-                const float dx = rec[a].c[0] - rec[b].c[0], dy = rec[a].c[1] - rec[b].c[1], dz = rec[a].c[2] - rec[b].c[2];
-                d2 = (dx * dx + dy * dy) + dz * dz;
-              }
-              inr = (d2 >= cut_lo) && (final_round || d2 < cut_hi);
-              pid = ((uint32_t)a << 16) | (uint32_t)b;
+        for (int base = 0; base < Pact; base += 256) {
+          int va[4], vb[4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            while (ia < n_act - 1 && qq >= n_act - 1 - ia) { qq -= (n_act - 1 - ia); ++ia; }
+            ok[k] = ia < n_act - 1;
+            const int ib = ia + 1 + qq;
+            va[k] = ok[k] ? (ident ? ia : (int)alist[ia]) : 0;
+            vb[k] = ok[k] ? (ident ? ib : (int)alist[ib]) : 0;   // va < vb: alist is ascending
+            qq += 64;
+          }
+          float4 pa[4], pb[4];
+          bool diff[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pa[k] = cpos[va[k]]; pb[k] = cpos[vb[k]];
+            diff[k] = ok[k] && (merges == 0 || seg[va[k]] != seg[vb[k]]);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float d2 = 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
+            if (pa[k].w != 0.0f && pb[k].w != 0.0f) {
+              const float dx = pa[k].x - pb[k].x, dy = pa[k].y - pb[k].y, dz = pa[k].z - pb[k].z;
+              d2 = (dx * dx + dy * dy) + dz * dz;
             }
+            const bool inr = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
+            const unsigned long long mk = __ballot(inr);
+            if (inr) {
+              const int pos = n_list + count + __popcll(mk & lt_mask);
+              if (pos < LCAP) list[pos] = (uint64_t)(((uint32_t)va[k] << 16) | (uint32_t)vb[k]);
+            }
+            count += __popcll(mk);
           }
-          const unsigned long long mk = __ballot(inr);
-          if (inr) {
-            const int pos = n_list + count + __popcll(mk & ((1ull << lane) - 1ull));
-            if (pos < LCAP) list[pos] = (uint64_t)pid;
-          }
-          count += __popcll(mk);
-          qq += 64;
         }
       }
+      LW_ACC(1);  // enumerate
+      LW_CNT(8, 1);  // rounds
       if (count > free_slots) {
         // the shell holds more pairs than the list: shrink it (assume uniform density in d2) and redo
         if (++shrink > 24 || free_slots < 32) { if (lane == 0) atomicAdd(&counters[free_slots < 32 ? 4 : 3], 1ull); bail = true; break; }
@@ -146,99 +286,33 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       }
       shrink = 0;
       wave_sync();
-      // ---- 2. full weight of the shell's pairs ----
+      // ---- 2. full weight of the shell's pairs; NaN (Q3) and weights <= thr0 (fact S) are not stored ----
       int dropped = 0;
       for (int base = n_list; base < n_list + count; base += 64) {
         const int e = base + lane;
-        bool nanw = false;
+        bool drop = false;
         if (e < n_list + count) {
           const uint32_t pid = (uint32_t)list[e];
           const float w = vm_pair_weight(rec[pid >> 16], rec[pid & 0xffffu], W);
-          nanw = (w != w);
-          list[e] = nanw ? 0ull : (((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - pid));
+          drop = !(w > thr0);
+          list[e] = drop ? 0ull : (((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - pid));
         }
-        dropped += __popcll(__ballot(nanw));
+        dropped += __popcll(__ballot(drop));
       }
-      n_evals += (unsigned long long)count;
+      if (lane == 0) n_evals += (unsigned long long)count;
       n_list += count;
-      // ---- 3. sort descending (weight, then ascending (a, b)); NaN edges (key 0) fall off the end ----
-      int np = 64;
-      while (np < n_list) np <<= 1;
-      for (int k = n_list + lane; k < np; k += 64) list[k] = 0ull;
-      wave_sync();
-      for (int size = 2; size <= np; size <<= 1) {
-        for (int strd = size >> 1; strd > 0; strd >>= 1) {
-          for (int t = lane; t < (np >> 1); t += 64) {
-            const int lo = ((t / strd) * (strd << 1)) + (t % strd);
-            const int hi = lo + strd;
-            const bool dn = ((lo & size) == 0);
-            const uint64_t x = list[lo], y = list[hi];
-            if ((x < y) == dn) { list[lo] = y; list[hi] = x; }
-          }
-          wave_sync();
-        }
-      }
+      LW_ACC(2);  // evaluate
+      // ---- 3. sort, 4. merge down to the level ----
+      sort_list(n_list);
+      LW_CNT(9, n_list);
       n_list -= dropped;
-      // ---- 4. merge down to the level ----
+      LW_ACC(3);  // sort
       const float level = final_round ? -1.0f : lw_level(cut_hi, W);
-      int pos = 0;
-      bool reached_level = false;
-      while (pos < n_list && !reached_level) {
-        const int e = pos + lane;
-        float w = 0.f;
-        int sa = 0, sb = 0;
-        bool proc = false;
-        if (e < n_list) {
-          const uint64_t key = list[e];
-          w = vm_from_bits((uint32_t)(key >> 32));
-          proc = w > level;
-          const uint32_t pid = 0xffffffffu - (uint32_t)key;
-          sa = seg[pid >> 16];
-          sb = seg[pid & 0xffffu];
-          while (rep[sa] != sa) sa = rep[sa];
-          while (rep[sb] != sb) sb = rep[sb];
-        }
-        const int nproc = __popcll(__ballot(proc));  // sorted: the processable edges are a prefix of the step
-        float ta = thr[sa], tb = thr[sb];
-        int za = ssz[sa], zb = ssz[sb];
-        bool alive = proc;
-        while (true) {
-          const bool pass = alive && (sa != sb) && (w > ta) && (w > tb);
-          const unsigned long long mk = __ballot(pass);
-          if (mk == 0ull) break;
-          const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-          const float wf = lw_readlane_f(w, f);
-          const int s1 = __builtin_amdgcn_readlane(sa, f), s2 = __builtin_amdgcn_readlane(sb, f);
-          const float t1 = lw_readlane_f(ta, f), t2 = lw_readlane_f(tb, f);
-          const int z1 = __builtin_amdgcn_readlane(za, f), z2 = __builtin_amdgcn_readlane(zb, f);
-          const int keep = (t1 >= t2) ? s1 : s2;   // VS:1972-1983
-          const int gone = (t1 >= t2) ? s2 : s1;
-          const int nsz = z1 + z2;
-          const float nthr = vm_cut_threshold(wf, cut, nsz);  // seg_int = w (VS:1988)
-          if (sa == gone) sa = keep;
-          if (sb == gone) sb = keep;
-          if (sa == keep) { ta = nthr; za = nsz; }
-          if (sb == keep) { tb = nthr; zb = nsz; }
-          alive = alive && (lane > f);
-          if (lane == 0) { rep[gone] = (uint16_t)keep; thr[keep] = nthr; ssz[keep] = (uint16_t)nsz; ssz[gone] = 0; }
-          ++merges;
-        }
-        wave_sync();
-        if (nproc < 64) { pos += nproc; reached_level = true; } else pos += 64;
-        if (merges >= m - 1) break;  // one segment left
-      }
-      // vertex -> live representative
-      for (int c = lane; c < m; c += 64) {
-        int s = seg[c];
-        while (rep[s] != s) s = rep[s];
-        seg[c] = (uint16_t)s;
-      }
-      wave_sync();
-      if (merges >= m - 1 || final_round) break;
-      // ---- 5. freeze and carry ----
-      // Every edge still to come (carried or not yet evaluated) weighs <= level.  A segment whose threshold is
-      // >= level can therefore never merge again (its threshold only moves when it merges): its vertices leave the
-      // pair enumeration and its edges are dropped.  Exact, and it is what keeps plane/plane borders cheap.
+      const int pos = merge_list(n_list, level);
+      LW_ACC(4);  // merge
+      if (merges >= m - 1) break;
+      if (final_round || !(level > thr0)) { phase_a_complete = true; break; }
+      // ---- 5. freeze (fact F) and carry ----
       int n_new = 0;
       for (int base = 0; base < n_act; base += 64) {
         const int ia = base + lane;
@@ -247,7 +321,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         if (ia < n_act) { v = alist[ia]; act = thr[seg[v]] < level; }
         const unsigned long long mk = __ballot(act);
         wave_sync();
-        if (act) alist[n_new + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)v;
+        if (act) alist[n_new + __popcll(mk & lt_mask)] = (uint16_t)v;
         n_new += __popcll(mk);
         wave_sync();
       }
@@ -257,7 +331,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         const int c = base + lane;
         active_segs += __popcll(__ballot((c < m) && (ssz[c] != 0) && (thr[c] < level)));
       }
-      if (active_segs < 2) break;
+      if (active_segs < 2) break;  // nothing can merge at any weight <= level
       int kept = 0;
       for (int base = pos; base < n_list; base += 64) {
         const int e = base + lane;
@@ -271,13 +345,73 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         }
         const unsigned long long mk = __ballot(keep_e);
         wave_sync();  // all lanes have read their entry before anyone overwrites the front of the list
-        if (keep_e) list[kept + __popcll(mk & ((1ull << lane) - 1ull))] = key;
+        if (keep_e) list[kept + __popcll(mk & lt_mask)] = key;
         kept += __popcll(mk);
         wave_sync();
       }
       n_list = kept;
+      LW_ACC(5);  // freeze + carry
       cut_lo = cut_hi;
       cut_hi = cut_hi * P.grow;
+    }
+    // =========================== phase B: edges at or below a singleton's threshold ===========================
+    if (phase_a_complete && !bail && merges < m - 1) {
+      // every edge heavier than thr0 has been examined in order; singletons are frozen.  What can still merge:
+      // non-singleton segments whose threshold is below thr0, through edges with w <= thr0 between them.
+      int nb = 0;
+      for (int base = 0; base < m; base += 64) {
+        const int v = base + lane;
+        bool act = false;
+        if (v < m) { const int s = seg[v]; act = (ssz[s] >= 2) && (thr[s] < thr0); }
+        const unsigned long long mk = __ballot(act);
+        if (act) alist[nb + __popcll(mk & lt_mask)] = (uint16_t)v;
+        nb += __popcll(mk);
+      }
+      int active_segs = 0;
+      for (int base = 0; base < m; base += 64) {
+        const int c = base + lane;
+        active_segs += __popcll(__ballot((c < m) && (ssz[c] >= 2) && (thr[c] < thr0)));
+      }
+      wave_sync();
+#ifdef VGS_PROF
+      _t0 = clock64();
+#endif
+      if (active_segs >= 2) {
+        LW_CNT(10, 1);
+        const int Pb = nb * (nb - 1) / 2;
+        int count = 0;
+        int ia = 0, qq = lane;
+        for (int base = 0; base < Pb; base += 64) {
+          while (ia < nb - 1 && qq >= nb - 1 - ia) { qq -= (nb - 1 - ia); ++ia; }
+          bool inr = false;
+          uint64_t key = 0;
+          if (ia < nb - 1) {
+            const int a = alist[ia], b = alist[ia + 1 + qq];
+            if (seg[a] != seg[b]) {
+              const float w = vm_pair_weight(rec[a], rec[b], W);
+              ++n_evals;
+              inr = (w <= thr0);  // heavier edges were examined in phase A; NaN compares false
+              key = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
+            }
+          }
+          const unsigned long long mk = __ballot(inr);
+          if (inr) {
+            const int pos = count + __popcll(mk & lt_mask);
+            if (pos < LCAP) list[pos] = key;
+          }
+          count += __popcll(mk);
+          qq += 64;
+        }
+        if (count > LCAP) {
+          if (lane == 0) atomicAdd(&counters[6], 1ull);
+          bail = true;
+        } else {
+          wave_sync();
+          sort_list(count);
+          merge_list(count, -1.0f);
+        }
+        LW_ACC(6);  // phase B
+      }
     }
   }
   if (bail) {
@@ -290,7 +424,11 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     for (int c = lane; c < m; c += 64)
       if (seg[c] == s0) crow[loc[c]] = 1;
   }
-  if (lane == 0 && n_evals) atomicAdd(&counters[0], n_evals);
+  for (int o = 32; o > 0; o >>= 1) n_evals += __shfl_xor(n_evals, o, 64);
+  if (lane == 0) evals_out[u] = (uint32_t)n_evals;  // summed on the host on request: no same-address atomics on the hot path
+#ifdef VGS_PROF
+  if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }
+#endif
 }
 
 #endif

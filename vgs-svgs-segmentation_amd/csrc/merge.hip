@@ -78,22 +78,22 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
 
 // ------------------------------------------------------------------ closestCheck
 // flags: bit0 candidate (list == {self} and adjacency vector longer than adjacency_min), bit1 success
-__global__ void k_cc_candidates(const uint32_t* __restrict__ used_ids, int64_t U, const uint32_t* __restrict__ adj_cnt,
+__global__ void k_cc_candidates(const uint32_t* __restrict__ used_ids, int64_t U, const uint32_t* __restrict__ adj_nall,
                                 const uint32_t* __restrict__ csize, int adjacency_min, uint8_t* __restrict__ flags,
                                 uint32_t* __restrict__ cand_list, unsigned int* __restrict__ n_cand) {
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= U) return;
   const uint32_t i = used_ids[u];
   // voxels_adjacency_idx_[i] = [count, idx...]: its size is n + 1 (VS:2201)
-  const bool cand = (csize[i] == 1u) && ((int)adj_cnt[u] + 1 > adjacency_min);
+  const bool cand = (csize[i] == 1u) && ((int)adj_nall[u] + 1 > adjacency_min);
   if (cand) { flags[i] = 1; cand_list[atomicAdd(n_cand, 1u)] = (uint32_t)u; }
 }
 
 // scan entry j of voxel i's raw adjacency vector: j == 0 is the neighbour COUNT read as a voxel id (Q7, VS:2243)
-__device__ __forceinline__ int cc_entry(int j, int n, const uint64_t* row, const MgParams& P) {
+__device__ __forceinline__ int cc_entry(int j, int n_all, const uint64_t* row, const MgParams& P) {
   if (j == 0) {
-    if (!P.q7 || (int64_t)n >= P.V) return -1;
-    return n;
+    if (!P.q7 || (int64_t)n_all >= P.V) return -1;
+    return n_all;
   }
   return (int)(uint32_t)row[j - 1];
 }
@@ -101,7 +101,8 @@ __device__ __forceinline__ int cc_entry(int j, int n, const uint64_t* row, const
 template <bool CHOOSE>
 __global__ __launch_bounds__(64) void k_cc_pass(const uint32_t* __restrict__ cand_list, int n_cand, const uint32_t* __restrict__ used_ids,
                                                 const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
-                                                int adj_stride, const NodeRec* __restrict__ node, const uint32_t* __restrict__ csize,
+                                                const uint32_t* __restrict__ adj_nall, int adj_stride,
+                                                const NodeRec* __restrict__ node, const uint32_t* __restrict__ csize,
                                                 uint8_t* __restrict__ flags, MgParams P, int32_t* __restrict__ attach,
                                                 unsigned int* __restrict__ changed) {
   if ((int)blockIdx.x >= n_cand) return;
@@ -110,14 +111,17 @@ __global__ __launch_bounds__(64) void k_cc_pass(const uint32_t* __restrict__ can
   const uint32_t i = used_ids[u];
   if (!CHOOSE && (flags[i] & 2)) return;
   if (CHOOSE && !(flags[i] & 2)) { if (lane == 0) attach[i] = -1; return; }
+  // the row may hold the used neighbours only: an unused voxel is never an eligible target (its list is empty),
+  // so skipping it changes neither the choice nor the "last equal weight wins" order
   const int n = (int)adj_cnt[u];
+  const int n_all = (int)adj_nall[u];
   const uint64_t* row = adj_key + (int64_t)u * adj_stride;
   const NodeRec me = node[i];
   float best_w = -1.0f;
   int best_j = -1, best_t = -1;
   bool any = false;
   for (int j = lane; j < n + 1; j += 64) {
-    const int t = cc_entry(j, n, row, P);
+    const int t = cc_entry(j, n_all, row, P);
     if (t < 0) continue;
     // eligible at voxel i's turn: list longer than one after crossValidation, or an earlier candidate that succeeded
     const bool elig = (csize[t] > 1u) || ((uint32_t)t < i && (flags[t] & 3) == 3);
@@ -143,10 +147,13 @@ __global__ __launch_bounds__(64) void k_cc_pass(const uint32_t* __restrict__ can
 
 // ------------------------------------------------------------------ connected components
 __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+  // path halving: parents only ever move towards the root (smaller ids), so a stale write is still an ancestor
   while (true) {
     const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == x) return x;
-    x = p;
+    const uint32_t g = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g != p) __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = g;
   }
 }
 __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
@@ -187,10 +194,20 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
 
 __global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, uint32_t* __restrict__ csz) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
+  if (v >= V) return;   // V is padded to the block size by the caller? no: tail lanes simply leave
   const uint32_t r = uf_find(parent, (uint32_t)v);
   parent[v] = r;   // only shortens paths: concurrent finds stay correct
-  atomicAdd(&csz[r], 1u);
+  // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address)
+  unsigned long long todo = __ballot(true);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int l0 = __ffsll((long long)todo) - 1;
+    const uint32_t r0 = (uint32_t)__shfl((int)r, l0, 64);
+    const unsigned long long same = __ballot(r == r0) & todo;
+    if (lane == l0) atomicAdd(&csz[r0], (unsigned int)__popcll(same));
+    todo &= ~same;
+    if ((same >> lane) & 1ull) break;
+  }
 }
 
 __global__ void k_root_flags(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ csz, int64_t V, int voxels_min,
@@ -265,7 +282,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
     unsigned int* d_ncand = (unsigned int*)(c->counters.p + 0);
     unsigned int* d_changed = (unsigned int*)(c->counters.p + 1);
-    hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_cnt.p,
+    hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_mused.p,
                        c->csize.p, MP.adjacency_min, c->cc_flags.p, c->work_ids.p, d_ncand);
     VGS_HIP_TRY(c, hipMemcpyAsync(&n_cand, d_ncand, 4, hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -273,14 +290,14 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       for (int it = 0; it < 1 << 20; ++it) {
         VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
         hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
-                           c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
+                           c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
         unsigned int ch = 0;
         VGS_HIP_TRY(c, hipMemcpyAsync(&ch, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
         VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!ch) break;
       }
       hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
-                         c->adj_cnt.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
+                         c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
     }
   } else {
     VGS_HIP_TRY(c, c->conn.ensure(16));

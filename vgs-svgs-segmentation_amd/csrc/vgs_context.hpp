@@ -111,7 +111,9 @@ struct vgs_ctx {
   int n_off = 0;
   int adj_stride = 0;
   DevBuf<uint64_t> adj_key;
-  DevBuf<uint32_t> adj_cnt, adj_mused;
+  DevBuf<uint32_t> adj_cnt, adj_mused;  // per used voxel: stored row length, number of ALL neighbours
+  bool adj_pruned = false;              // rows hold used neighbours only
+  float adj_r2 = 0.f;
 
   // local cut / merge
   DevBuf<uint8_t> conn;
@@ -147,6 +149,8 @@ struct vgs_ctx {
 vgs_status vgs_stage_voxelize(vgs_ctx* c);
 vgs_status vgs_stage_features(vgs_ctx* c);
 vgs_status vgs_stage_adjacency(vgs_ctx* c);
+vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2);
+bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_localcut(vgs_ctx* c);
 vgs_status vgs_stage_merge(vgs_ctx* c);
 

@@ -110,17 +110,19 @@ __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_
 }
 
 // run heads in the sorted code array (invalid codes == 0 sit at the tail of the descending order)
-__global__ void k_heads(const uint64_t* __restrict__ code, int64_t n, uint32_t* __restrict__ head,
-                        unsigned long long* __restrict__ n_valid) {
+__global__ void k_heads(const uint64_t* __restrict__ code, int64_t n, uint32_t* __restrict__ head) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool valid = false;
   if (j < n) {
     uint64_t c = code[j];
-    valid = c != 0;
-    head[j] = (valid && (j == 0 || code[j - 1] != c)) ? 1u : 0u;
+    head[j] = (c != 0 && (j == 0 || code[j - 1] != c)) ? 1u : 0u;
   }
-  unsigned long long m = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_valid, (unsigned long long)__popcll(m));
+}
+
+// number of valid (non-zero) codes = index of the first zero in the descending array
+__global__ void k_count_valid(const uint64_t* __restrict__ code, int64_t n, unsigned long long* __restrict__ n_valid) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (code[mid] != 0) lo = mid + 1; else hi = mid; }
+  *n_valid = (unsigned long long)lo;
 }
 
 __global__ void k_voxel_table(const uint64_t* __restrict__ code, const uint32_t* __restrict__ head,
@@ -238,7 +240,8 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   // sorted: code_b, perm_b
   unsigned long long* d_cnt = (unsigned long long*)c->counters.p;
   VGS_HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, N, c->head_flag.p, d_cnt);
+  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, N, c->head_flag.p);
+  hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, c->stream, c->code_b.p, N, d_cnt);
   uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
   VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
   unsigned long long nf = 0;
