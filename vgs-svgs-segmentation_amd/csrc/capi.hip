@@ -110,7 +110,8 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
   if (!c) return VGS_E_NOMEM;
   c->P = *p;
   c->device = p->device;
-  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
     g_create_err = "vgs_create: hipSetDevice/hipStreamCreate failed";
     delete c;
     return VGS_E_HIP;
@@ -135,6 +136,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 

@@ -383,8 +383,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     WP.d2_all = reach * reach * 1.01f;
   }
-  WP.shell0 = 8.0f;
+  WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
   WP.grow = 2.25f;
+  WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   auto launch_block = [&](const uint32_t* ids, unsigned int nw) -> vgs_status {
     // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond
     if (nw == 0) return VGS_OK;
@@ -398,18 +399,33 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     return VGS_OK;
   };
   (void)SMALL_M; (void)SMALL_CAP;
+  uint32_t* dbg_buf = nullptr;
+#ifdef VGS_PROF
+  static DevBuf<uint32_t> s_dbg;
+  VGS_HIP_TRY(c, s_dbg.ensure(4 * (size_t)U));
+  VGS_HIP_TRY(c, hipMemset(s_dbg.p, 0, 16 * (size_t)U));
+  dbg_buf = s_dbg.p;
+#endif
   VGS_HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
   VGS_HIP_TRY(c, hipMemsetAsync(c->conn.p, 0, (size_t)U * c->adj_stride, c->stream));  // connect flags start at 0
-  if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p);
-  if (nabc[1] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_b, (int)nabc[1], c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p);
+  // the heavy classes (few, long-running wavefronts) go to a side stream so that they overlap the light class
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
   {
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream2;  // launch_block uses c->stream
+    if (nabc[1] > 0)
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_b, (int)nabc[1],
+                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
     vgs_status st = launch_block(ids_c, nabc[2]);
+    c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
+  if (nabc[0] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   unsigned int nf = 0;
   VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -437,6 +453,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
 #ifdef VGS_PROF
+  {
+    std::vector<uint32_t> dbg(4 * (size_t)U);
+    VGS_HIP_TRY(c, hipMemcpy(dbg.data(), dbg_buf, dbg.size() * 4, hipMemcpyDeviceToHost));
+    // histogram of per-voxel cost by m bucket
+    double cyc[9] = {0}, cntb[9] = {0}, rnd[9] = {0}, evl[9] = {0}; double maxc = 0; size_t maxu = 0;
+    for (size_t q = 0; q < (size_t)U; ++q) { uint32_t mm = dbg[4*q]; if (!mm) continue; int b = mm <= 32 ? 0 : mm <= 64 ? 1 : mm <= 96 ? 2 : mm <= 128 ? 3 : mm <= 160 ? 4 : mm <= 192 ? 5 : mm <= 224 ? 6 : 7; double cy = 16.0 * dbg[4*q+2]; cyc[b] += cy; cntb[b] += 1; rnd[b] += dbg[4*q+1]; evl[b] += dbg[4*q+3]; if (cy > maxc) { maxc = cy; maxu = q; } }
+    for (int b = 0; b < 8; ++b) if (cntb[b] > 0) fprintf(stderr, "[vgs-prof] m-bucket %d: voxels=%.0f avg_cycles=%.0f avg_rounds=%.2f avg_evals=%.0f total_cycles=%.3g\n", b, cntb[b], cyc[b]/cntb[b], rnd[b]/cntb[b], evl[b]/cntb[b], cyc[b]);
+    fprintf(stderr, "[vgs-prof] slowest voxel u=%zu m=%u rounds=%u cycles=%.0f evals=%u\n", maxu, dbg[4*maxu], dbg[4*maxu+1], maxc, dbg[4*maxu+3]);
+  }
   {
     unsigned long long pr[16];
     VGS_HIP_TRY(c, hipMemcpy(pr, cnt + 16, sizeof(pr), hipMemcpyDeviceToHost));

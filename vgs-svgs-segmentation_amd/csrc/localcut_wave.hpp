@@ -42,20 +42,11 @@ struct LwParams {
   float d2_all;     // squared distance no pair of one neighbourhood can reach: last shell is open ended
   float shell0;     // first shell = shell0 * r2_graph / m
   float grow;       // shell growth factor (in squared distance)
+  int dbg_stop;     // diagnostics: leave the first round after step N (0 = run normally)
 };
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
-}
-
-// upper bound of the weight of any pair whose squared centroid distance is >= d2 (same float pipeline as
-// vm_distance_weight with all other distances dropped, then a 1e-6 relative margin for vm_exp's <= 1 ulp error)
-__device__ __forceinline__ float lw_level(float d2, const VgsWeightParams& W) {
-  const float d = vm_sqrt(d2);
-  float D;
-  if (!W.svgs) { const float s = d * W.inv_sig_p; D = vm_sqrt(s * s); }
-  else D = vm_sqrt(d * d * W.inv_sig_p);
-  return vm_exp((-0.5f * D) * W.inv_sig_w2) * 1.000001f;
 }
 
 template <int MAXM, int LCAP>
@@ -64,13 +55,14 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                       uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
-                                                      uint32_t* __restrict__ evals_out) {
+                                                      uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out) {
   __shared__ __attribute__((aligned(16))) NodeRec rec[MAXM];
   __shared__ __attribute__((aligned(16))) uint64_t list[LCAP];
   __shared__ __attribute__((aligned(16))) float4 cpos[MAXM];  // centroid + position-valid flag (w != 0)
   __shared__ float thr[MAXM];
   __shared__ uint16_t seg[MAXM], rep[MAXM], ssz[MAXM], loc[MAXM];
   __shared__ uint16_t alist[MAXM];  // vertices whose segment can still merge (ascending)
+  __shared__ uint16_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
 
   const int lane = threadIdx.x;
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
@@ -89,6 +81,9 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   unsigned long long prof[16] = {0};
 #endif
   LW_T0();
+#ifdef VGS_PROF
+  const long long t_start = clock64();
+#endif
 
   // ---- gather the used neighbours in adjacency order; their global ids go through the list area ----
   uint32_t* gid = (uint32_t*)list;
@@ -134,6 +129,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   wave_sync();
 
   LW_ACC(0);  // gather
+  if (P.shell0 < 0.0f) return;  // diagnostics: gather-only run
   unsigned long long n_evals = 0;
   int merges = 0;
   bool bail = false;
@@ -218,22 +214,83 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     return pos;
   };
 
+  // ---- can the voxel itself ever merge?  While it is a singleton it needs an incident edge heavier than thr0 ----
+  bool isolated = false;
   if (m >= 2) {
+    bool any = false;
+    for (int base = 1; base < m; base += 64) {
+      const int x = base + lane;
+      if (x < m) {
+        const float ub = vm_weight_bound_da(rec[0], rec[x], W);
+        if (!(ub <= thr0)) { const float w = vm_pair_weight(rec[0], rec[x], W); any = any || (w > thr0); }
+      }
+    }
+    isolated = (__ballot(any) == 0ull);
+    if (lane == 0) n_evals += (unsigned long long)(m - 1);
+  }
+  if (m >= 2 && !isolated) {
     // =========================== phase A: edges heavier than a singleton's threshold ===========================
     int n_list = 0;      // edges carried in the list (sorted, all lighter than the previous level, heavier than thr0)
     int n_act = m;       // vertices still able to merge; pairs are enumerated among them only
+    int n_min = 0, big = -1;  // later rounds: candidate pairs all involve a vertex outside the largest active segment
     float cut_lo = 0.0f;
+    // first shell: about shell0/2 pairs per vertex on a surface (pairs within d of each other ~ m^2 d^2 / (2 R^2)),
+    // but never more than ~60 % of the list
     float cut_hi = P.shell0 * P.r2_graph / (float)m;
+    {
+      const float cap = 2.0f * (0.6f * (float)LCAP) * P.r2_graph / ((float)m * (float)m);
+      cut_hi = cut_hi < cap ? cut_hi : cap;
+    }
     int shrink = 0;
     bool phase_a_complete = false;
+    int rounds = 0;
     while (true) {
+      // a neighbourhood that keeps hundreds of edges waiting above thr0 makes slow progress here: after a few
+      // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
+      if (++rounds > 6) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
-      const int Pact = n_act * (n_act - 1) / 2;
+      const bool use_minor = (big >= 0) && (2 * n_min < n_act);
+      const int Pact = use_minor ? n_min * n_act : n_act * (n_act - 1) / 2;   // (upper bound of) candidate pairs
       // once every pair between the still-active vertices fits in the list there is no point in further shells
       const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
       int count = 0;
-      {
+      if (use_minor) {
+        // pairs (x, y): x outside the largest segment, y any active vertex of another segment; a pair of two
+        // outside vertices is taken once (x < y)
+        for (int ix = 0; ix < n_min; ++ix) {
+          const int x = minor[ix];
+          const float4 px = cpos[x];
+          const int sx = seg[x];
+          for (int base = 0; base < n_act; base += 64) {
+            const int iy = base + lane;
+            bool inr = false;
+            uint32_t pid = 0;
+            if (iy < n_act) {
+              const int y = alist[iy];
+              const int sy = seg[y];
+              if (sy != sx && (sy == big || x < y)) {
+                const float4 py = cpos[y];
+                float d2 = 1.0e4f;
+                if (px.w != 0.0f && py.w != 0.0f) {
+                  const float dx = (x < y) ? px.x - py.x : py.x - px.x;
+                  const float dy = (x < y) ? px.y - py.y : py.y - px.y;
+                  const float dz = (x < y) ? px.z - py.z : py.z - px.z;
+                  d2 = (dx * dx + dy * dy) + dz * dz;
+                }
+                inr = (d2 >= cut_lo) && (final_round || d2 < cut_hi);
+                pid = (x < y) ? (((uint32_t)x << 16) | (uint32_t)y) : (((uint32_t)y << 16) | (uint32_t)x);
+              }
+            }
+            const unsigned long long mk = __ballot(inr);
+            if (inr) {
+              const int pos = n_list + count + __popcll(mk & lt_mask);
+              if (pos < LCAP) list[pos] = (uint64_t)pid;
+            }
+            count += __popcll(mk);
+          }
+        }
+      } else {
         // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
         // LDS reads of a trip are issued together
         const bool ident = (n_act == m);  // alist is still the identity
@@ -275,6 +332,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         }
       }
       LW_ACC(1);  // enumerate
+      if (P.dbg_stop == 1) return;
       LW_CNT(8, 1);  // rounds
       if (count > free_slots) {
         // the shell holds more pairs than the list: shrink it (assume uniform density in d2) and redo
@@ -293,7 +351,12 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         bool drop = false;
         if (e < n_list + count) {
           const uint32_t pid = (uint32_t)list[e];
-          const float w = vm_pair_weight(rec[pid >> 16], rec[pid & 0xffffu], W);
+          const NodeRec& A = rec[pid >> 16];
+          const NodeRec& B = rec[pid & 0xffffu];
+          // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
+          const float ub = vm_weight_bound_da(A, B, W);
+          float w = 0.0f;
+          if (!(ub <= thr0)) w = vm_pair_weight(A, B, W);
           drop = !(w > thr0);
           list[e] = drop ? 0ull : (((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - pid));
         }
@@ -302,14 +365,17 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       if (lane == 0) n_evals += (unsigned long long)count;
       n_list += count;
       LW_ACC(2);  // evaluate
+      if (P.dbg_stop == 2) return;
       // ---- 3. sort, 4. merge down to the level ----
       sort_list(n_list);
       LW_CNT(9, n_list);
       n_list -= dropped;
       LW_ACC(3);  // sort
-      const float level = final_round ? -1.0f : lw_level(cut_hi, W);
+      if (P.dbg_stop == 3) return;
+      const float level = final_round ? -1.0f : vm_weight_bound_d(cut_hi, W);
       const int pos = merge_list(n_list, level);
       LW_ACC(4);  // merge
+      if (P.dbg_stop == 4) return;
       if (merges >= m - 1) break;
       if (final_round || !(level > thr0)) { phase_a_complete = true; break; }
       // ---- 5. freeze (fact F) and carry ----
@@ -326,12 +392,35 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         wave_sync();
       }
       n_act = n_new;
+      {
+        // largest active segment and the active vertices outside it
+        int best = -1;
+        for (int base = 0; base < m; base += 64) {
+          const int c = base + lane;
+          if (c < m && ssz[c] != 0 && thr[c] < level) { const int key = ((int)ssz[c] << 16) | c; best = key > best ? key : best; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(best, o, 64); best = other > best ? other : best; }
+        big = best >= 0 ? (best & 0xffff) : -1;
+        n_min = 0;
+        for (int base = 0; base < n_act; base += 64) {
+          const int ia = base + lane;
+          bool out = false;
+          int v = 0;
+          if (ia < n_act) { v = alist[ia]; out = (int)seg[v] != big; }
+          const unsigned long long mk = __ballot(out);
+          if (out) minor[n_min + __popcll(mk & lt_mask)] = (uint16_t)v;
+          n_min += __popcll(mk);
+        }
+        wave_sync();
+      }
       int active_segs = 0;
       for (int base = 0; base < m; base += 64) {
         const int c = base + lane;
         active_segs += __popcll(__ballot((c < m) && (ssz[c] != 0) && (thr[c] < level)));
       }
       if (active_segs < 2) break;  // nothing can merge at any weight <= level
+      // only the segment of vertex 0 (the voxel itself) is reported: once it is frozen its membership is final
+      if (!(thr[seg[0]] < level)) break;
       int kept = 0;
       for (int base = pos; base < n_list; base += 64) {
         const int e = base + lane;
@@ -376,6 +465,10 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
 #ifdef VGS_PROF
       _t0 = clock64();
 #endif
+      {
+        const int s0 = seg[0];
+        if (!((ssz[s0] >= 2) && (thr[s0] < thr0))) active_segs = 0;  // vertex 0's segment is frozen: nothing to report changes
+      }
       if (active_segs >= 2) {
         LW_CNT(10, 1);
         const int Pb = nb * (nb - 1) / 2;
@@ -427,6 +520,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   for (int o = 32; o > 0; o >>= 1) n_evals += __shfl_xor(n_evals, o, 64);
   if (lane == 0) evals_out[u] = (uint32_t)n_evals;  // summed on the host on request: no same-address atomics on the hot path
 #ifdef VGS_PROF
+  if (lane == 0 && dbg_out) { long long tnow = clock64(); dbg_out[4 * (size_t)u + 0] = (uint32_t)m; dbg_out[4 * (size_t)u + 1] = (uint32_t)prof[8]; dbg_out[4 * (size_t)u + 2] = (uint32_t)((tnow - t_start) >> 4); dbg_out[4 * (size_t)u + 3] = (uint32_t)n_evals; }
   if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }
 #endif
 }

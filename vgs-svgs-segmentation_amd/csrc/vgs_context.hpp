@@ -71,6 +71,7 @@ struct vgs_ctx {
   vgs_params P;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // side stream: heavy local-cut classes overlap the light one
   std::string err;
   int stage = ST_NONE;
 

@@ -472,6 +472,37 @@ VGS_HD float vm_pair_weight(const VgsNode& v1, const VgsNode& v2, const VgsWeigh
   return vm_distance_weight(d, P);
 }
 
+// Upper bounds of vm_pair_weight used by the lazy local cut (never part of a result, only of the schedule).
+// Every float step of vm_distance_weight is monotone in each squared term, so dropping non-negative terms from
+// the sum under the square root can only raise the weight; the 1e-6 factor covers vm_exp's <= 1 ulp error.
+//   vm_weight_bound_d(d2):    every pair whose squared centroid distance is >= d2 weighs <= this
+//   vm_weight_bound_da(a, b): this pair weighs <= this (proximity and normal-angle terms only; a NaN bound
+//                             means "unknown": the caller then evaluates the full weight)
+VGS_HD float vm_weight_bound_d(float d2, const VgsWeightParams& P) {
+  const float d = vm_sqrt(d2);
+  float D;
+  if (!P.svgs) { const float s = d * P.inv_sig_p; D = vm_sqrt(s * s); }
+  else D = vm_sqrt(d * d * P.inv_sig_p);
+  return vm_exp((-0.5f * D) * P.inv_sig_w2) * 1.000001f;
+}
+
+VGS_HD float vm_weight_bound_da(const VgsNode& v1, const VgsNode& v2, const VgsWeightParams& P) {
+  float dist_space = 100.0f, dist_angle = 100.0f, d12 = 0.0f;
+  if ((v1.flags & VGS_F_POS) && (v2.flags & VGS_F_POS)) {
+    const float dx = v1.c[0] - v2.c[0], dy = v1.c[1] - v2.c[1], dz = v1.c[2] - v2.c[2];
+    d12 = vm_sqrt((dx * dx + dy * dy) + dz * dz);
+    dist_space = d12;
+  }
+  if ((v1.flags & VGS_F_NRM) && (v2.flags & VGS_F_NRM)) {
+    const bool guard = P.svgs ? (d12 != 0.0f) : (dist_space != 0.0f);
+    if (guard) dist_angle = vm_acos(vm_dot3(v1.n, v2.n));
+  }
+  float D;
+  if (!P.svgs) { const float s = dist_space * P.inv_sig_p, a = dist_angle * P.inv_sig_n; D = vm_sqrt(s * s + a * a); }
+  else D = vm_sqrt(dist_space * dist_space * P.inv_sig_p + dist_angle * dist_angle * P.inv_sig_n);
+  return vm_exp((-0.5f * D) * P.inv_sig_w2) * 1.000001f;
+}
+
 // Threshold of a segment in the local cut (VS:1968-1969): seg_int - cut/size, float.
 VGS_HD float vm_cut_threshold(float seg_int, float cut, int size) { return seg_int - cut / (float)size; }
 
