@@ -365,7 +365,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   uint32_t* ids_f = c->work_ids.p + 3 * U;    // voxels the wave kernels handed over
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
-  constexpr int WAVE_A = 96, WAVE_B = 256, WAVE_LCAP = 512;
+  constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_LCAP = 512;
   constexpr int SMALL_M = 160, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
