@@ -186,6 +186,37 @@ int ref_cut_graph(float cut, const float* W, int n, int flavour, int* out) {
   for (size_t i = 0; i < r.size(); ++i) out[i] = r[i];
   return (int)r.size();
 }
+// schedule bounds of the lazy local cut (csrc/vgs_math.h): exported so that CPU tests can check bound >= weight
+static VgsNode dev_node(const float* a) {
+  VgsNode v;
+  for (int i = 0; i < 3; ++i) { v.c[i] = a[i]; v.n[i] = a[3 + i]; }
+  for (int i = 0; i < 8; ++i) v.f[i] = a[6 + i];
+  v.flags = 0; v.pad = 0;
+  if (a[0] != 0 && a[1] != 0 && a[2] != 0) v.flags |= VGS_F_POS;
+  if (a[3] != 0 && a[4] != 0 && a[5] != 0) v.flags |= VGS_F_NRM;
+  if ((int)a[14] > 1) v.flags |= VGS_F_EIG;
+  return v;
+}
+static VgsWeightParams dev_params(const RefParamsC* p, int svgs) {
+  VgsWeightParams W;
+  W.inv_sig_p = 1.0f / p->sig_p; W.inv_sig_n = 1.0f / p->sig_n; W.inv_sig_o = 1.0f / p->sig_o;
+  W.inv_sig_e = 1.0f / p->sig_e; W.inv_sig_c = 1.0f / p->sig_c;
+  W.inv_sig_w2 = 1.0f / (p->sig_w * p->sig_w);
+  W.svgs = svgs;
+  return W;
+}
+void ref_weight_and_bounds(const float* a16, const float* b16, const RefParamsC* p, int svgs, float* out3) {
+  VgsNode A = dev_node(a16), B = dev_node(b16);
+  VgsWeightParams W = dev_params(p, svgs);
+  out3[0] = vm_pair_weight(A, B, W);
+  out3[1] = vm_weight_bound_da(A, B, W);
+  float d2 = 1.0e4f;
+  if ((A.flags & VGS_F_POS) && (B.flags & VGS_F_POS)) {
+    float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
+    d2 = (dx * dx + dy * dy) + dz * dz;
+  }
+  out3[2] = vm_weight_bound_d(d2, W);
+}
 void ref_compute_node(const float* xyz, int stride_floats, const int* idx, int count, int math, int svgs, float* out16) {
   Node nd;
   compute_node(xyz, stride_floats, idx, count, math, svgs != 0, nd);

@@ -81,6 +81,7 @@ def lib():
         L.ref_compute_node.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ref_eigen_features.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ref_eigen33.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_weight_and_bounds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RefParams), C.c_int, C.c_void_p]
         L.ref_devmath.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _LIB = L
     return _LIB
@@ -204,6 +205,13 @@ def distance_weight(d5, params, svgs=False):
 
 def pair_weight(a16, b16, params, svgs=False):
     return float(lib().ref_pair_weight(_p(a16), _p(b16), C.byref(params), int(svgs)))
+
+
+def weight_and_bounds(a16, b16, params, svgs=False):
+    """(DevMath weight, bound from proximity+normal angle, bound from proximity) -- schedule bounds of the lazy cut."""
+    out = np.zeros(3, dtype=np.float32)
+    lib().ref_weight_and_bounds(_p(a16), _p(b16), C.byref(params), int(svgs), _p(out))
+    return out
 
 
 def cut_graph(W, cut, flavour=0):

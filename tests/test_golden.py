@@ -1,0 +1,77 @@
+"""Golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py with the CPU oracle).
+CPU: the oracle still reproduces them (pins the oracle).  GPU: the HIP path reproduces the integer tables
+exactly, the RefMath attributes within the P1 tolerances and the DevMath labels bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import canonical_labels, partition_agreement
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _params(g):
+    return {str(k): float(v) for k, v in zip(g["params_keys"], g["params_vals"])}
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_reproduces_golden(oracle, path):
+    g = np.load(path)
+    kw = _params(g)
+    for math, tag in ((0, "ref"), (1, "dev")):
+        r = oracle.run_vgs(g["xyz"], oracle.vgs_params(math=math, flavour=1, **kw))
+        t = r.voxel_table()
+        np.testing.assert_array_equal(t["key"], g["key"])
+        np.testing.assert_array_equal(t["start"], g["start"])
+        np.testing.assert_array_equal(t["point_voxel"], g["point_voxel"])
+        np.testing.assert_array_equal(r.bbox(), g["bbox"])
+        nd = r.nodes()
+        np.testing.assert_array_equal(nd["used"], g["used"])
+        np.testing.assert_array_equal(nd["centroid"].view(np.uint32), g[f"centroid_{tag}"].view(np.uint32))
+        if math == 1:  # DevMath is libm-free: bit-reproducible everywhere
+            np.testing.assert_array_equal(nd["normal"].view(np.uint32), g["normal_dev"].view(np.uint32))
+            np.testing.assert_array_equal(nd["eigen"].view(np.uint32), g["eigen_dev"].view(np.uint32))
+            np.testing.assert_array_equal(r.labels()[0], g["point_label_dev"])
+        else:          # RefMath goes through libm: allow ulp-level drift between libm builds
+            np.testing.assert_allclose(nd["eigen"], g["eigen_ref"], atol=1e-5)
+            assert partition_agreement(r.labels()[0], g["point_label_ref"]) > 0.999
+        off, _ = r.lists("adjacency")
+        np.testing.assert_array_equal(np.diff(off).astype(np.int32), g["adj_len"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_gpu_reproduces_golden(gpu, path):
+    g = np.load(path)
+    kw = _params(g)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(g["xyz"])
+    eng.run()
+    t = eng.voxel_table()
+    np.testing.assert_array_equal(t["key"], g["key"])
+    np.testing.assert_array_equal(t["start"], g["start"])
+    np.testing.assert_array_equal(eng.point_voxel(), g["point_voxel"])
+    np.testing.assert_array_equal(eng.bbox(), g["bbox"])
+    a = eng.attributes()
+    np.testing.assert_array_equal(a["used"], g["used"])
+    # bit-exact against the DevMath vectors
+    for k in ("centroid", "normal", "eigen"):
+        np.testing.assert_array_equal(a[k].view(np.uint32), g[f"{k}_dev"].view(np.uint32))
+    np.testing.assert_array_equal(eng.point_labels(), g["point_label_dev"])
+    root, _ = eng.node_labels()
+    np.testing.assert_array_equal(canonical_labels(root), canonical_labels(g["node_cluster_dev"]))
+    c = eng.counts()
+    assert [c["clusters"], c["kept"]] == g["clusters_dev"].tolist()
+    # P1 against the RefMath vectors: centroid 1e-4 m, normal angle 1e-3 rad, eigen features 1e-3
+    used = g["used"].astype(bool)
+    np.testing.assert_allclose(a["centroid"], g["centroid_ref"], atol=1e-4)
+    cosang = (a["normal"][used] * g["normal_ref"][used]).sum(1)
+    assert (np.arccos(np.clip(cosang, -1, 1)) < 1e-3).mean() > 0.999
+    assert np.nanmax(np.abs(a["eigen"] - g["eigen_ref"])) < 2e-3
+    # P2 against the RefMath labels
+    assert partition_agreement(eng.point_labels(), g["point_label_ref"]) >= 0.995
+    off, _ = eng.lists("adjacency")
+    np.testing.assert_array_equal(np.diff(off).astype(np.int32)[used], g["adj_len"][used])

@@ -1,0 +1,128 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/vgs.h declares,
+parameter surface / task-file parsing (test:25-37, 108-125; point_clouds_IO.cpp:148-169), loud failure without a
+GPU, scene determinism, schedule-bound properties of the lazy local cut."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(vgs):
+    hdr = open(os.path.join(ROOT, "include", "vgs.h")).read()
+    declared = set(re.findall(r"\b(s?vgs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"vgs_status"}
+    lib = C.CDLL(vgs._lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    bound = {n for n, _, _ in vgs._lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+
+
+def test_defaults_match_task_files(vgs):
+    p = vgs.default_params(2)
+    assert (p.method, p.points_min, p.adjacency_min, p.voxels_min) == (2, 10, 3, 3)
+    assert np.float32(p.voxel_size) == np.float32(0.15) and np.float32(p.sig_w) == np.float32(2.0) and np.float32(p.cut_thred) == np.float32(0.3)
+    s = vgs.default_params(3)
+    assert s.method == 3 and np.float32(s.voxel_size) == np.float32(0.05) and np.float32(s.seed_size) == np.float32(0.25)
+    assert np.float32(s.sig_w) == np.float32(1.0) and np.float32(s.cut_thred) == np.float32(0.5)
+    assert (np.float32(s.color_impt), np.float32(s.spatial_impt), np.float32(s.normal_impt)) == (np.float32(0), np.float32(0.25), np.float32(0.75))
+
+
+def _write_task(path, method, lines):
+    body = ["// header"] * 70
+    for k, v in lines.items():
+        body[k] = str(v)
+    body[24] = str(method)
+    with open(path, "wb") as f:
+        f.write("\r\n".join(body).encode())  # the reference's task files are CRLF
+
+
+def test_parse_task_file_vgs(vgs, tmp_path):
+    f = tmp_path / "Task_File_VGS.txt"
+    _write_task(f, 2, {7: "Seg", 15: "Town_Test.pcd", 21: "Town_Test_VGS.pcd", 28: 0.15, 30: 0.5, 32: 0.2, 34: 0.21, 36: 0.22,
+                       38: 0.23, 40: 0.24, 42: 2, 44: 0.3, 46: 10, 48: 3, 50: 4})
+    p, inn, out = vgs.parse_task_file(str(f))
+    assert (inn, out) == ("Town_Test.pcd", "Town_Test_VGS.pcd")
+    assert p.method == 2 and (p.points_min, p.adjacency_min, p.voxels_min) == (10, 3, 4)
+    got = [p.voxel_size, p.graph_size, p.sig_p, p.sig_n, p.sig_o, p.sig_e, p.sig_c, p.sig_w, p.cut_thred]
+    np.testing.assert_array_equal(np.float32(got), np.float32([0.15, 0.5, 0.2, 0.21, 0.22, 0.23, 0.24, 2, 0.3]))
+
+
+def test_parse_task_file_svgs(vgs, tmp_path):
+    f = tmp_path / "Task_File_SVGS.txt"
+    _write_task(f, 3, {15: "a.pcd", 21: "b.pcd", 28: 0.05, 30: 0.25, 32: 0.5, 34: 0.2, 36: 0.2, 38: 0.2, 40: 0.2, 42: 0.2, 44: 1,
+                       46: 0, 48: 0.25, 50: 0.75, 52: 0.5, 54: 10, 56: 10, 58: 3, 60: 3})
+    p, _, _ = vgs.parse_task_file(str(f))
+    assert p.method == 3 and p.adjacency_min == 3
+    np.testing.assert_array_equal(np.float32([p.voxel_size, p.seed_size, p.graph_size, p.sig_w, p.cut_thred, p.color_impt, p.spatial_impt, p.normal_impt]),
+                                  np.float32([0.05, 0.25, 0.5, 1, 0.5, 0, 0.25, 0.75]))
+
+
+def test_parse_reference_task_files_if_present(vgs):
+    ref = "/root/reference/Task_File_VGS.txt"
+    if not os.path.exists(ref):
+        pytest.skip("reference not mounted (GPU box)")
+    p, inn, out = vgs.parse_task_file(ref)
+    d = vgs.default_params(2)
+    assert (inn, out) == ("Town_Test.pcd", "Town_Test_VGS.pcd")
+    for k in ("voxel_size", "graph_size", "sig_p", "sig_n", "sig_o", "sig_e", "sig_c", "sig_w", "cut_thred", "points_min", "adjacency_min", "voxels_min"):
+        assert getattr(p, k) == getattr(d, k), k
+    p3, _, _ = vgs.parse_task_file("/root/reference/Task_File_SVGS.txt")
+    d3 = vgs.default_params(3)
+    for k in ("voxel_size", "seed_size", "graph_size", "sig_w", "cut_thred", "color_impt", "spatial_impt", "normal_impt", "adjacency_min"):
+        assert getattr(p3, k) == getattr(d3, k), k
+
+
+def test_no_cpu_fallback(vgs):
+    """Without a HIP device the engine refuses to exist (the driver runs this file on a GPU-less container)."""
+    import conftest
+    if conftest._has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(vgs.VgsError) as e:
+        vgs.Engine(vgs.default_params(2))
+    assert e.value.status == vgs._lib.VGS_E_HIP
+
+
+def test_scenes_are_deterministic(vgs):
+    a = vgs.scenes.urban_scene(5000)
+    b = vgs.scenes.urban_scene(5000)
+    assert a.dtype == np.float32 and a.shape == (5000, 3)
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a).max() < 150 and (a != 0).all()
+    t0 = vgs.scenes.tiled_urban_scene(16000, tiles=(2, 1), tile_index=0)
+    t1 = vgs.scenes.tiled_urban_scene(16000, tiles=(2, 1), tile_index=1)
+    both = vgs.scenes.tiled_urban_scene(16000, tiles=(2, 1))
+    np.testing.assert_array_equal(np.concatenate([t0, t1]), both)
+    assert t0[:, 0].mean() < 0 < t1[:, 0].mean()
+
+
+def test_schedule_bounds_dominate_weight(oracle):
+    """csrc/vgs_math.h: vm_weight_bound_da >= weight and vm_weight_bound_d >= weight for every pair -- the two
+    facts the lazy local cut's evaluation order relies on."""
+    rng = np.random.default_rng(11)
+    for svgs, P in ((False, oracle.vgs_params(math=1)), (True, oracle.svgs_params(math=1)), (False, oracle.vgs_params(math=1, sig_p=0.05, sig_n=1.5, sig_w=0.7))):
+        for _ in range(4000):
+            def node():
+                c = rng.standard_normal(3) * rng.choice([0.05, 0.3, 2.0]) + np.array([3.0, -2.0, 1.0])
+                n = rng.standard_normal(3)
+                n /= np.linalg.norm(n)
+                f = rng.random(8)
+                nd = oracle.node16(c, n, f)
+                if rng.random() < 0.03:
+                    nd[rng.integers(0, 3)] = 0.0      # invalid position
+                if rng.random() < 0.03:
+                    nd[3 + rng.integers(0, 3)] = 0.0  # invalid normal
+                return nd
+            a, b = node(), node()
+            if rng.random() < 0.3:
+                b[3:6] = a[3:6] + rng.standard_normal(3).astype(np.float32) * 1e-3   # nearly parallel normals
+                b[3:6] /= np.linalg.norm(b[3:6])
+            w, ub_da, ub_d = oracle.weight_and_bounds(a, b, P, svgs)
+            if np.isnan(w):
+                continue
+            assert np.isnan(ub_da) or ub_da >= w, (w, ub_da)
+            assert ub_d >= w, (w, ub_d)
