@@ -132,23 +132,27 @@ vgs_status vgs_get_point_labels_device(vgs_ctx* ctx, const int32_t** labels_dev 
 vgs_status vgs_get_clusters(vgs_ctx* ctx, int64_t* offsets, int32_t* point_idx);
 
 /* ---- multi-GPU support (spatial tiles) -------------------------------------- */
-/* Shared grid: every rank bins on the grid whose growth state is chained rank to rank. */
+/* The reference is single-process; these entry points are what a tiled driver needs around the same stages.
+ * One context per GPU holds one tile plus a halo of raw points (2*graph_size + voxel_size wide).
+ * Shared grid: the octree growth state (PCL OctreePointCloud box) is chained rank to rank. */
 typedef struct { double min[3]; uint64_t shift[3]; int32_t depth; int32_t defined; } vgs_grid_state;
 vgs_status vgs_grid_state_init(vgs_grid_state* g);
-/* advance g over this context's points (in index order), i.e. what inserting them after all earlier ranks'
- * points does to the octree box; call on rank r after receiving g from rank r-1 */
+/* advance g over this context's points in index order (what inserting them after all earlier ranks' points does
+ * to the octree box); call on rank r after receiving g from rank r-1 */
 vgs_status vgs_grid_advance(vgs_ctx* ctx, vgs_grid_state* g);
-/* pin the final grid before vgs_voxelize (all ranks use the state after the last rank) */
+/* pin the final grid before vgs_voxelize: every rank bins with the state left by the last rank */
 vgs_status vgs_set_grid(vgs_ctx* ctx, const vgs_grid_state* g);
-/* mark which voxels this rank owns: those whose centre lies in [lo, hi) in x and y */
+/* this rank owns the voxels whose centre lies in [lo, hi) in x and y; others are halo (computed redundantly,
+ * their own connections are not trusted).  Components are then built from the connections that have an owned
+ * endpoint, cluster sizes count owned voxels, and point labels wait for vgs_apply_root_labels. */
 vgs_status vgs_set_owned_region(vgs_ctx* ctx, const double* lo_xy, const double* hi_xy);
-/* boundary records after vgs_segment: for every final connection (i,k) with i owned and k not owned:
- * (global voxel code of i, local root of i, global voxel code of k); plus per owned root: (root, owned voxel count) */
-vgs_status vgs_get_boundary(vgs_ctx* ctx, int64_t* n_edges, uint64_t* edge_code_i, int32_t* edge_root_i, uint64_t* edge_code_k);
-vgs_status vgs_get_owned_roots(vgs_ctx* ctx, int64_t* n_roots, int32_t* root, int32_t* owned_voxels, uint64_t* root_code);
-vgs_status vgs_lookup_codes(vgs_ctx* ctx, const uint64_t* codes, int64_t n, int32_t* voxel_id /* -1 if absent */,
-                            int32_t* root_of, uint8_t* owned);
-/* relabel points with a caller-computed global label per local root (-1 = dropped) */
+/* after vgs_segment: one record (global voxel code, local component root) for both endpoints of every final
+ * connection that crosses the ownership border.  Records of all ranks that share a code name the same segment.
+ * Two-call protocol: code == NULL returns the count. */
+vgs_status vgs_get_boundary(vgs_ctx* ctx, int64_t* n_records, uint64_t* code, int32_t* root);
+/* local component roots that contain owned voxels, with the number of owned voxels (two-call protocol) */
+vgs_status vgs_get_owned_roots(vgs_ctx* ctx, int64_t* n_roots, int32_t* root, int32_t* owned_voxels);
+/* final labels: label[k] for local root root[k] (-1 = dropped); points of halo voxels and of unlisted roots get -1 */
 vgs_status vgs_apply_root_labels(vgs_ctx* ctx, const int32_t* root, const int32_t* label, int64_t n_roots);
 
 #ifdef __cplusplus

@@ -80,9 +80,8 @@ SYMBOLS = [
     ("vgs_grid_advance", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_set_grid", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_set_owned_region", C.c_int, [_P, _P, _P]),
-    ("vgs_get_boundary", C.c_int, [_P, _P, _P, _P, _P]),
-    ("vgs_get_owned_roots", C.c_int, [_P, _P, _P, _P, _P]),
-    ("vgs_lookup_codes", C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
+    ("vgs_get_boundary", C.c_int, [_P, _P, _P, _P]),
+    ("vgs_get_owned_roots", C.c_int, [_P, _P, _P, _P]),
     ("vgs_apply_root_labels", C.c_int, [_P, _P, _P, C.c_int64]),
 ]
 

@@ -133,6 +133,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->node.release(); c->used_ids.release(); c->used_rank.release();
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_key.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->conn.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
+  c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -464,18 +465,5 @@ vgs_status vgs_get_clusters(vgs_ctx* c, int64_t* offsets, int32_t* point_idx) {
 }
 
 // ---- multi-GPU ---------------------------------------------------------------
-vgs_status vgs_grid_state_init(vgs_grid_state* g) {
-  if (!g) return VGS_E_ARG;
-  std::memset(g, 0, sizeof(*g));
-  return VGS_OK;
-}
-
-vgs_status vgs_grid_advance(vgs_ctx* c, vgs_grid_state*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_set_grid(vgs_ctx* c, const vgs_grid_state*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_set_owned_region(vgs_ctx* c, const double*, const double*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_get_boundary(vgs_ctx* c, int64_t*, uint64_t*, int32_t*, uint64_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_get_owned_roots(vgs_ctx* c, int64_t*, int32_t*, int32_t*, uint64_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_lookup_codes(vgs_ctx* c, const uint64_t*, int64_t, int32_t*, int32_t*, uint8_t*) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
-vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t*, const int32_t*, int64_t) { if (!c) return VGS_E_ARG; c->err = "multi-GPU tiling not built yet"; return VGS_E_UNSUPPORTED; }
 
 }  // extern "C"

@@ -174,7 +174,7 @@ __global__ void k_iota(uint32_t* p, int64_t n) {
 __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
-                                                     uint32_t* __restrict__ parent) {
+                                                     const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent) {
   const int64_t u = blockIdx.x;
   if (u >= U) return;
   const uint32_t i = used_ids[u];
@@ -184,21 +184,23 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
   for (int k = threadIdx.x; k < n; k += 64) {
     if (!mrow[k]) continue;
     const uint32_t t = (uint32_t)row[k];
-    if (t > i) uf_union(parent, i, t);  // each mutual edge appears in both rows: union once
+    // tiled runs: a connection is trusted only if one endpoint is owned (both neighbourhoods are then complete)
+    if (t > i && (!owned || owned[i] || owned[t])) uf_union(parent, i, t);  // each mutual edge appears in both rows: union once
   }
   if (threadIdx.x == 0) {
     const int32_t t = attach[i];
-    if (t >= 0) uf_union(parent, i, (uint32_t)t);
+    if (t >= 0 && (!owned || owned[i])) uf_union(parent, i, (uint32_t)t);
   }
 }
 
-__global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, uint32_t* __restrict__ csz) {
+__global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, const uint8_t* __restrict__ owned, uint32_t* __restrict__ csz) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;   // V is padded to the block size by the caller? no: tail lanes simply leave
   const uint32_t r = uf_find(parent, (uint32_t)v);
   parent[v] = r;   // only shortens paths: concurrent finds stay correct
   // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address)
-  unsigned long long todo = __ballot(true);
+  unsigned long long todo = __ballot(!owned || owned[v]);   // tiled runs count owned voxels only
+  if (owned && !owned[v]) return;
   const int lane = threadIdx.x & 63;
   while (todo) {
     const int l0 = __ffsll((long long)todo) - 1;
@@ -303,11 +305,12 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->conn.ensure(16));
   }
   // connected components
+  if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
   hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, mutual, c->attach.p, c->parent.p);
-  hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->csz.p);
+                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
+  hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
   // cluster filter + labels
   uint32_t* keep_flag = c->head_flag.p;  // >= N >= V entries, free after features
   VGS_HIP_TRY(c, c->head_flag.ensure(V + 1));

@@ -135,6 +135,10 @@ struct vgs_ctx {
   // multi-GPU
   bool have_region = false;
   double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
+  DevBuf<uint8_t> owned;        // per voxel: 1 = centre inside this rank's region
+  DevBuf<uint64_t> bnd_code;    // boundary records
+  DevBuf<int32_t> bnd_root;
+  DevBuf<int32_t> root_label;   // per voxel id: label of the component rooted there
 };
 
 #define VGS_HIP_TRY(ctx, expr)                                                                       \
@@ -154,5 +158,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_localcut(vgs_ctx* c);
 vgs_status vgs_stage_merge(vgs_ctx* c);
+vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs);
+vgs_status vgs_compute_owned(vgs_ctx* c);
 
 #endif

@@ -150,20 +150,18 @@ __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 // ---------------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------------
-static vgs_status grow_box(vgs_ctx* c) {
-  // Sequential semantics, parallel execution: only points that fall outside the current box change it,
-  // so the device finds the next such point and the host replays PCL's growth rule for it.
-  c->epochs.clear();
-  OctreeBox& box = c->box;
-  if (c->grid_pinned) {
-    Epoch e; e.first = 0;
-    for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
-    c->epochs.push_back(e);
-  } else {
-    box = OctreeBox();
-    box.res = (double)c->P.voxel_size;
+// Sequential semantics, parallel execution: only points that fall outside the current box change it, so the
+// device finds the next such point and the host replays PCL's growth rule for it.
+vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
+  if (record_epochs) {
+    c->epochs.clear();
+    if (box.defined) {
+      Epoch e; e.first = 0;
+      for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
+      c->epochs.push_back(e);
+    }
   }
-  VGS_HIP_TRY(c, c->counters.ensure(16));
+  VGS_HIP_TRY(c, c->counters.ensure(64));
   unsigned long long* d_res = (unsigned long long*)c->counters.p;
   int64_t start = 0;
   float pt[3];
@@ -182,16 +180,26 @@ static vgs_status grow_box(vgs_ctx* c) {
     VGS_HIP_TRY(c, hipMemcpyAsync(&idx, d_res, sizeof(idx), hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (idx == ~0ull) break;
-    if (c->grid_pinned) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
+    if (c->grid_pinned && record_epochs) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
     VGS_HIP_TRY(c, hipMemcpy(pt, c->xyz + (int64_t)idx * c->stride_f, 3 * sizeof(float), hipMemcpyDeviceToHost));
     box.adopt(pt);
-    Epoch e; e.first = (int64_t)idx;
-    for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
-    c->epochs.push_back(e);
-    if ((int)c->epochs.size() >= VGS_MAX_EPOCHS) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
+    if (record_epochs) {
+      Epoch e; e.first = (int64_t)idx;
+      for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
+      c->epochs.push_back(e);
+      if ((int)c->epochs.size() >= VGS_MAX_EPOCHS) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
+    }
     start = (int64_t)idx + 1;
   }
   return VGS_OK;
+}
+
+static vgs_status grow_box(vgs_ctx* c) {
+  if (!c->grid_pinned) {
+    c->box = OctreeBox();
+    c->box.res = (double)c->P.voxel_size;
+  }
+  return vgs_grow_box_from(c, c->box, true);
 }
 
 vgs_status vgs_stage_voxelize(vgs_ctx* c) {

@@ -1,0 +1,214 @@
+"""One process per GPU: spatial tiles, shared grid, one all-gather of boundary records.
+
+The reference is single-process.  Everything per voxel (binning, PCA, adjacency, local cut, mutual filter) is
+local to a ball of radius graph_size; only the connected components are global.  Each rank therefore segments
+its tile plus a halo of raw points (2*graph_size + voxel_size wide) on ONE shared grid, trusts the connections
+that have an owned endpoint, and publishes one (voxel code, local root) record per endpoint of every connection
+crossing the ownership border.  After one all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) every rank
+runs the same small union-find over (rank, root) pairs and labels its own points.  Payloads are O(boundary
+voxels): the exchange is latency-bound, so it is a single collective with no tuning.
+
+`merge_boundary` is pure host logic (numpy/scipy) and is what the world_size-2 gloo tests exercise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VgsGridState
+from .api import Engine, _ptr
+
+
+def tile_regions(tiles, pitch, center=(0.0, 0.0)):
+    """Ownership rectangles [lo, hi) of a tiles[0] x tiles[1] layout; outer edges are open ended."""
+    tx, ty = tiles
+    big = 1.0e30
+    out = []
+    for k in range(tx * ty):
+        i, j = k % tx, k // tx
+        x0 = center[0] + (i - tx / 2.0) * pitch
+        y0 = center[1] + (j - ty / 2.0) * pitch
+        lo = [x0 if i > 0 else -big, y0 if j > 0 else -big]
+        hi = [x0 + pitch if i < tx - 1 else big, y0 + pitch if j < ty - 1 else big]
+        out.append((np.array(lo, dtype=np.float64), np.array(hi, dtype=np.float64)))
+    return out
+
+
+def merge_boundary(records, roots, voxels_min):
+    """Global segments from per-rank results.
+
+    records[r] = (codes uint64[], local_roots int32[]): one entry per endpoint of a border-crossing connection.
+    roots[r]   = (local_roots int32[], owned_voxel_counts int32[]): every local component with owned voxels.
+    Returns labels[r] (int32, aligned with roots[r][0]): dense global label or -1 when the global segment has
+    <= voxels_min voxels (the reference's filter, voxel_segmentation.h:969), and the number of kept segments.
+    Deterministic: every rank computes the same table from the same gathered inputs.
+    """
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    world = len(roots)
+    ids, cnts, owner = [], [], []
+    for r in range(world):
+        rt, oc = roots[r]
+        ids.append((np.int64(r) << 32) | rt.astype(np.int64))
+        cnts.append(oc.astype(np.int64))
+        owner.append(np.full(rt.shape, r, dtype=np.int64))
+    ids = np.concatenate(ids) if ids else np.zeros(0, np.int64)
+    cnts = np.concatenate(cnts) if cnts else np.zeros(0, np.int64)
+    rec_code = np.concatenate([records[r][0].astype(np.uint64) for r in range(world)]) if world else np.zeros(0, np.uint64)
+    rec_id = np.concatenate([(np.int64(r) << 32) | records[r][1].astype(np.int64) for r in range(world)]) if world else np.zeros(0, np.int64)
+    # nodes: every (rank, root) that owns voxels or appears in a record
+    nodes = np.unique(np.concatenate([ids, rec_id]))
+    n = nodes.size
+    if n == 0:
+        return [np.zeros(0, np.int32) for _ in range(world)], 0
+    pos = np.searchsorted(nodes, rec_id)
+    order = np.argsort(rec_code, kind="stable")
+    c_sorted, p_sorted = rec_code[order], pos[order]
+    same = c_sorted[1:] == c_sorted[:-1]
+    a, b = p_sorted[:-1][same], p_sorted[1:][same]
+    g = coo_matrix((np.ones(a.size, dtype=np.int8), (a, b)), shape=(n, n))
+    _, comp = connected_components(g, directed=False)
+    total = np.zeros(comp.max() + 1, dtype=np.int64)
+    np.add.at(total, comp[np.searchsorted(nodes, ids)], cnts)
+    keep = total > voxels_min
+    # dense labels in order of the smallest (rank, root) id of each kept component
+    first = np.full(comp.max() + 1, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, comp, nodes)
+    kept_ids = np.nonzero(keep)[0]
+    rank_of = np.full(comp.max() + 1, -1, dtype=np.int64)
+    rank_of[kept_ids[np.argsort(first[kept_ids], kind="stable")]] = np.arange(kept_ids.size)
+    labels = []
+    for r in range(world):
+        rt = roots[r][0]
+        nid = (np.int64(r) << 32) | rt.astype(np.int64)
+        labels.append(rank_of[comp[np.searchsorted(nodes, nid)]].astype(np.int32))
+    return labels, int(kept_ids.size)
+
+
+def all_gather_varlen(dist, arr, device=None):
+    """all_gather of 1-D numpy arrays of different lengths (one size exchange + one padded payload exchange)."""
+    import torch
+    world = dist.get_world_size()
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if device is not None:
+        t = t.to(device)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    outs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+class TiledSegmenter:
+    """Drives one Engine per rank over one tile of a tiles[0] x tiles[1] layout."""
+
+    def __init__(self, params, dist, tiles, rank, world, pitch=None, center=(0.0, 0.0)):
+        self.p = params
+        self.dist = dist
+        self.rank, self.world = rank, world
+        self.tiles = tiles
+        self.halo = 2.0 * params.graph_size + params.voxel_size
+        self.engine = Engine(params)
+        self.pitch = pitch
+        self.center = center
+        self.device = None       # where the points live
+        self.coll_device = None  # where collective payloads live: the GPU for RCCL ("nccl"), the host for gloo
+        self._keep = None
+        self.n_own = 0
+        self.kept = 0
+
+    # -- input: own points + halo strips of the neighbours (data loading, outside the timed region) --
+    def set_points_device(self, d_xyz, xyz_host):
+        import torch
+        self.device = d_xyz.device
+        backend = self.dist.get_backend() if hasattr(self.dist, "get_backend") else "nccl"
+        self.coll_device = self.device if backend == "nccl" else torch.device("cpu")
+        if self.pitch is None:
+            ext = float(xyz_host[:, 0].max() - xyz_host[:, 0].min())
+            t = torch.tensor([ext], device=self.coll_device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            self.pitch = float(t.item())
+        self.regions = tile_regions(self.tiles, self.pitch, self.center)
+        lo, hi = self.regions[self.rank]
+        h = self.halo
+        x, y = xyz_host[:, 0].astype(np.float64), xyz_host[:, 1].astype(np.float64)
+        near = (x < lo[0] + h) | (x >= hi[0] - h) | (y < lo[1] + h) | (y >= hi[1] - h)
+        strips = all_gather_varlen(self.dist, np.ascontiguousarray(xyz_host[near]).reshape(-1), self.coll_device)
+        extra = []
+        for r, s in enumerate(strips):
+            if r == self.rank or s.size == 0:
+                continue
+            s = s.reshape(-1, 3)
+            sx, sy = s[:, 0].astype(np.float64), s[:, 1].astype(np.float64)
+            m = (sx >= lo[0] - h) & (sx < hi[0] + h) & (sy >= lo[1] - h) & (sy < hi[1] + h)
+            extra.append(s[m])
+        self.n_own = xyz_host.shape[0]
+        if extra and sum(e.shape[0] for e in extra):
+            halo_pts = torch.from_numpy(np.concatenate(extra)).to(self.device)
+            local = torch.cat([d_xyz, halo_pts], dim=0).contiguous()
+        else:
+            local = d_xyz
+        torch.cuda.synchronize(self.device)
+        self._keep = local
+        self.engine.set_points_device(local.data_ptr(), local.shape[0], 12, keep=local)
+        self.engine._ck(self.engine._L.vgs_set_owned_region(self.engine._h, _ptr(lo), _ptr(hi)))
+
+    def _chain_grid(self):
+        import torch
+        g = VgsGridState()
+        L = self.engine._L
+        L.vgs_grid_state_init(C.byref(g))
+        buf = torch.zeros(8, dtype=torch.float64, device=self.coll_device)
+        for r in range(self.world):
+            if self.rank == r:
+                self.engine._ck(L.vgs_grid_advance(self.engine._h, C.byref(g)))
+                vals = [g.min[0], g.min[1], g.min[2], float(g.shift[0]), float(g.shift[1]), float(g.shift[2]), float(g.depth), float(g.defined)]
+                buf = torch.tensor(vals, dtype=torch.float64, device=self.coll_device)
+            self.dist.broadcast(buf, src=r)
+            v = buf.cpu().numpy()
+            for a in range(3):
+                g.min[a] = float(v[a])
+                g.shift[a] = int(v[3 + a])
+            g.depth, g.defined = int(v[6]), int(v[7])
+        self.engine._ck(L.vgs_set_grid(self.engine._h, C.byref(g)))
+
+    def run(self):
+        eng, L = self.engine, self.engine._L
+        self._chain_grid()
+        eng.voxelize(); eng.features(); eng.adjacency(); eng.segment()
+        n = C.c_int64(0)
+        eng._ck(L.vgs_get_boundary(eng._h, C.byref(n), None, None))
+        code = np.zeros(max(n.value, 1), dtype=np.uint64)
+        root = np.zeros(max(n.value, 1), dtype=np.int32)
+        if n.value:
+            eng._ck(L.vgs_get_boundary(eng._h, C.byref(n), _ptr(code), _ptr(root)))
+        code, root = code[: n.value], root[: n.value]
+        nr = C.c_int64(0)
+        eng._ck(L.vgs_get_owned_roots(eng._h, C.byref(nr), None, None))
+        rt = np.zeros(max(nr.value, 1), dtype=np.int32)
+        oc = np.zeros(max(nr.value, 1), dtype=np.int32)
+        if nr.value:
+            eng._ck(L.vgs_get_owned_roots(eng._h, C.byref(nr), _ptr(rt), _ptr(oc)))
+        rt, oc = rt[: nr.value], oc[: nr.value]
+        # the one data-path collective: boundary records + per-root owned counts of every rank
+        codes = all_gather_varlen(self.dist, code.view(np.int64), self.coll_device)
+        rroots = all_gather_varlen(self.dist, root, self.coll_device)
+        allrt = all_gather_varlen(self.dist, rt, self.coll_device)
+        alloc = all_gather_varlen(self.dist, oc, self.coll_device)
+        records = [(c.view(np.uint64), r) for c, r in zip(codes, rroots)]
+        roots = list(zip(allrt, alloc))
+        labels, self.kept = merge_boundary(records, roots, self.p.voxels_min)
+        mine = np.ascontiguousarray(labels[self.rank])
+        eng._ck(L.vgs_apply_root_labels(eng._h, _ptr(np.ascontiguousarray(rt)), _ptr(mine), rt.size))
+
+    def point_labels(self):
+        """Labels of this rank's own points (halo points belong to other ranks)."""
+        return self.engine.point_labels()[: self.n_own]
