@@ -93,6 +93,16 @@ class Engine:
     def segment(self): self._ck(self._L.vgs_segment(self._h))
     def run(self): self._ck(self._L.vgs_run(self._h))
 
+    # ---- SVGS
+    def set_supervoxel_labels(self, labels, max_label):
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        if labels.shape[0] != self.n:
+            raise ValueError("one label per point required")
+        self._ck(self._L.svgs_set_supervoxel_labels(self._h, _ptr(labels), int(max_label)))
+
+    def supervoxels(self): self._ck(self._L.svgs_supervoxels(self._h))
+    def svgs_segment(self): self._ck(self._L.svgs_segment(self._h))
+
     # ---- results
     def counts(self):
         c = np.zeros(_lib.N_COUNTS, dtype=np.int64)
@@ -256,6 +266,82 @@ class VoxelBasedSegmentation:
     def getClusterIdx(self):                                 # VS:117
         if not self._drawn:
             return []   # clusters_point_idx_ is only filled by drawColorMapofPointsinClusters (VS:1006)
+        off, idx = self._eng.clusters()
+        return [idx[off[k]:off[k + 1]].tolist() for k in range(len(off) - 1)]
+
+    @property
+    def engine(self):
+        return self._eng
+
+
+class SuperVoxelBasedSegmentation:
+    """pcl::SuperVoxelBasedSegmentation<PointXYZ> (supervoxel_segmentation.h:58-2308), same member names and call order."""
+
+    def __init__(self, input_resolution, device=0):                                   # SS:85
+        self._p = default_params(3, voxel_size=float(input_resolution), device=device)
+        self._eng = Engine(self._p)
+        self._cloud = None
+        self._have_labels = False
+
+    def setInputCloud(self, cloud):
+        self._cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+
+    def getCloudPointNum(self, cloud):                                                # SS:101
+        self._cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        return int(self._cloud.shape[0])
+
+    def addPointsFromInputCloud(self):                                                # test:142 (own octree: bookkeeping only)
+        self._eng.set_points(self._cloud)
+
+    def setVoxelSize(self, input_resolution, points_num_min):                         # SS:143
+        self._p.voxel_size = float(input_resolution)
+        self._p.points_min = int(points_num_min)
+        self._eng.set_params(self._p)
+
+    def setSupervoxelSize(self, input_resolution, voxels_num_min, points_num_min, adjacency_num_min):  # SS:150
+        self._p.seed_size = float(input_resolution)
+        self._p.voxels_min = int(voxels_num_min)
+        self._p.adjacency_min = int(adjacency_num_min)
+        self._eng.set_params(self._p)
+
+    def setGraphSize(self, small_resolution, large_resolution):                       # SS:159 (the small radius feeds nothing, SS:1438-1475)
+        self._p.graph_size = float(large_resolution)
+        self._eng.set_params(self._p)
+
+    def setBoundingBox(self, *args):                                                  # SS:166
+        pass
+
+    def setSupervoxelCentersCentroids(self):                                          # SS:178 (own-octree bookkeeping)
+        pass
+
+    def setSupervoxelLabels(self, labels, max_label):
+        """What pcl::SupervoxelClustering::getLabeledCloud / getMaxLabel return (SS:283-284), supplied by the caller."""
+        self._eng.set_supervoxel_labels(labels, max_label)
+        self._have_labels = True
+
+    def getVoxelNum(self):                                                            # SS:111
+        return self._eng.counts()["voxels"]
+
+    def getSuperVoxelNum(self):                                                       # SS:118
+        return self._eng.counts()["supervoxels"]
+
+    def segmentSupervoxelCloudWithGraphModel(self, sig_a, sig_b, sig_l, cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w):  # SS:362
+        q = self._p
+        q.color_impt, q.spatial_impt, q.normal_impt = float(sig_a), float(sig_b), float(sig_l)
+        q.cut_thred, q.sig_p, q.sig_n, q.sig_o, q.sig_e, q.sig_c, q.sig_w = (float(v) for v in (
+            cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w))
+        self._eng.set_params(q)
+        if not self._have_labels:
+            self._eng.supervoxels()
+        self._eng.svgs_segment()
+
+    def drawColorMapofPointsinClusters(self, output_cloud=None):                      # SS:613
+        return self._eng.point_labels()
+
+    def getClusterNum(self):                                                          # SS:124
+        return self._eng.counts()["clusters"]
+
+    def getClusterIdx(self):                                                          # SS:130
         off, idx = self._eng.clusters()
         return [idx[off[k]:off[k + 1]].tolist() for k in range(len(off) - 1)]
 

@@ -133,6 +133,8 @@ void vgs_destroy(vgs_ctx* c) {
   c->node.release(); c->used_ids.release(); c->used_rank.release();
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_key.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->conn.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
+  c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
+  c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -236,8 +238,10 @@ vgs_status vgs_segment(vgs_ctx* c) {
 vgs_status vgs_run(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
   if (c->P.method == 3) {
-    vgs_status s = svgs_supervoxels(c);
-    if (s != VGS_OK) return s;
+    if (!c->sv_have_labels) {
+      vgs_status s = svgs_supervoxels(c);
+      if (s != VGS_OK) return s;
+    }
     return svgs_segment(c);
   }
   vgs_status s;
@@ -250,21 +254,40 @@ vgs_status vgs_run(vgs_ctx* c) {
   return VGS_OK;
 }
 
-// ---- SVGS (to be widened: SURVEY.md 8 rows a12-a15) ---------------------------------------
-vgs_status svgs_set_supervoxel_labels(vgs_ctx* c, const int32_t*, int32_t) {
-  if (!c) return VGS_E_ARG;
-  c->err = "SVGS path not built yet";
-  return VGS_E_UNSUPPORTED;
+// ---- SVGS -------------------------------------------------------
+vgs_status svgs_set_supervoxel_labels(vgs_ctx* c, const int32_t* labels_host, int32_t max_label) {
+  if (!c || (!labels_host && c->N > 0)) return VGS_E_ARG;
+  if (c->P.method != 3) { c->err = "svgs_set_supervoxel_labels: context was created for method 2 (VGS)"; return VGS_E_STATE; }
+  if (c->stage < ST_POINTS) { c->err = "svgs_set_supervoxel_labels: set the input cloud first"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  VGS_HIP_TRY(c, c->sv_label.ensure(c->N > 0 ? c->N : 1));
+  if (c->N > 0) VGS_HIP_TRY(c, hipMemcpy(c->sv_label.p, labels_host, (size_t)c->N * 4, hipMemcpyHostToDevice));
+  c->sv_max_label = max_label;
+  c->sv_have_labels = true;
+  if (c->stage > ST_POINTS) c->stage = ST_POINTS;
+  return VGS_OK;
 }
+
 vgs_status svgs_supervoxels(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
-  c->err = "SVGS path not built yet";
+  c->err = "svgs_supervoxels: the VCCS-style clustering kernel is not built yet; supply labels with svgs_set_supervoxel_labels";
   return VGS_E_UNSUPPORTED;
 }
+
 vgs_status svgs_segment(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
-  c->err = "SVGS path not built yet";
-  return VGS_E_UNSUPPORTED;
+  if (c->P.method != 3) { c->err = "svgs_segment: context was created for method 2 (VGS)"; return VGS_E_STATE; }
+  if (c->stage < ST_POINTS || !c->sv_have_labels) { c->err = "svgs_segment: needs the input cloud and supervoxel labels (createSupervoxels)"; return VGS_E_STATE; }
+  vgs_status s;
+  if ((s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_svgs_group(c); })) != VGS_OK) return s;       // SS:279-331
+  if ((s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); })) != VGS_OK) return s;         // SS:1238-1303
+  if ((s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_svgs_neighbours(c); })) != VGS_OK) return s;  // SS:1477-1521
+  if ((s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); })) != VGS_OK) return s;          // SS:384-413
+  if ((s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); })) != VGS_OK) return s;                // SS:416-420
+  c->stage = ST_SEGMENTED;
+  c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] +
+                          c->times[VGS_T_MERGE];
+  return VGS_OK;
 }
 
 // ---- results ------------------------------------------------------------------------------
@@ -372,7 +395,7 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
     VGS_HIP_TRY(c, hipSetDevice(c->device));
     VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     keys.resize((size_t)U * c->adj_stride);
-    if (which == 0 && c->adj_pruned) {
+    if (which == 0 && c->adj_pruned && c->P.method == 2) {
       // getOneVoxelAdjacency wants every neighbour: the hot-path rows keep the used ones only, so run the FULL pass
       DevBuf<uint64_t> fk; DevBuf<uint32_t> fc, fn;
       VGS_HIP_TRY(c, fk.ensure(keys.size())); VGS_HIP_TRY(c, fc.ensure(U)); VGS_HIP_TRY(c, fn.ensure(U));

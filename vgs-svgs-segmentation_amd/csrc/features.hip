@@ -114,7 +114,8 @@ vgs_status vgs_stage_features(vgs_ctx* c) {
   uint32_t* used_flag = c->head_flag.p;  // free after voxelize
   uint32_t* excl = c->perm_a.p;
   const unsigned nb = (unsigned)((V + FEAT_TB - 1) / FEAT_TB);
-  hipLaunchKernelGGL(k_features, dim3(nb), dim3(FEAT_TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, c->P.points_min,
+  hipLaunchKernelGGL(k_features, dim3(nb), dim3(FEAT_TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V,
+                     c->P.method == 3 ? -1 : c->P.points_min,  // every supervoxel is used (SS:1288)
                      c->P.method == 3 ? 1 : 0, c->node.p, used_flag);
   size_t bytes = 0;
   VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, bytes, used_flag, excl, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));

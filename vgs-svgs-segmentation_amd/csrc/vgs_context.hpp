@@ -132,6 +132,14 @@ struct vgs_ctx {
   double times[VGS_T_COUNT] = {0};
   hipEvent_t ev[8] = {nullptr};
 
+  // SVGS
+  DevBuf<int32_t> sv_label;     // per point: supervoxel label (0 = unassigned), what getLabeledCloud returns (SS:283)
+  int32_t sv_max_label = 0;
+  bool sv_have_labels = false;
+  DevBuf<uint32_t> sv_key_a, sv_key_b;
+  DevBuf<uint64_t> cell_code_a, cell_code_b;
+  DevBuf<uint32_t> cell_id_a, cell_id_b, cell_start;
+
   // multi-GPU
   bool have_region = false;
   double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
@@ -158,6 +166,8 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_localcut(vgs_ctx* c);
 vgs_status vgs_stage_merge(vgs_ctx* c);
+vgs_status vgs_stage_svgs_group(vgs_ctx* c);
+vgs_status vgs_stage_svgs_neighbours(vgs_ctx* c);
 vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs);
 vgs_status vgs_compute_owned(vgs_ctx* c);
 
