@@ -30,11 +30,11 @@ def cpu_baseline(v, xyz_full, params, target_points=40_000):
     import numpy as np
     import refcpu_py as R
 
-    # crop: a square window around a building corner of the scene (ground + two facades), grown until it
-    # holds about target_points points
-    x0, y0 = float(xyz_full[:, 0].mean()), float(xyz_full[:, 1].mean())
-    # building of lot (0,0) of the urban layout sits near (-L/2 + pitch/2): use the densest 2 m cell instead
-    H, xe, ye = np.histogram2d(xyz_full[:, 0], xyz_full[:, 1], bins=64)
+    # crop: a square window centred on the strongest facade column of the scene (most points above 1 m in a
+    # 0.5 m x 0.5 m cell), grown until it holds about target_points points: ground + facade, the mix the scene is made of
+    hi = xyz_full[:, 2] > 1.0
+    nb = max(8, int((xyz_full[:, 0].max() - xyz_full[:, 0].min()) / 0.5))
+    H, xe, ye = np.histogram2d(xyz_full[hi, 0], xyz_full[hi, 1], bins=nb)
     i, j = np.unravel_index(np.argmax(H), H.shape)
     x0, y0 = 0.5 * (xe[i] + xe[i + 1]), 0.5 * (ye[j] + ye[j + 1])
     a = 0.5
@@ -42,7 +42,7 @@ def cpu_baseline(v, xyz_full, params, target_points=40_000):
         m = (np.abs(xyz_full[:, 0] - x0) < a) & (np.abs(xyz_full[:, 1] - y0) < a)
         if m.sum() >= target_points or a > 30:
             break
-        a *= 1.15
+        a *= 1.1
     sample = np.ascontiguousarray(xyz_full[m])
     rp = R.vgs_params(voxel_size=params.voxel_size, graph_size=params.graph_size, sig_p=params.sig_p, sig_n=params.sig_n,
                       sig_o=params.sig_o, sig_e=params.sig_e, sig_c=params.sig_c, sig_w=params.sig_w, cut_thred=params.cut_thred,

@@ -145,7 +145,171 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
     }
   };
 
-  for (int round = 0; m >= 2; ++round) {
+  // descending bitonic sort of list[0, nl): weight first, then ascending (a, b); every thread takes part
+  auto sort_desc = [&](int nl) {
+    int np = 64;
+    while (np < nl) np <<= 1;
+    for (int k = nl + tid; k < np; k += LC_TB) list[k] = 0ull;
+    __syncthreads();
+    for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
+      for (int sl = sbit - 1; sl >= 0; --sl) {
+        const int strd = 1 << sl;
+        for (int t = tid; t < (np >> 1); t += LC_TB) {
+          const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
+          const int hi = lo + strd;
+          const bool dn = ((lo & size) == 0);
+          const uint64_t x = list[lo], y = list[hi];
+          if ((x < y) == dn) { list[lo] = y; list[hi] = x; }
+        }
+        __syncthreads();
+      }
+    }
+  };
+  // sequential merge of the sorted list on one wavefront, 64 edges per step; ends with a workgroup barrier
+  auto merge_all = [&](int nl) {
+    if (wave == 0) {
+      int pos = 0;
+      while (pos < nl) {
+        const int e = pos + lane;
+        bool pass = false;
+        float w = 0.f;
+        int sa = 0, sb = 0;
+        if (e < nl) {
+          const uint64_t key = list[e];
+          w = vm_from_bits((uint32_t)(key >> 32));
+          const uint32_t tb = 0xffffffffu - (uint32_t)key;
+          sa = seg[tb >> 16];
+          sb = seg[tb & 0xffffu];
+          pass = (sa != sb) && (w > thr[sa]) && (w > thr[sb]);
+        }
+        const unsigned long long mk = __ballot(pass);
+        if (mk == 0ull) { pos += 64; continue; }  // nothing in these 64 edges can merge in the current state
+        const int f = __ffsll((long long)mk) - 1;  // first mergeable edge in order: it merges (state unchanged before it)
+        const float wf = __shfl(w, f, 64);
+        const int s1 = __shfl(sa, f, 64), s2 = __shfl(sb, f, 64);
+        const float t1 = thr[s1], t2 = thr[s2];
+        const int keep = (t1 >= t2) ? s1 : s2;   // VS:1972-1983: the segment with the larger threshold survives
+        const int gone = (t1 >= t2) ? s2 : s1;
+        const int nsz = (int)ssize[keep] + (int)ssize[gone];
+        wave_sync();
+        if (lane == 0) {
+          ssize[keep] = (uint16_t)nsz;
+          ssize[gone] = 0;
+          thr[keep] = vm_cut_threshold(wf, P.cut, nsz);  // seg_int = w (VS:1988)
+        }
+        for (int c = lane; c < m; c += 64)
+          if (seg[c] == gone) seg[c] = (uint16_t)keep;
+        wave_sync();
+        pos += f + 1;
+        // stop when fewer than two segments can still merge at the next (and every later) weight
+        const float wn = (pos < nl) ? vm_from_bits((uint32_t)(list[pos] >> 32)) : 0.f;
+        int active = 0;
+        for (int c = lane; c < m; c += 64) active += (ssize[c] != 0 && thr[c] < wn) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o, 64);
+        if (active < 2) break;
+      }
+    }
+    __syncthreads();
+  };
+
+  // ======================= fast path (facts S and F of localcut_wave.hpp) =======================
+  // 1. the voxel can only ever merge through an incident edge heavier than a singleton's threshold thr0;
+  // 2. all edges heavier than thr0, found with the cheap proximity+angle bound in front of the full weight;
+  // 3. the few pairs between non-singleton segments still below thr0.  Falls back to the histogram rounds below
+  //    (from a clean state) if a list overflows.
+  bool fast_done = false;
+  if (m >= 2) {
+    const float thr0 = vm_cut_threshold(1.0f, P.cut, 1);
+    auto nd = [&](int a) -> const NodeRec& { return NODES_LDS ? lnode[a] : node[gid[a]]; };
+    if (tid == 0) { s_sel = 0; s_nlist = 0; }
+    __syncthreads();
+    for (int x = 1 + tid; x < m; x += LC_TB) {
+      const NodeRec& A = nd(0);
+      const NodeRec& B = nd(x);
+      const float ub = vm_weight_bound_da(A, B, P.W);
+      ++my_pairs;
+      if (!(ub <= thr0)) { const float w = vm_pair_weight(A, B, P.W); if (w > thr0) s_sel = 1; }
+    }
+    __syncthreads();
+    if (s_sel == 0) {
+      fast_done = true;  // the voxel stays alone
+    } else {
+      {
+        int a = 0, qq = tid;
+        while (true) {
+          while (a < m - 1 && qq >= m - 1 - a) { qq -= (m - 1 - a); ++a; }
+          if (a >= m - 1) break;
+          const int b = a + 1 + qq;
+          const NodeRec& A = nd(a);
+          const NodeRec& B = nd(b);
+          const float ub = vm_weight_bound_da(A, B, P.W);
+          ++my_pairs;
+          if (!(ub <= thr0)) {
+            const float w = vm_pair_weight(A, B, P.W);
+            if (w > thr0) {
+              const int pos = atomicAdd(&s_nlist, 1);
+              if (pos < CAP) list[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
+            }
+          }
+          qq += LC_TB;
+        }
+      }
+      __syncthreads();
+      const int nlA = s_nlist;
+      __syncthreads();
+      if (nlA <= CAP) {
+        sort_desc(nlA);
+        merge_all(nlA);
+        // phase B: vertices of non-singleton segments that can still merge below thr0
+        const int s0 = seg[0];
+        int active = 0;
+        for (int c = tid; c < m; c += LC_TB) active += (ssize[c] >= 2 && thr[c] < thr0) ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o, 64);
+        if (lane == 0) s_act[wave] = active;
+        if (tid == 0) s_nlist = 0;
+        __syncthreads();
+        int tot = 0;
+        for (int x = 0; x < LC_TB / 64; ++x) tot += s_act[x];
+        const bool need_b = (tot >= 2) && (ssize[s0] >= 2) && (thr[s0] < thr0);
+        __syncthreads();
+        if (!need_b) {
+          fast_done = true;
+        } else {
+          int a = 0, qq = tid;
+          while (true) {
+            while (a < m - 1 && qq >= m - 1 - a) { qq -= (m - 1 - a); ++a; }
+            if (a >= m - 1) break;
+            const int b = a + 1 + qq;
+            const int sa = seg[a], sb = seg[b];
+            if (sa != sb && ssize[sa] >= 2 && ssize[sb] >= 2 && thr[sa] < thr0 && thr[sb] < thr0) {
+              const float w = vm_pair_weight(nd(a), nd(b), P.W);
+              ++my_pairs;
+              if (w <= thr0) {
+                const int pos = atomicAdd(&s_nlist, 1);
+                if (pos < CAP) list[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
+              }
+            }
+            qq += LC_TB;
+          }
+          __syncthreads();
+          const int nlB = s_nlist;
+          __syncthreads();
+          if (nlB <= CAP) {
+            sort_desc(nlB);
+            merge_all(nlB);
+            fast_done = true;
+          }
+        }
+      }
+      if (!fast_done) {  // a list overflowed: start again from a clean state with the general rounds
+        for (int c = tid; c < m; c += LC_TB) { seg[c] = (uint16_t)c; ssize[c] = 1; thr[c] = thr0; }
+        if (tid == 0) atomicAdd(&counters[7], 1ull);
+        __syncthreads();
+      }
+    }
+  }
+
+  for (int round = 0; m >= 2 && !fast_done; ++round) {
     const int rdone = s_rdone;  // edges with rank >= rdone have been examined
     const bool single = (round == 0 && Ptot <= (long long)CAP);
     int take_from = 0;          // this round examines ranks [take_from, rdone)
@@ -216,66 +380,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
     });
     __syncthreads();
     const int nl = s_nlist < CAP ? s_nlist : CAP;
-    // ---- bitonic sort, descending: weight first, then ascending (a, b) ----
-    int np = 64;
-    while (np < nl) np <<= 1;
-    for (int k = nl + tid; k < np; k += LC_TB) list[k] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= np; size <<= 1) {
-      for (int strd = size >> 1; strd > 0; strd >>= 1) {
-        for (int t = tid; t < (np >> 1); t += LC_TB) {
-          const int lo = ((t / strd) * (strd << 1)) + (t & (strd - 1));
-          const int hi = lo + strd;
-          const bool dn = ((lo & size) == 0);
-          const uint64_t x = list[lo], y = list[hi];
-          if ((x < y) == dn) { list[lo] = y; list[hi] = x; }
-        }
-        __syncthreads();
-      }
-    }
-    // ---- sequential merge on one wavefront, 64 sorted edges per step ----
-    if (wave == 0) {
-      int pos = 0;
-      while (pos < nl) {
-        const int e = pos + lane;
-        bool pass = false;
-        float w = 0.f;
-        int sa = 0, sb = 0;
-        if (e < nl) {
-          const uint64_t key = list[e];
-          w = vm_from_bits((uint32_t)(key >> 32));
-          const uint32_t tb = 0xffffffffu - (uint32_t)key;
-          sa = seg[tb >> 16];
-          sb = seg[tb & 0xffffu];
-          pass = (sa != sb) && (w > thr[sa]) && (w > thr[sb]);
-        }
-        const unsigned long long mk = __ballot(pass);
-        if (mk == 0ull) { pos += 64; continue; }  // nothing in these 64 edges can merge in the current state
-        const int f = __ffsll((long long)mk) - 1;  // first mergeable edge in order: it merges (state unchanged before it)
-        const float wf = __shfl(w, f, 64);
-        const int s1 = __shfl(sa, f, 64), s2 = __shfl(sb, f, 64);
-        const float t1 = thr[s1], t2 = thr[s2];
-        const int keep = (t1 >= t2) ? s1 : s2;   // VS:1972-1983: the segment with the larger threshold survives
-        const int gone = (t1 >= t2) ? s2 : s1;
-        const int nsz = (int)ssize[keep] + (int)ssize[gone];
-        wave_sync();
-        if (lane == 0) {
-          ssize[keep] = (uint16_t)nsz;
-          ssize[gone] = 0;
-          thr[keep] = vm_cut_threshold(wf, P.cut, nsz);  // seg_int = w (VS:1988)
-        }
-        for (int c = lane; c < m; c += 64)
-          if (seg[c] == gone) seg[c] = (uint16_t)keep;
-        wave_sync();
-        pos += f + 1;
-        // stop when fewer than two segments can still merge at the next (and every later) weight
-        const float wn = (pos < nl) ? vm_from_bits((uint32_t)(list[pos] >> 32)) : 0.f;
-        int active = 0;
-        for (int c = lane; c < m; c += 64) active += (ssize[c] != 0 && thr[c] < wn) ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o, 64);
-        if (active < 2) break;
-      }
-    }
+    sort_desc(nl);
+    merge_all(nl);
     __syncthreads();
     if (single || take_from <= 0) break;
     // every unexamined edge has rank < take_from, i.e. weight below wub: go on only if two segments can merge there
@@ -366,7 +472,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_LCAP = 512;
-  constexpr int SMALL_M = 160, SMALL_CAP = 4096;
+  constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
                      0, WAVE_A, WAVE_B, ids_a, ids_b, ids_c, d_nabc);
@@ -386,10 +492,16 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
   WP.grow = 2.25f;
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
-  auto launch_block = [&](const uint32_t* ids, unsigned int nw) -> vgs_status {
+  auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
     // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond
     if (nw == 0) return VGS_OK;
-    {
+    if (mid) {
+      auto kern = k_localcut<SMALL_M, SMALL_CAP, true>;
+      const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, true>();
+      VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+                         c->node.p, LP, c->conn.p, cnt, c->csize.p);
+    } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
@@ -398,7 +510,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     }
     return VGS_OK;
   };
-  (void)SMALL_M; (void)SMALL_CAP;
+  static_assert(WAVE_B <= SMALL_M, "wave-kernel hand-overs must fit the mid-size workgroup kernel");
   uint32_t* dbg_buf = nullptr;
 #ifdef VGS_PROF
   static DevBuf<uint32_t> s_dbg;
@@ -417,7 +529,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (nabc[1] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_b, (int)nabc[1],
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
-    vgs_status st = launch_block(ids_c, nabc[2]);
+    vgs_status st = launch_block(ids_c, nabc[2], false);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
@@ -430,7 +542,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (nf > 0) {
-    vgs_status st = launch_block(ids_f, nf);
+    vgs_status st = launch_block(ids_f, nf, true);  // handed over by the wave kernels: m <= WAVE_B <= SMALL_M
     if (st != VGS_OK) return st;
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
