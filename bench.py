@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
-def cpu_baseline(v, xyz_full, params, target_points=40_000):
+def cpu_baseline(v, xyz_full, params, target_points=150_000):
     """The oracle in the reference's own arithmetic and data flow (RefMath, faithful: by-value vectors,
     n x n matrix, std::sort of n^2 weights), one thread, on a bounded spatial crop of the same scene."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
