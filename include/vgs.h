@@ -108,6 +108,8 @@ vgs_status vgs_run(vgs_ctx* ctx);        /* all stages for ctx's method (segment
 vgs_status svgs_set_supervoxel_labels(vgs_ctx* ctx, const int32_t* labels_host, int32_t max_label);
 vgs_status svgs_supervoxels(vgs_ctx* ctx);  /* createSupervoxels: VCCS-style clustering on the GPU (SS:245-331) */
 vgs_status svgs_segment(vgs_ctx* ctx);      /* attributes + neighbours + local cuts + merge (SS:362-421) */
+/* getLabeledCloud / getMaxLabel (SS:283-284): one label per point (0 = unassigned) */
+vgs_status svgs_get_supervoxel_labels(vgs_ctx* ctx, int32_t* labels, int32_t* max_label);
 
 /* ---- results ---------------------------------------------------------------------------- */
 vgs_status vgs_get_counts(vgs_ctx* ctx, int64_t* counts /* VGS_N_COUNTS */);

@@ -43,8 +43,9 @@ def svgs_params(**kw):
 
 def build(force=False):
     so = os.path.join(_HERE, "librefcpu.so")
-    srcs = [os.path.join(_HERE, f) for f in ("refcpu.cpp", "refcpu_capi.cpp", "refcpu.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("refcpu.cpp", "refcpu_vccs.cpp", "refcpu_capi.cpp", "refcpu.hpp")]
     srcs.append(os.path.join(_HERE, "..", "vgs-svgs-segmentation_amd", "csrc", "vgs_math.h"))
+    srcs.append(os.path.join(_HERE, "..", "vgs-svgs-segmentation_amd", "csrc", "vccs_common.h"))
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -61,6 +62,8 @@ def lib():
         L.ref_svgs_run_from_labels.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.POINTER(RefParams)]
         L.ref_voxelize.restype = C.c_void_p
         L.ref_voxelize.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
+        L.ref_vccs.restype = C.c_int
+        L.ref_vccs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_free.argtypes = [C.c_void_p]
         L.ref_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_vgs_bbox.argtypes = [C.c_void_p, C.c_void_p]
@@ -171,6 +174,14 @@ def run_svgs_from_labels(xyz, labels, max_label, params):
     labels = np.ascontiguousarray(labels, dtype=np.int32)
     h = lib().ref_svgs_run_from_labels(_p(xyz), xyz.shape[0], xyz.shape[1], _p(labels), int(max_label), C.byref(params))
     return Result(h, xyz.shape[0], 1)
+
+
+def vccs(xyz, params):
+    """VCCS-style supervoxel labels (0 = unassigned) and max_label, restating csrc/vccs.hip on the CPU."""
+    xyz = _xyz(xyz)
+    lab = np.zeros(xyz.shape[0], dtype=np.int32)
+    mx = lib().ref_vccs(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
+    return lab, int(mx)
 
 
 def voxelize(xyz, voxel_size):

@@ -1,0 +1,137 @@
+// oracle/refcpu_vccs.cpp -- TEST INFRASTRUCTURE: CPU restatement of the VCCS-STYLE supervoxel stage of the product
+// (csrc/vccs.hip, arithmetic in csrc/vccs_common.h).  PARITY UNPINNED with respect to pcl::SupervoxelClustering
+// (reference supervoxel_segmentation.h:265-284): PCL is not available, its owner iteration is sequential and order
+// dependent; this file restates the synchronous variant documented in vccs.hip so that the GPU stage can be checked
+// label for label, and tests/test_gpu_vccs.py checks the published algorithm's invariants on top.
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "refcpu.hpp"
+#include "vccs_common.h"
+
+namespace refcpu {
+
+void vccs_supervoxels(const float* xyz, int64_t n, int stride, const Params& P, std::vector<int>& label, int& max_label) {
+  VoxelTable T;
+  build_voxel_table(xyz, n, stride, P.voxel_size, T);
+  const int V = T.V();
+  label.assign((size_t)n, 0);
+  max_label = 0;
+  if (V == 0) return;
+  // centroids: sequential float sums in ascending point index order
+  std::vector<float> cen((size_t)V * 3), nrm((size_t)V * 3);
+  for (int v = 0; v < V; ++v) {
+    float sx = 0, sy = 0, sz = 0;
+    for (int k = T.start[v]; k < T.start[v + 1]; ++k) {
+      const float* p = xyz + (int64_t)T.point_idx[k] * stride;
+      sx = sx + p[0]; sy = sy + p[1]; sz = sz + p[2];
+    }
+    const int cnt = T.start[v + 1] - T.start[v];
+    cen[3 * v] = sx / cnt; cen[3 * v + 1] = sy / cnt; cen[3 * v + 2] = sz / cnt;
+  }
+  // 26-neighbour table
+  std::unordered_map<uint64_t, int> by_code;
+  by_code.reserve((size_t)V * 2);
+  for (int v = 0; v < V; ++v) by_code[vm_morton(T.key[3 * v], T.key[3 * v + 1], T.key[3 * v + 2])] = v;
+  const uint32_t lim = 1u << T.depth;
+  std::vector<int> nbr((size_t)V * 26, -1);
+  for (int v = 0; v < V; ++v) {
+    float pts[27 * 3];
+    int np = 1;
+    pts[0] = cen[3 * v]; pts[1] = cen[3 * v + 1]; pts[2] = cen[3 * v + 2];
+    for (int o = 0; o < 26; ++o) {
+      int dx, dy, dz;
+      vccs_offset(o, &dx, &dy, &dz);
+      const uint32_t nx = T.key[3 * v] + (uint32_t)dx, ny = T.key[3 * v + 1] + (uint32_t)dy, nz = T.key[3 * v + 2] + (uint32_t)dz;
+      int t = -1;
+      if (nx < lim && ny < lim && nz < lim) {
+        auto it = by_code.find(vm_morton(nx, ny, nz));
+        if (it != by_code.end()) t = it->second;
+      }
+      nbr[(size_t)26 * v + o] = t;
+      if (t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
+    }
+    vccs_normal_from_points(pts, np, &nrm[3 * v]);
+  }
+  // seeds
+  const float seed = P.seed_size;
+  const float mn[3] = {(float)T.min[0], (float)T.min[1], (float)T.min[2]};
+  std::vector<uint64_t> cell((size_t)V);
+  for (int v = 0; v < V; ++v) cell[v] = vccs_seed_cell(cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], mn[0], mn[1], mn[2], seed);
+  std::vector<uint64_t> uniq(cell);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  const int K = (int)uniq.size();
+  std::vector<uint64_t> seed_key((size_t)K, ~0ull);
+  for (int v = 0; v < V; ++v) {
+    const int k = (int)(std::lower_bound(uniq.begin(), uniq.end(), cell[v]) - uniq.begin());
+    const float d2 = vccs_cell_center_d2(cell[v], cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], mn[0], mn[1], mn[2], seed);
+    const uint64_t key = ((uint64_t)vm_bits(d2) << 32) | (uint64_t)(uint32_t)v;
+    if (key < seed_key[k]) seed_key[k] = key;
+  }
+  // expansion passes
+  const int Tn = (int)(1.8f * P.seed_size / P.voxel_size);
+  const float w_s_over_seed = P.spatial_impt / P.seed_size;
+  const float w_n = P.normal_impt;
+  std::vector<float> sc((size_t)K * 3, 0.f), sn((size_t)K * 3, 0.f);
+  std::vector<int> lab((size_t)V, -1), lab2((size_t)V, -1);
+  std::vector<float> dist((size_t)V, 3.0e38f), dist2((size_t)V, 3.0e38f);
+  std::vector<long long> sums((size_t)K * 6);
+  std::vector<unsigned> count((size_t)K);
+  for (int pass = 0; pass < 6; ++pass) {
+    if (pass > 0) {
+      std::fill(seed_key.begin(), seed_key.end(), ~0ull);
+      for (int v = 0; v < V; ++v) {
+        const int l = lab[v];
+        if (l < 0) continue;
+        const float dx = cen[3 * v] - sc[3 * l], dy = cen[3 * v + 1] - sc[3 * l + 1], dz = cen[3 * v + 2] - sc[3 * l + 2];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const uint64_t key = ((uint64_t)vm_bits(d2) << 32) | (uint64_t)(uint32_t)v;
+        if (key < seed_key[l]) seed_key[l] = key;
+      }
+    }
+    std::fill(lab.begin(), lab.end(), -1);
+    std::fill(dist.begin(), dist.end(), 3.0e38f);
+    for (int k = 0; k < K; ++k) {
+      if (seed_key[k] == ~0ull) { for (int a = 0; a < 3; ++a) { sc[3 * k + a] = 0.f; sn[3 * k + a] = 0.f; } continue; }
+      const uint32_t v = (uint32_t)seed_key[k];
+      lab[v] = k; dist[v] = 0.0f;
+      for (int a = 0; a < 3; ++a) { sc[3 * k + a] = cen[3 * v + a]; sn[3 * k + a] = nrm[3 * v + a]; }
+    }
+    for (int it = 0; it < Tn; ++it) {
+      for (int v = 0; v < V; ++v) {
+        int best_l = lab[v];
+        float best_d = dist[v];
+        for (int o = 0; o < 26; ++o) {
+          const int t = nbr[(size_t)26 * v + o];
+          if (t < 0) continue;
+          const int l = lab[t];
+          if (l < 0 || l == lab[v]) continue;
+          const float d = vccs_distance(&cen[3 * v], &nrm[3 * v], &sc[3 * l], &sn[3 * l], w_s_over_seed, w_n);
+          if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
+        }
+        lab2[v] = best_l; dist2[v] = best_d;
+      }
+      lab.swap(lab2); dist.swap(dist2);
+      std::fill(sums.begin(), sums.end(), 0);
+      std::fill(count.begin(), count.end(), 0u);
+      for (int v = 0; v < V; ++v) {
+        const int l = lab[v];
+        if (l < 0) continue;
+        for (int a = 0; a < 3; ++a) { sums[(size_t)6 * l + a] += vccs_fix_pos(cen[3 * v + a]); sums[(size_t)6 * l + 3 + a] += vccs_fix_nrm(nrm[3 * v + a]); }
+        count[l]++;
+      }
+      for (int k = 0; k < K; ++k)
+        if (count[k]) vccs_state_from_sums(&sums[(size_t)6 * k], count[k], &sc[3 * k], &sn[3 * k]);
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const int v = T.point_voxel[(size_t)i];
+    label[(size_t)i] = (v < 0 || lab[v] < 0) ? 0 : lab[v] + 1;
+  }
+  max_label = K;
+}
+
+}  // namespace refcpu

@@ -1,0 +1,82 @@
+"""svgs_supervoxels (csrc/vccs.hip): the VCCS-style supervoxel stage that stands in for pcl::SupervoxelClustering
+(supervoxel_segmentation.h:265-284; PCL is unavailable -> parity with PCL is unpinned).  Checked (a) label for label
+against the oracle's CPU restatement of the same algorithm, (b) through invariants of the published algorithm
+(SURVEY.md B.4), (c) end to end: vgs_run on an SVGS context equals the oracle pipeline fed with those labels."""
+import numpy as np
+import pytest
+from scipy.sparse import coo_matrix
+from scipy.sparse.csgraph import connected_components
+
+from helpers import oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def run(gpu, oracle):
+    xyz = gpu.scenes.urban_scene(250_000)
+    p = gpu.default_params(3)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()                      # svgs_supervoxels + svgs_segment (segmentationSVGS, test:138-160)
+    labels, max_label = eng.supervoxel_labels()
+    return dict(eng=eng, xyz=xyz, labels=labels, max_label=max_label, p=p)
+
+
+def test_labels_match_oracle_restatement(run, oracle):
+    ref_labels, ref_max = oracle.vccs(run["xyz"], oracle_params(oracle, run["p"]))
+    assert run["max_label"] == ref_max
+    np.testing.assert_array_equal(run["labels"], ref_labels)
+
+
+def test_vccs_invariants(run, oracle):
+    xyz, labels, p = run["xyz"], run["labels"], run["p"]
+    assert labels.min() >= 0 and labels.max() <= run["max_label"]
+    assert (labels == 0).mean() < 0.01                       # nearly every point is reached by some supervoxel
+    t = oracle.voxelize(xyz, p.voxel_size).voxel_table()     # the VCCS voxels (same binning as the engine)
+    pv = t["point_voxel"]
+    V = t["key"].shape[0]
+    vlab = np.zeros(V, dtype=np.int64)
+    vlab[pv] = labels                                        # all points of a voxel share its label
+    assert (vlab[pv] == labels).all()
+    # number of supervoxels ~ occupied seed cells (one seed per occupied seed_res cell)
+    cells = np.unique(np.floor((xyz - xyz.min(0)) / p.seed_size).astype(np.int64), axis=0).shape[0]
+    assert 0.5 * cells <= run["max_label"] <= 1.5 * cells
+    # each supervoxel is 26-connected and compact
+    key = t["key"].astype(np.int64)
+    code = {tuple(k): i for i, k in enumerate(key.tolist())}
+    src, dst = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if (dx, dy, dz) <= (0, 0, 0):
+                    continue
+                nb = key + np.array([dx, dy, dz])
+                for i, k in enumerate(map(tuple, nb.tolist())):
+                    j = code.get(k)
+                    if j is not None and vlab[i] == vlab[j] and vlab[i] > 0:
+                        src.append(i); dst.append(j)
+    g = coo_matrix((np.ones(len(src), np.int8), (src, dst)), shape=(V, V))
+    _, comp = connected_components(g, directed=False)
+    lab_v, comp_v = vlab[vlab > 0], comp[vlab > 0]
+    pairs, cnt = np.unique(np.stack([lab_v, comp_v], 1), axis=0, return_counts=True)
+    tot = np.bincount(lab_v)
+    big = np.zeros_like(tot)
+    np.maximum.at(big, pairs[:, 0], cnt)
+    # stealing (as in PCL's expand) can cut voxels off in sparse clutter, where voxels hold ~1 point and normals are
+    # noise; on surfaces supervoxels are connected.  Bars calibrated on this scene: 0.92 overall, 0.996 / 0.96 on the ground
+    assert big.sum() / tot.sum() >= 0.85
+    ground = np.unique(vlab[(t["center"][:, 2] < 0.06) & (vlab > 0)])
+    assert big[ground].sum() / tot[ground].sum() >= 0.98
+    assert (big[ground] == tot[ground]).mean() >= 0.90
+    lab_ids = np.unique(lab_v)
+    ext = np.array([np.ptp(t["center"][vlab == l], axis=0).max() for l in lab_ids[:400]])
+    assert np.percentile(ext, 95) <= 2.5 * p.seed_size
+
+
+def test_end_to_end_matches_oracle_pipeline(run, oracle):
+    ref = oracle.run_svgs_from_labels(run["xyz"], run["labels"], run["max_label"], oracle_params(oracle, run["p"]))
+    pl, _ = ref.labels()
+    np.testing.assert_array_equal(run["eng"].point_labels(), pl)
+    c = run["eng"].counts()
+    assert c["clusters"] == ref.clusters_num

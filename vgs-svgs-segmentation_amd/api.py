@@ -174,6 +174,13 @@ class Engine:
         self._ck(self._L.vgs_get_point_labels(self._h, _ptr(out)))
         return out
 
+    def supervoxel_labels(self):
+        """Per-point supervoxel labels of the last svgs_supervoxels / set_supervoxel_labels (0 = unassigned) and max_label."""
+        out = np.zeros(self.n, dtype=np.int32)
+        mx = C.c_int32(0)
+        self._ck(self._L.svgs_get_supervoxel_labels(self._h, _ptr(out), C.byref(mx)))
+        return out, int(mx.value)
+
     def point_labels_device_ptr(self):
         p = C.c_void_p()
         self._ck(self._L.vgs_get_point_labels_device(self._h, C.byref(p)))

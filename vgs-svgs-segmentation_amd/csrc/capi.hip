@@ -133,6 +133,8 @@ void vgs_destroy(vgs_ctx* c) {
   c->node.release(); c->used_ids.release(); c->used_rank.release();
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_key.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->conn.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
+  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_label.release();
+  c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
@@ -270,8 +272,21 @@ vgs_status svgs_set_supervoxel_labels(vgs_ctx* c, const int32_t* labels_host, in
 
 vgs_status svgs_supervoxels(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
-  c->err = "svgs_supervoxels: the VCCS-style clustering kernel is not built yet; supply labels with svgs_set_supervoxel_labels";
-  return VGS_E_UNSUPPORTED;
+  if (c->P.method != 3) { c->err = "svgs_supervoxels: context was created for method 2 (VGS)"; return VGS_E_STATE; }
+  if (c->stage < ST_POINTS) { c->err = "svgs_supervoxels: set the input cloud first"; return VGS_E_STATE; }
+  if (!(c->P.seed_size > c->P.voxel_size)) { c->err = "svgs_supervoxels: seed_size must exceed voxel_size"; return VGS_E_ARG; }
+  vgs_status s = timed(c, VGS_T_SUPERVOXEL, [&] { return vgs_stage_vccs(c); });
+  if (s == VGS_OK) c->stage = ST_POINTS;
+  return s;
+}
+
+vgs_status svgs_get_supervoxel_labels(vgs_ctx* c, int32_t* labels, int32_t* max_label) {
+  if (!c || !labels || !max_label) return VGS_E_ARG;
+  if (!c->sv_have_labels) { c->err = "svgs_get_supervoxel_labels: no supervoxel labelling yet"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  if (c->N > 0) VGS_HIP_TRY(c, hipMemcpy(labels, c->sv_label.p, (size_t)c->N * 4, hipMemcpyDeviceToHost));
+  *max_label = c->sv_max_label;
+  return VGS_OK;
 }
 
 vgs_status svgs_segment(vgs_ctx* c) {

@@ -139,6 +139,12 @@ struct vgs_ctx {
   DevBuf<uint32_t> sv_key_a, sv_key_b;
   DevBuf<uint64_t> cell_code_a, cell_code_b;
   DevBuf<uint32_t> cell_id_a, cell_id_b, cell_start;
+  // VCCS-style supervoxel stage
+  DevBuf<float> vc_cen, vc_nrm, vc_dist, vc_state;
+  DevBuf<int32_t> vc_nbr, vc_label;
+  DevBuf<uint64_t> vc_seedkey;
+  DevBuf<long long> vc_sums;
+  DevBuf<uint32_t> vc_count;
 
   // multi-GPU
   bool have_region = false;
@@ -166,6 +172,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_localcut(vgs_ctx* c);
 vgs_status vgs_stage_merge(vgs_ctx* c);
+vgs_status vgs_stage_vccs(vgs_ctx* c);
 vgs_status vgs_stage_svgs_group(vgs_ctx* c);
 vgs_status vgs_stage_svgs_neighbours(vgs_ctx* c);
 vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs);
