@@ -18,41 +18,68 @@
 
 #include "vgs_context.hpp"
 
+// ---- brick table -------------------------------------------------------------------------------------------
+// Voxels are sorted by (descending) x-major Morton code, so the voxels of one 4x4x4 brick (code >> 6) are contiguous
+// in the voxel array.  One 32-byte entry per brick -- key, occupancy mask, used mask, id of the brick's first voxel --
+// answers "which voxel sits in lattice cell c, and is it used?" with one hash probe:
+//     id(c) = first + popcount(occupancy >> (local + 1))        (ids ascend while the local code descends)
+// About V/9 bricks: the table is a few MB and stays in the 4 MB L2 of each XCD, where the per-voxel hash (24 MB at
+// 10 M points) was served from the fabric, and the used flag no longer costs a 64-byte node read per neighbour.
+struct Brick { unsigned long long key; unsigned long long occ; unsigned long long used; uint32_t first; uint32_t pad; };
+
 __device__ __forceinline__ uint32_t hash_slot(uint64_t code, uint32_t hbits) {
   return (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> (64 - hbits));
 }
 
-__global__ void k_hash_insert(const uint64_t* __restrict__ vox_code, int64_t V, unsigned long long* __restrict__ hkey,
-                              uint32_t* __restrict__ hval, uint32_t hbits) {
+__global__ void k_brick_heads(const uint64_t* __restrict__ vox_code, int64_t V, uint32_t* __restrict__ head) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  const unsigned long long key = vox_code[v] + 1ull;  // 0 = empty
-  const uint32_t mask = (1u << hbits) - 1u;
-  uint32_t s = hash_slot(key, hbits);
-  while (true) {
-    unsigned long long prev = atomicCAS(&hkey[s], 0ull, key);
-    if (prev == 0ull) { hval[s] = (uint32_t)v; return; }
-    s = (s + 1) & mask;
-  }
+  head[v] = (v == 0 || (vox_code[v - 1] >> 6) != (vox_code[v] >> 6)) ? 1u : 0u;
 }
 
-__device__ __forceinline__ int hash_find(const uint64_t* __restrict__ hkey, const uint32_t* __restrict__ hval, uint32_t hbits,
-                                         uint64_t code) {
-  const uint64_t key = code + 1ull;
+// every voxel finds (or creates) its brick's slot and ORs its bits in; the brick's first voxel is the smallest id
+__global__ void k_brick_insert(const uint64_t* __restrict__ vox_code, const NodeRec* __restrict__ node, int64_t V,
+                               Brick* __restrict__ table, uint32_t hbits) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint64_t code = vox_code[v];
+  const unsigned long long key = (code >> 6) + 1ull;  // 0 = empty
+  const unsigned long long bit = 1ull << (code & 63ull);
   const uint32_t mask = (1u << hbits) - 1u;
   uint32_t s = hash_slot(key, hbits);
   while (true) {
-    uint64_t k = hkey[s];
-    if (k == key) return (int)hval[s];
+    const unsigned long long prev = atomicCAS(&table[s].key, 0ull, key);
+    if (prev == 0ull || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicOr(&table[s].occ, bit);
+  if (node[v].flags & VGS_F_EIG) atomicOr(&table[s].used, bit);
+  atomicMin(&table[s].first, (uint32_t)v);
+}
+
+// voxel id in lattice cell (nx, ny, nz), -1 if empty; *is_used tells whether that voxel has > points_min points
+__device__ __forceinline__ int brick_find(const Brick* __restrict__ table, uint32_t hbits, uint64_t code, bool* is_used) {
+  const unsigned long long key = (code >> 6) + 1ull;
+  const uint32_t mask = (1u << hbits) - 1u;
+  uint32_t s = hash_slot(key, hbits);
+  while (true) {
+    const unsigned long long k = table[s].key;
+    if (k == key) break;
     if (k == 0ull) return -1;
     s = (s + 1) & mask;
   }
+  const unsigned long long occ = table[s].occ;
+  const int local = (int)(code & 63ull);
+  if (!((occ >> local) & 1ull)) return -1;
+  *is_used = ((table[s].used >> local) & 1ull) != 0;
+  const unsigned long long above = (local == 63) ? 0ull : (occ >> (local + 1));
+  return (int)(table[s].first + (uint32_t)__popcll(above));
 }
 
 // one wavefront (64-thread workgroup) per used voxel
 template <int CAP, bool FULL>
 __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids,
-                                                  int64_t U, const uint64_t* __restrict__ hkey, const uint32_t* __restrict__ hval,
+                                                  int64_t U, const Brick* __restrict__ bricks,
                                                   uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int depth,
                                                   float res_f, float min_x, float min_y, float min_z, float r2,
                                                   const NodeRec* __restrict__ node, int adj_stride,
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
       const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
       const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;  // wraps past 0 fail the range test
       if (nx < lim && ny < lim && nz < lim) {
-        const int t = hash_find(hkey, hval, hbits, vm_morton(nx, ny, nz));
+        const int t = brick_find(bricks, hbits, vm_morton(nx, ny, nz), &is_used);
         if (t >= 0) {
           const float tx = cx - vm_voxel_center(nx, res_f, min_x);
           const float ty = cy - vm_voxel_center(ny, res_f, min_y);
@@ -87,7 +114,6 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
           if (d2 < r2) {
             keep = true;
             key64 = ((uint64_t)vm_bits(d2) << 32) | (uint32_t)t;
-            is_used = (node[t].flags & VGS_F_EIG) != 0;
           }
         }
       }
@@ -136,14 +162,20 @@ bool vgs_unused_are_inert(const vgs_params& p) {
 
 static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   const int64_t V = c->V;
+  // brick table: the number of bricks is not known without a pass, V/4 slots would already be generous; size by V/2
   uint32_t hbits = 4;
-  while ((1ull << hbits) < (uint64_t)(2 * V)) ++hbits;
+  while ((1ull << hbits) < (uint64_t)(V / 2 + 16)) ++hbits;
   c->hbits = hbits;
   const size_t H = (size_t)1 << hbits;
-  VGS_HIP_TRY(c, c->hkey.ensure(H)); VGS_HIP_TRY(c, c->hval.ensure(H));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->hkey.p, 0, H * sizeof(uint64_t), c->stream));
-  hipLaunchKernelGGL(k_hash_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, V,
-                     (unsigned long long*)c->hkey.p, c->hval.p, hbits);
+  VGS_HIP_TRY(c, c->hkey.ensure(H * (sizeof(Brick) / 8)));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->hkey.p, 0, H * sizeof(Brick), c->stream));
+  {
+    // first = min over the brick's voxel ids: start from 0xffffffff
+    Brick* tab = (Brick*)c->hkey.p;
+    VGS_HIP_TRY(c, hipMemset2DAsync(&tab[0].first, sizeof(Brick), 0xff, sizeof(uint32_t), H, c->stream));
+  }
+  hipLaunchKernelGGL(k_brick_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, c->node.p, V,
+                     (Brick*)c->hkey.p, hbits);
   // ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps)
   const double r = (double)c->P.graph_size;
   const double res = (double)c->P.voxel_size;
@@ -175,7 +207,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
 #define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
   hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3((unsigned)U), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
-                     c->hkey.p, c->hval.p, c->hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
+                     (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall)
   if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }
   else if (c->n_off <= 8192) { if (full) LAUNCH_ADJ(8192, true); else LAUNCH_ADJ(8192, false); }

@@ -171,6 +171,32 @@ __global__ void k_iota(uint32_t* p, int64_t n) {
   if (v < n) p[v] = (uint32_t)v;
 }
 
+// first hook (ECL-CC style): every used voxel points at its smallest trusted neighbour with a smaller id.  Ids only
+// decrease along parent links, so this is a forest; it already joins most of every large segment without atomics.
+__global__ __launch_bounds__(64) void k_cc_init(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
+                                                const uint32_t* __restrict__ adj_cnt, int adj_stride, const uint8_t* __restrict__ mutual,
+                                                const int32_t* __restrict__ attach, const uint8_t* __restrict__ owned,
+                                                uint32_t* __restrict__ parent) {
+  const int64_t u = blockIdx.x;
+  if (u >= U) return;
+  const uint32_t i = used_ids[u];
+  const int n = (int)adj_cnt[u];
+  const uint64_t* row = adj_key + u * adj_stride;
+  const uint8_t* mrow = mutual + u * adj_stride;
+  uint32_t best = i;
+  for (int k = threadIdx.x; k < n; k += 64) {
+    if (!mrow[k]) continue;
+    const uint32_t t = (uint32_t)row[k];
+    if (t < best && (!owned || owned[i] || owned[t])) best = t;
+  }
+  if (threadIdx.x == 0) {
+    const int32_t t = attach[i];
+    if (t >= 0 && (uint32_t)t < best && (!owned || owned[i])) best = (uint32_t)t;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
+  if (threadIdx.x == 0) parent[i] = best;
+}
+
 __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
@@ -307,6 +333,9 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   // connected components
   if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
   hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+  if (U > 0)
+    hipLaunchKernelGGL(k_cc_init, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
+                       c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   if (U > 0)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
