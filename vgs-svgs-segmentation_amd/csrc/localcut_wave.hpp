@@ -221,12 +221,12 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     for (int base = 1; base < m; base += 64) {
       const int x = base + lane;
       if (x < m) {
+        // the cheap bound alone: "not provably isolated" just means the voxel takes the normal path below
         const float ub = vm_weight_bound_da(rec[0], rec[x], W);
-        if (!(ub <= thr0)) { const float w = vm_pair_weight(rec[0], rec[x], W); any = any || (w > thr0); }
+        any = any || !(ub <= thr0);
       }
     }
     isolated = (__ballot(any) == 0ull);
-    if (lane == 0) n_evals += (unsigned long long)(m - 1);
   }
   if (m >= 2 && !isolated) {
     // =========================== phase A: edges heavier than a singleton's threshold ===========================
@@ -293,19 +293,24 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       } else {
         // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
         // LDS reads of a trip are issued together
+        // pair p (row-major over ia < ib) is decoded arithmetically, counting from the END of the triangle:
+        // q = P-1-p lies in row r = floor((sqrt(8q+1)-1)/2) from the end (8q+1 < 2^24: exact in float at the row starts)
         const bool ident = (n_act == m);  // alist is still the identity
-        int ia = 0, qq = lane;
         for (int base = 0; base < Pact; base += 256) {
           int va[4], vb[4];
           bool ok[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            while (ia < n_act - 1 && qq >= n_act - 1 - ia) { qq -= (n_act - 1 - ia); ++ia; }
-            ok[k] = ia < n_act - 1;
-            const int ib = ia + 1 + qq;
-            va[k] = ok[k] ? (ident ? ia : (int)alist[ia]) : 0;
-            vb[k] = ok[k] ? (ident ? ib : (int)alist[ib]) : 0;   // va < vb: alist is ascending
-            qq += 64;
+            const int p = base + 64 * k + lane;
+            ok[k] = p < Pact;
+            const int q = ok[k] ? (Pact - 1 - p) : 0;
+            int r = (int)((vm_sqrt((float)(8 * q + 1)) - 1.0f) * 0.5f);
+            r += ((r + 1) * (r + 2) / 2 <= q) ? 1 : 0;   // guard against a sqrt rounded down just below a row start
+            r -= (r * (r + 1) / 2 > q) ? 1 : 0;
+            const int ia = n_act - 2 - r;
+            const int ib = n_act - 1 - (q - r * (r + 1) / 2);
+            va[k] = ident ? ia : (int)alist[ia];
+            vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
           }
           float4 pa[4], pb[4];
           bool diff[4];
