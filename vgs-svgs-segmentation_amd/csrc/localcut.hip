@@ -413,17 +413,17 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 // split the used voxels into three classes by the number of used neighbours (one atomic per wavefront and class)
 __global__ void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
-                           int max_a, int max_b, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
-                           uint32_t* __restrict__ ids_c, unsigned int* __restrict__ n_abc) {
+                           int max_a, int max_b, int max_c, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
+                           uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d, unsigned int* __restrict__ n_abc) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int cls = -1;
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
-    cls = m <= max_a ? 0 : (m <= max_b ? 1 : 2);
+    cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3));
   }
-  uint32_t* const outs[3] = {ids_a, ids_b, ids_c};
-  for (int k = 0; k < 3; ++k) {
+  uint32_t* const outs[4] = {ids_a, ids_b, ids_c, ids_d};
+  for (int k = 0; k < 4; ++k) {
     const unsigned long long mk = __ballot(cls == k);
     if (mk == 0ull) continue;
     unsigned int base = 0;
@@ -461,23 +461,26 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.prune_unused = 0;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure(4 * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure(6 * (size_t)U + 16));
   VGS_HIP_TRY(c, c->csize.ensure((size_t)(c->V > U ? c->V : U)));  // used here as per-voxel evaluation counters (index u)
   VGS_HIP_TRY(c, c->counters.ensure(64));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
-  uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, small LDS footprint
-  uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel
-  uint32_t* ids_c = c->work_ids.p + 2 * U;    // the rest: one workgroup per voxel (k_localcut)
-  uint32_t* ids_f = c->work_ids.p + 3 * U;    // voxels the wave kernels handed over
-  unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);
+  uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, records in LDS, small footprint
+  uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel, records in LDS
+  uint32_t* ids_c = c->work_ids.p + 2 * U;    // m <= WAVE_C: one wavefront per voxel, centroids in LDS, records through L2
+  uint32_t* ids_d = c->work_ids.p + 3 * U;    // the rest: one workgroup per voxel (k_localcut)
+  uint32_t* ids_f = c->work_ids.p + 4 * U;    // handed over by the A/B wave kernels (m <= WAVE_B)
+  uint32_t* ids_g = c->work_ids.p + 5 * U;    // handed over by the C wave kernel
+  unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 4 class counters (2 words)
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
-  constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_LCAP = 512;
+  unsigned int* d_ng = d_nf + 1;
+  constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512, WAVE_LCAP = 512;
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
-                     0, WAVE_A, WAVE_B, ids_a, ids_b, ids_c, d_nabc);
-  unsigned int nabc[3] = {0, 0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 12, hipMemcpyDeviceToHost, c->stream));
+                     0, WAVE_A, WAVE_B, WAVE_C, ids_a, ids_b, ids_c, ids_d, d_nabc);
+  unsigned int nabc[4] = {0, 0, 0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 16, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
   LwParams WP;
@@ -526,27 +529,35 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   {
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
+    if (nabc[2] > 0)
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, 2048, false>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_c, (int)nabc[2],
+                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
     if (nabc[1] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_b, (int)nabc[1],
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP, true>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_b, (int)nabc[1],
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
-    vgs_status st = launch_block(ids_c, nabc[2], false);
+    vgs_status st = launch_block(ids_d, nabc[3], false);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
   if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP, true>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
                        c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
-  unsigned int nf = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_nf, 4, hipMemcpyDeviceToHost, c->stream));
+  unsigned int nfg[2] = {0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(nfg, d_nf, 8, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (nf > 0) {
-    vgs_status st = launch_block(ids_f, nf, true);  // handed over by the wave kernels: m <= WAVE_B <= SMALL_M
+  const unsigned int nf = nfg[0] + nfg[1];
+  if (nfg[0] > 0) {
+    vgs_status st = launch_block(ids_f, nfg[0], true);   // m <= WAVE_B <= SMALL_M
+    if (st != VGS_OK) return st;
+  }
+  if (nfg[1] > 0) {
+    vgs_status st = launch_block(ids_g, nfg[1], false);
     if (st != VGS_OK) return st;
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->counts[13] = nabc[0]; c->counts[14] = nabc[1]; c->counts[15] = nabc[2];
+  c->counts[13] = nabc[0]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -49,14 +49,17 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 
-template <int MAXM, int LCAP>
+template <int MAXM, int LCAP, bool REC_LDS>
 __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict__ work, int n_work,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                       uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
                                                       uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out) {
-  __shared__ __attribute__((aligned(16))) NodeRec rec[MAXM];
+  // neighbour records: in LDS for the common sizes; for the largest class only the centroids live in LDS and the
+  // few hundred pairs that get a full evaluation read their records through L2
+  __shared__ __attribute__((aligned(16))) NodeRec rec_lds[REC_LDS ? MAXM : 1];
+  __shared__ uint32_t gid_lds[REC_LDS ? 1 : MAXM];
   __shared__ __attribute__((aligned(16))) uint64_t list[LCAP];
   __shared__ __attribute__((aligned(16))) float4 cpos[MAXM];  // centroid + position-valid flag (w != 0)
   __shared__ float thr[MAXM];
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
 #endif
 
   // ---- gather the used neighbours in adjacency order; their global ids go through the list area ----
-  uint32_t* gid = (uint32_t*)list;
+  uint32_t* gid = REC_LDS ? (uint32_t*)list : gid_lds;
+  auto R = [&](int v) -> const NodeRec& { return REC_LDS ? rec_lds[v] : node[gid[v]]; };
 #ifdef VGS_PROF
   if (n == 0x7fffffff) return;  // force the dependent loads to complete before the timestamp
   __builtin_amdgcn_s_waitcnt(0);
@@ -114,9 +118,9 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   LW_ACC(14);  // gather: row read + compaction
   wave_sync();
   LW_ACC(15);  // gather: first sync (waits for the row zeroing stores)
-  {
+  if (REC_LDS) {
     const float4* src = (const float4*)node;
-    float4* dst = (float4*)rec;
+    float4* dst = (float4*)rec_lds;
     for (int e = lane; e < m * 4; e += 64) dst[e] = src[(size_t)gid[e >> 2] * 4 + (e & 3)];
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   LW_ACC(7);  // gather: record loads
   for (int c = lane; c < m; c += 64) {
     seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (uint16_t)c;
-    cpos[c] = make_float4(rec[c].c[0], rec[c].c[1], rec[c].c[2], (rec[c].flags & VGS_F_POS) ? 1.0f : 0.0f);
+    const NodeRec& rc = R(c);
+    cpos[c] = make_float4(rc.c[0], rc.c[1], rc.c[2], (rc.flags & VGS_F_POS) ? 1.0f : 0.0f);
   }
   wave_sync();
 
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       const int x = base + lane;
       if (x < m) {
         // the cheap bound alone: "not provably isolated" just means the voxel takes the normal path below
-        const float ub = vm_weight_bound_da(rec[0], rec[x], W);
+        const float ub = vm_weight_bound_da(R(0), R(x), W);
         any = any || !(ub <= thr0);
       }
     }
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     while (true) {
       // a neighbourhood that keeps hundreds of edges waiting above thr0 makes slow progress here: after a few
       // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
-      if (++rounds > 6) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
+      if (++rounds > (MAXM > 128 ? 14 : 6)) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
       const bool use_minor = (big >= 0) && (2 * n_min < n_act);
@@ -356,8 +361,8 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         bool drop = false;
         if (e < n_list + count) {
           const uint32_t pid = (uint32_t)list[e];
-          const NodeRec& A = rec[pid >> 16];
-          const NodeRec& B = rec[pid & 0xffffu];
+          const NodeRec& A = R(pid >> 16);
+          const NodeRec& B = R(pid & 0xffffu);
           // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
           const float ub = vm_weight_bound_da(A, B, W);
           float w = 0.0f;
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
           if (ia < nb - 1) {
             const int a = alist[ia], b = alist[ia + 1 + qq];
             if (seg[a] != seg[b]) {
-              const float w = vm_pair_weight(rec[a], rec[b], W);
+              const float w = vm_pair_weight(R(a), R(b), W);
               ++n_evals;
               inr = (w <= thr0);  // heavier edges were examined in phase A; NaN compares false
               key = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
