@@ -541,7 +541,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
   if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP, true>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP, false>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
                        c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   unsigned int nfg[2] = {0, 0};

@@ -306,14 +306,15 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
           bool ok[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int p = base + 64 * k + lane;
-            ok[k] = p < Pact;
-            const int q = ok[k] ? (Pact - 1 - p) : 0;
-            int r = (int)((vm_sqrt((float)(8 * q + 1)) - 1.0f) * 0.5f);
-            r += ((r + 1) * (r + 2) / 2 <= q) ? 1 : 0;   // guard against a sqrt rounded down just below a row start
-            r -= (r * (r + 1) / 2 > q) ? 1 : 0;
-            const int ia = n_act - 2 - r;
-            const int ib = n_act - 1 - (q - r * (r + 1) / 2);
+            const uint32_t p = (uint32_t)(base + 64 * k + lane);
+            ok[k] = p < (uint32_t)Pact;
+            const uint32_t q = ok[k] ? ((uint32_t)Pact - 1u - p) : 0u;
+            // raw v_sqrt_f32 (1 ulp) is enough: the two compares below repair an off-by-one row
+            uint32_t r = (uint32_t)((__builtin_amdgcn_sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
+            r += (((r + 1u) * (r + 2u)) >> 1) <= q ? 1u : 0u;
+            r -= ((r * (r + 1u)) >> 1) > q ? 1u : 0u;
+            const int ia = n_act - 2 - (int)r;
+            const int ib = n_act - 1 - (int)(q - ((r * (r + 1u)) >> 1));
             va[k] = ident ? ia : (int)alist[ia];
             vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
           }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_cc_pass(const uint32_t* __restrict__ can
       const int ot = __shfl_xor(best_t, o, 64);
       if (ow > best_w || (ow == best_w && oj > best_j)) { best_w = ow; best_j = oj; best_t = ot; }
     }
-    if (lane == 0) attach[i] = best_t;
+    if (lane == 0) { attach[i] = best_t; if (best_t >= 0) atomicAdd(changed, 1u); }  // `changed` counts re-attachments in this pass
   }
 }
 
@@ -324,6 +324,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
         VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!ch) break;
       }
+      VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
       hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
                          c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
     }
@@ -361,7 +362,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipMemcpyAsync(&last_rank, c->kept_rank.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipMemcpyAsync(&last_flag, keep_flag + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  (void)n_succ;
+  if (U > 0 && n_cand > 0) VGS_HIP_TRY(c, hipMemcpy(&n_succ, (unsigned int*)(c->counters.p + 1), 4, hipMemcpyDeviceToHost));
+  c->counts[VGS_N_REATTACHED] = n_succ;
   c->counts[VGS_N_CLUSTERS] = n_roots;
   c->counts[VGS_N_KEPT] = (int64_t)last_rank + last_flag;
   c->counts[VGS_N_ISOLATED] = n_cand;

@@ -137,21 +137,29 @@ __global__ void k_vccs_reset(int64_t V, int32_t* __restrict__ label, float* __re
 }
 
 __global__ void k_vccs_plant(const unsigned long long* __restrict__ seed_key, int K, const float* __restrict__ cen, const float* __restrict__ nrm,
-                             int32_t* __restrict__ label, float* __restrict__ dist, VccsState* __restrict__ st) {
+                             int32_t* __restrict__ label, float* __restrict__ dist, VccsState* __restrict__ st,
+                             long long* __restrict__ sums, unsigned int* __restrict__ count) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   const unsigned long long key = seed_key[k];
+  for (int a = 0; a < 6; ++a) sums[6 * k + a] = 0;
+  count[k] = 0;
   if (key == ~0ull) { for (int a = 0; a < 3; ++a) { st[k].c[a] = 0.f; st[k].n[a] = 0.f; } return; }  // supervoxel without voxels
   const uint32_t v = (uint32_t)key;
   label[v] = k;
   dist[v] = 0.0f;
-  for (int a = 0; a < 3; ++a) { st[k].c[a] = cen[3 * v + a]; st[k].n[a] = nrm[3 * v + a]; }
+  for (int a = 0; a < 3; ++a) {
+    st[k].c[a] = cen[3 * v + a]; st[k].n[a] = nrm[3 * v + a];
+    sums[6 * k + a] = vccs_fix_pos(cen[3 * v + a]); sums[6 * k + 3 + a] = vccs_fix_nrm(nrm[3 * v + a]);
+  }
+  count[k] = 1;
 }
 
 // one synchronous round: every voxel looks at the labels its 26 neighbours (and itself) had at the start of the round
 __global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, const float* __restrict__ nrm,
                               const int32_t* __restrict__ label_in, const float* __restrict__ dist_in, const VccsState* __restrict__ st,
-                              float w_s_over_seed, float w_n, int32_t* __restrict__ label_out, float* __restrict__ dist_out) {
+                              float w_s_over_seed, float w_n, int32_t* __restrict__ label_out, float* __restrict__ dist_out,
+                              long long* __restrict__ sums, unsigned int* __restrict__ count) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   int best_l = label_in[v];
@@ -168,6 +176,22 @@ __global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const 
   }
   label_out[v] = best_l;
   dist_out[v] = best_d;
+  // the per-supervoxel sums are integers: moving this voxel's contribution from its old owner to the new one gives
+  // exactly the sums a full re-accumulation would (and after the first rounds only the frontier moves)
+  const int old_l = label_in[v];
+  if (best_l != old_l) {
+    for (int a = 0; a < 3; ++a) {
+      const long long fp = vccs_fix_pos(c[a]), fn = vccs_fix_nrm(n[a]);
+      if (old_l >= 0) {
+        atomicAdd((unsigned long long*)&sums[6 * old_l + a], (unsigned long long)(-fp));
+        atomicAdd((unsigned long long*)&sums[6 * old_l + 3 + a], (unsigned long long)(-fn));
+      }
+      atomicAdd((unsigned long long*)&sums[6 * best_l + a], (unsigned long long)fp);
+      atomicAdd((unsigned long long*)&sums[6 * best_l + 3 + a], (unsigned long long)fn);
+    }
+    if (old_l >= 0) atomicSub(&count[old_l], 1u);
+    atomicAdd(&count[best_l], 1u);
+  }
 }
 
 __global__ void k_vccs_accumulate(int64_t V, const int32_t* __restrict__ label, const float* __restrict__ cen, const float* __restrict__ nrm,
@@ -274,14 +298,11 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
       hipLaunchKernelGGL(k_vccs_reseed, dim3(nbV), dim3(TB), 0, c->stream, V, lab[cur], cen.p, state, seed_key);
     }
     hipLaunchKernelGGL(k_vccs_reset, dim3(nbV), dim3(TB), 0, c->stream, V, lab[cur], dst[cur]);
-    hipLaunchKernelGGL(k_vccs_plant, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, cen.p, nrm.p, lab[cur], dst[cur], state);
+    hipLaunchKernelGGL(k_vccs_plant, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, cen.p, nrm.p, lab[cur], dst[cur], state, c->vc_sums.p, c->vc_count.p);
     for (int it = 0; it < T; ++it) {
       hipLaunchKernelGGL(k_vccs_expand, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
-                         lab[cur ^ 1], dst[cur ^ 1]);
+                         lab[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
       cur ^= 1;
-      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * 8, c->stream));
-      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
-      hipLaunchKernelGGL(k_vccs_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, lab[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
       hipLaunchKernelGGL(k_vccs_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state);
     }
   }
