@@ -110,13 +110,17 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
   if (!c) return VGS_E_NOMEM;
   c->P = *p;
   c->device = p->device;
+  // the side streams carry few, long-running workgroups that must not queue behind the bulk class: highest priority
+  int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
+      hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     g_create_err = "vgs_create: hipSetDevice/hipStreamCreate failed";
     delete c;
     return VGS_E_HIP;
   }
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 10; ++i)
     if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
   *out = c;
   return VGS_OK;
@@ -139,9 +143,10 @@ void vgs_destroy(vgs_ctx* c) {
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
-  for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   delete c;
 }
 

@@ -482,6 +482,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int nabc[4] = {0, 0, 0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 16, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef VGS_PROF
+  if (const char* oc = getenv("VGS_ONLY_CLASS")) {  // diagnostics: run a single class (results are incomplete)
+    for (int k = 0; k < 4; ++k) if (k != atoi(oc)) nabc[k] = 0;
+  }
+#endif
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
   LwParams WP;
   WP.lc = LP;
@@ -495,6 +500,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
   WP.grow = 2.25f;
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
+  WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
   auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
     // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond
     if (nw == 0) return VGS_OK;
@@ -523,26 +529,30 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 #endif
   VGS_HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
   VGS_HIP_TRY(c, hipMemsetAsync(c->conn.p, 0, (size_t)U * c->adj_stride, c->stream));  // connect flags start at 0
-  // the heavy classes (few, long-running wavefronts) go to a side stream so that they overlap the light class
+  // The heavy classes (few, long-running wavefronts with a large LDS footprint) run on two side streams and are
+  // launched BEFORE the bulk class: once the bulk class has filled every CU's LDS with its small workgroups a 35 KB
+  // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[2], 0));
+  // the bulk class waits on an event that crosses queues once more, so it starts a few microseconds after the others
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[9], c->stream3));
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[9], 0));
   {
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, 2048, false>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_c, (int)nabc[2],
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, 2048, false>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2],
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
-    if (nabc[1] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP, true>), dim3(((nabc[1] + 7) / 8) * 8), dim3(64), 0, c->stream2, ids_b, (int)nabc[1],
-                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
     vgs_status st = launch_block(ids_d, nabc[3], false);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
-  if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, WAVE_LCAP, false>), dim3(((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream, ids_a, (int)nabc[0], c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+  if (nabc[0] + nabc[1] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP, false>), dim3(((nabc[1] + 7) / 8) * 8 + ((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream,
+                       ids_b, (int)nabc[1], ids_a, (int)nabc[0], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
+                       ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   unsigned int nfg[2] = {0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nfg, d_nf, 8, hipMemcpyDeviceToHost, c->stream));

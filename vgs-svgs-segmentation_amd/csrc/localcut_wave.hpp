@@ -43,6 +43,7 @@ struct LwParams {
   float shell0;     // first shell = shell0 * r2_graph / m
   float grow;       // shell growth factor (in squared distance)
   int dbg_stop;     // diagnostics: leave the first round after step N (0 = run normally)
+  int max_rounds;   // shells a wavefront works through before it hands the voxel over (classes A/B)
 };
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
@@ -50,7 +51,8 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
 }
 
 template <int MAXM, int LCAP, bool REC_LDS>
-__global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict__ work, int n_work,
+__global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
+                                                      const uint32_t* __restrict__ work, int n_work,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
@@ -70,10 +72,16 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   const int lane = threadIdx.x;
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
   // Morton-ordered work list so that neighbouring voxels share their L2
-  const int per_xcd = (n_work + 7) >> 3;
-  const int widx = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-  if (widx >= n_work) return;
-  const uint32_t u = work[widx];
+  // An optional first list (the heavier voxels of the launch) is dealt out the same way before the main list, so
+  // that the long-running wavefronts start first and the light ones fill the tail.
+  const unsigned int nb_first = ((unsigned int)n_first + 7u) & ~7u;
+  const bool first = blockIdx.x < nb_first;
+  const unsigned int bidx = first ? blockIdx.x : blockIdx.x - nb_first;
+  const int n_mine = first ? n_first : n_work;
+  const int per_xcd = (n_mine + 7) >> 3;
+  const int widx = (int)(bidx & 7u) * per_xcd + (int)(bidx >> 3);
+  if (widx >= n_mine) return;
+  const uint32_t u = (first ? work_first : work)[widx];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + (int64_t)u * adj_stride;
   uint8_t* crow = conn + (int64_t)u * adj_stride;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     while (true) {
       // a neighbourhood that keeps hundreds of edges waiting above thr0 makes slow progress here: after a few
       // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
-      if (++rounds > (MAXM > 128 ? 14 : 6)) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
+      if (++rounds > (MAXM > 128 ? 14 : P.max_rounds)) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
       const bool use_minor = (big >= 0) && (2 * n_min < n_act);

@@ -219,9 +219,17 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
   }
 }
 
+// pointer jumping between the first hook and the union pass: every later find starts one hop from a root
+__global__ void k_compress(uint32_t* __restrict__ parent, int64_t V) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint32_t r = uf_find(parent, (uint32_t)v);
+  if (r != (uint32_t)v) __hip_atomic_store(&parent[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, const uint8_t* __restrict__ owned, uint32_t* __restrict__ csz) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;   // V is padded to the block size by the caller? no: tail lanes simply leave
+  if (v >= V) return;
   const uint32_t r = uf_find(parent, (uint32_t)v);
   parent[v] = r;   // only shortens paths: concurrent finds stay correct
   // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address)
@@ -337,6 +345,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0)
     hipLaunchKernelGGL(k_cc_init, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
+  if (U > 0) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
