@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   uint32_t* __restrict__ adj_mused) {
   __shared__ uint64_t lst[CAP];
   const int lane = threadIdx.x;
-  const int64_t u = blockIdx.x;
+  const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const uint32_t i = used_ids[u];
   const uint64_t code = vox_code[i];
@@ -206,7 +206,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   const float res_f = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
 #define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
-  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3((unsigned)U), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
+  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall)
   if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }

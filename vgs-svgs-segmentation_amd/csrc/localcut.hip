@@ -474,7 +474,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 4 class counters (2 words)
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
   unsigned int* d_ng = d_nf + 1;
-  constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512, WAVE_LCAP = 512;
+  constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
+  constexpr int LCAP_A = 448, LCAP_B = 320, LCAP_C = 2048;  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
@@ -542,17 +543,22 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, 2048, false>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2],
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2],
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
     vgs_status st = launch_block(ids_d, nabc[3], false);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
-  if (nabc[0] + nabc[1] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, WAVE_LCAP, false>), dim3(((nabc[1] + 7) / 8) * 8 + ((nabc[0] + 7) / 8) * 8), dim3(64), 0, c->stream,
-                       ids_b, (int)nabc[1], ids_a, (int)nabc[0], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
-                       ids_f, d_nf, c->csize.p, dbg_buf);
+  // classes A and B have the same LDS footprint, so their workgroups interleave freely; B (heavier) goes first
+  if (nabc[1] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
+                       ids_b, (int)nabc[1], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
+  if (nabc[0] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, (const uint32_t*)nullptr, 0,
+                       ids_a, (int)nabc[0], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   unsigned int nfg[2] = {0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nfg, d_nf, 8, hipMemcpyDeviceToHost, c->stream));

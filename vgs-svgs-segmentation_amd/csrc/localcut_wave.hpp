@@ -25,6 +25,8 @@
 #ifndef LOCALCUT_WAVE_HPP_
 #define LOCALCUT_WAVE_HPP_
 
+#include <type_traits>
+
 // VGS_PROF=1 builds accumulate per-phase shader cycles (s_memtime) into counters[16..31] (diagnostics only)
 #ifdef VGS_PROF
 #define LW_T0() long long _t0 = clock64()
@@ -34,6 +36,11 @@
 #define LW_T0() do {} while (0)
 #define LW_ACC(slot) do {} while (0)
 #define LW_CNT(slot, v) do {} while (0)
+#endif
+
+// wavefronts per SIMD the compiler must leave room for (register budget 512 / LW_WAVES)
+#ifndef LW_WAVES
+#define LW_WAVES 8
 #endif
 
 struct LwParams {
@@ -50,24 +57,33 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 
-template <int MAXM, int LCAP, bool REC_LDS>
-__global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
+// LDS diet.  The kernel is bound by dependent LDS/L2 latency, not by issue slots (measured: time ~ 2.9 ms + 99 ms /
+// (wavefronts per CU) on URB10M), so the footprint is cut to 5 KB per wavefront = the 32-wavefronts-per-CU cap:
+// centroids SoA without a flag word (an unusable position is a NaN x), one-byte vertex/segment indices up to 256
+// vertices, and the edge list as two arrays (weight bits, complemented pair id) instead of one 8-byte key.
+template <int MAXM, int LCAP>
+__global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
                                                       const uint32_t* __restrict__ work, int n_work,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                       uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
                                                       uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out) {
-  // neighbour records: in LDS for the common sizes; for the largest class only the centroids live in LDS and the
-  // few hundred pairs that get a full evaluation read their records through L2
-  __shared__ __attribute__((aligned(16))) NodeRec rec_lds[REC_LDS ? MAXM : 1];
-  __shared__ uint32_t gid_lds[REC_LDS ? 1 : MAXM];
-  __shared__ __attribute__((aligned(16))) uint64_t list[LCAP];
-  __shared__ __attribute__((aligned(16))) float4 cpos[MAXM];  // centroid + position-valid flag (w != 0)
+  constexpr bool SMALL = MAXM <= 255;  // indices and segment sizes fit a byte
+  typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;   // vertex / segment index, segment size
+  typedef typename std::conditional<SMALL, uint16_t, uint32_t>::type pid_t;  // pair id (a << PSH) | b with a < b
+  constexpr int PSH = SMALL ? 8 : 16;
+  constexpr uint32_t PMASK = (1u << PSH) - 1u;
+  constexpr uint32_t PCOMP = SMALL ? 0xffffu : 0xffffffffu;  // stored complemented: descending (w, ~pid) = w desc, pid asc
+  // edge list: lw = weight bits, lp = PCOMP - pid; a dropped entry is (0, 0), below every real edge (real lp >= 1)
+  __shared__ uint32_t lw[LCAP];
+  __shared__ float cx[MAXM], cy[MAXM], cz[MAXM];  // centroids; cx = NaN when the position is unusable (VS:1829)
   __shared__ float thr[MAXM];
-  __shared__ uint16_t seg[MAXM], rep[MAXM], ssz[MAXM], loc[MAXM];
-  __shared__ uint16_t alist[MAXM];  // vertices whose segment can still merge (ascending)
-  __shared__ uint16_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
+  __shared__ uint32_t gid[MAXM];                  // global voxel ids: the few pairs that get a full evaluation read their records through L2
+  __shared__ pid_t lp[LCAP];
+  __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
+  __shared__ idx_t alist[MAXM];  // vertices whose segment can still merge (ascending)
+  __shared__ idx_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
 
   const int lane = threadIdx.x;
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
@@ -96,48 +112,22 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   const long long t_start = clock64();
 #endif
 
-  // ---- gather the used neighbours in adjacency order; their global ids go through the list area ----
-  uint32_t* gid = REC_LDS ? (uint32_t*)list : gid_lds;
-  auto R = [&](int v) -> const NodeRec& { return REC_LDS ? rec_lds[v] : node[gid[v]]; };
-#ifdef VGS_PROF
-  if (n == 0x7fffffff) return;  // force the dependent loads to complete before the timestamp
-  __builtin_amdgcn_s_waitcnt(0);
-#endif
-  LW_ACC(10);  // work + adj_cnt loads
-  LW_ACC(6);   // (the connect flags were zeroed by one memset before the launch)
-  int m = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int k = base + lane;
-    bool keep = false;
-    uint32_t t = 0;
-    if (k < n) {
-      t = (uint32_t)row[k];
-      keep = P.lc.prune_unused ? ((node[t].flags & VGS_F_EIG) != 0) : true;
-    }
-    const unsigned long long mk = __ballot(keep);
-    const int pos = m + __popcll(mk & lt_mask);
-    if (keep && pos < MAXM) { gid[pos] = t; loc[pos] = (uint16_t)k; }
-    m += __popcll(mk);
-  }
+  // ---- the neighbourhood in adjacency order (the adjacency stage already dropped inert unused voxels) ----
+  auto R = [&](int v) -> const NodeRec& { return node[gid[v]]; };
+  const int m = n;
   if (m > MAXM) {  // classification guarantees this does not happen; hand over to the general kernel anyway
     if (lane == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
     return;
   }
-  LW_ACC(14);  // gather: row read + compaction
-  wave_sync();
-  LW_ACC(15);  // gather: first sync (waits for the row zeroing stores)
-  if (REC_LDS) {
-    const float4* src = (const float4*)node;
-    float4* dst = (float4*)rec_lds;
-    for (int e = lane; e < m * 4; e += 64) dst[e] = src[(size_t)gid[e >> 2] * 4 + (e & 3)];
-  }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
-  wave_sync();
-  LW_ACC(7);  // gather: record loads
   for (int c = lane; c < m; c += 64) {
-    seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (uint16_t)c;
-    const NodeRec& rc = R(c);
-    cpos[c] = make_float4(rc.c[0], rc.c[1], rc.c[2], (rc.flags & VGS_F_POS) ? 1.0f : 0.0f);
+    const uint32_t t = (uint32_t)row[c];
+    gid[c] = t;
+    seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c;
+    const NodeRec& rc = node[t];
+    cx[c] = (rc.flags & VGS_F_POS) ? rc.c[0] : vm_nan();
+    cy[c] = rc.c[1];
+    cz[c] = rc.c[2];
   }
   wave_sync();
 
@@ -147,28 +137,37 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   int merges = 0;
   bool bail = false;
 
-  // descending bitonic sort of list[0, cnt) (keys 0 = dropped edges fall off the end)
+  // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
+  // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
+  // real one that never move, so cnt need not be a power of two and nothing is padded.
   auto sort_list = [&](int cnt) {
     int np = 64;
     while (np < cnt) np <<= 1;
-    for (int k = cnt + lane; k < np; k += 64) list[k] = 0ull;
+    auto cmpx = [&](int lo, int hi) {
+      if (hi >= cnt) return;
+      const uint32_t xw = lw[lo], yw = lw[hi];
+      const uint32_t xp = lp[lo], yp = lp[hi];
+      if ((xw < yw) || (xw == yw && xp < yp)) { lw[lo] = yw; lw[hi] = xw; lp[lo] = (pid_t)yp; lp[hi] = (pid_t)xp; }
+    };
     wave_sync();
     for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
-      for (int sl = sbit - 1; sl >= 0; --sl) {
+      for (int t = lane; t < (np >> 1); t += 64) {
+        const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
+        cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
+      }
+      wave_sync();
+      for (int sl = sbit - 2; sl >= 0; --sl) {
         const int strd = 1 << sl;
         for (int t = lane; t < (np >> 1); t += 64) {
           const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
-          const int hi = lo + strd;
-          const bool dn = ((lo & size) == 0);
-          const uint64_t x = list[lo], y = list[hi];
-          if ((x < y) == dn) { list[lo] = y; list[hi] = x; }
+          cmpx(lo, lo + strd);
         }
         wave_sync();
       }
     }
   };
 
-  // sequential merge of the sorted list[0, cnt) down to (not including) weights <= level; returns the position
+  // sequential merge of the sorted edge list [0, cnt) down to (not including) weights <= level; returns the position
   // of the first unprocessed edge; afterwards seg[] maps every vertex to its live representative
   auto merge_list = [&](int cnt, float level) -> int {
     int pos = 0;
@@ -179,12 +178,11 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       int sa = 0, sb = 0;
       bool proc = false;
       if (e < cnt) {
-        const uint64_t key = list[e];
-        w = vm_from_bits((uint32_t)(key >> 32));
+        w = vm_from_bits(lw[e]);
         proc = w > level;
-        const uint32_t pid = 0xffffffffu - (uint32_t)key;
-        sa = seg[pid >> 16];
-        sb = seg[pid & 0xffffu];
+        const uint32_t pid = PCOMP - (uint32_t)lp[e];
+        sa = seg[pid >> PSH];
+        sb = seg[pid & PMASK];
         while (rep[sa] != sa) sa = rep[sa];
         while (rep[sb] != sb) sb = rep[sb];
       }
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         if (sa == keep) { ta = nthr; za = nsz; }
         if (sb == keep) { tb = nthr; zb = nsz; }
         alive = alive && (lane > f);
-        if (lane == 0) { rep[gone] = (uint16_t)keep; thr[keep] = nthr; ssz[keep] = (uint16_t)nsz; ssz[gone] = 0; }
+        if (lane == 0) { rep[gone] = (idx_t)keep; thr[keep] = nthr; ssz[keep] = (idx_t)nsz; ssz[gone] = 0; }
         ++merges;
       }
       wave_sync();
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
     for (int c = lane; c < m; c += 64) {
       int s = seg[c];
       while (rep[s] != s) s = rep[s];
-      seg[c] = (uint16_t)s;
+      seg[c] = (idx_t)s;
     }
     wave_sync();
     return pos;
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         // outside vertices is taken once (x < y)
         for (int ix = 0; ix < n_min; ++ix) {
           const int x = minor[ix];
-          const float4 px = cpos[x];
+          const float pxx = cx[x], pxy = cy[x], pxz = cz[x];
           const int sx = seg[x];
           for (int base = 0; base < n_act; base += 64) {
             const int iy = base + lane;
@@ -283,22 +281,17 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
               const int y = alist[iy];
               const int sy = seg[y];
               if (sy != sx && (sy == big || x < y)) {
-                const float4 py = cpos[y];
-                float d2 = 1.0e4f;
-                if (px.w != 0.0f && py.w != 0.0f) {
-                  const float dx = (x < y) ? px.x - py.x : py.x - px.x;
-                  const float dy = (x < y) ? px.y - py.y : py.y - px.y;
-                  const float dz = (x < y) ? px.z - py.z : py.z - px.z;
-                  d2 = (dx * dx + dy * dy) + dz * dz;
-                }
+                const float dx = pxx - cx[y], dy = pxy - cy[y], dz = pxz - cz[y];  // (a-b)^2 == (b-a)^2: order-free
+                float d2 = (dx * dx + dy * dy) + dz * dz;
+                d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
                 inr = (d2 >= cut_lo) && (final_round || d2 < cut_hi);
-                pid = (x < y) ? (((uint32_t)x << 16) | (uint32_t)y) : (((uint32_t)y << 16) | (uint32_t)x);
+                pid = (x < y) ? (((uint32_t)x << PSH) | (uint32_t)y) : (((uint32_t)y << PSH) | (uint32_t)x);
               }
             }
             const unsigned long long mk = __ballot(inr);
             if (inr) {
               const int pos = n_list + count + __popcll(mk & lt_mask);
-              if (pos < LCAP) list[pos] = (uint64_t)pid;
+              if (pos < LCAP) lp[pos] = (pid_t)pid;
             }
             count += __popcll(mk);
           }
@@ -326,25 +319,24 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
             va[k] = ident ? ia : (int)alist[ia];
             vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
           }
-          float4 pa[4], pb[4];
+          float ax[4], ay[4], az[4], bx[4], by[4], bz[4];
           bool diff[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            pa[k] = cpos[va[k]]; pb[k] = cpos[vb[k]];
+            ax[k] = cx[va[k]]; ay[k] = cy[va[k]]; az[k] = cz[va[k]];
+            bx[k] = cx[vb[k]]; by[k] = cy[vb[k]]; bz[k] = cz[vb[k]];
             diff[k] = ok[k] && (merges == 0 || seg[va[k]] != seg[vb[k]]);
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            float d2 = 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
-            if (pa[k].w != 0.0f && pb[k].w != 0.0f) {
-              const float dx = pa[k].x - pb[k].x, dy = pa[k].y - pb[k].y, dz = pa[k].z - pb[k].z;
-              d2 = (dx * dx + dy * dy) + dz * dz;
-            }
+            const float dx = ax[k] - bx[k], dy = ay[k] - by[k], dz = az[k] - bz[k];
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
             const bool inr = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
             const unsigned long long mk = __ballot(inr);
             if (inr) {
               const int pos = n_list + count + __popcll(mk & lt_mask);
-              if (pos < LCAP) list[pos] = (uint64_t)(((uint32_t)va[k] << 16) | (uint32_t)vb[k]);
+              if (pos < LCAP) lp[pos] = (pid_t)(((uint32_t)va[k] << PSH) | (uint32_t)vb[k]);
             }
             count += __popcll(mk);
           }
@@ -369,15 +361,16 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         const int e = base + lane;
         bool drop = false;
         if (e < n_list + count) {
-          const uint32_t pid = (uint32_t)list[e];
-          const NodeRec& A = R(pid >> 16);
-          const NodeRec& B = R(pid & 0xffffu);
+          const uint32_t pid = (uint32_t)lp[e];
+          const NodeRec& A = R(pid >> PSH);
+          const NodeRec& B = R(pid & PMASK);
           // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
           const float ub = vm_weight_bound_da(A, B, W);
           float w = 0.0f;
           if (!(ub <= thr0)) w = vm_pair_weight(A, B, W);
           drop = !(w > thr0);
-          list[e] = drop ? 0ull : (((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - pid));
+          lw[e] = drop ? 0u : vm_bits(w);
+          lp[e] = drop ? (pid_t)0 : (pid_t)(PCOMP - pid);
         }
         dropped += __popcll(__ballot(drop));
       }
@@ -406,7 +399,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         if (ia < n_act) { v = alist[ia]; act = thr[seg[v]] < level; }
         const unsigned long long mk = __ballot(act);
         wave_sync();
-        if (act) alist[n_new + __popcll(mk & lt_mask)] = (uint16_t)v;
+        if (act) alist[n_new + __popcll(mk & lt_mask)] = (idx_t)v;
         n_new += __popcll(mk);
         wave_sync();
       }
@@ -427,7 +420,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
           int v = 0;
           if (ia < n_act) { v = alist[ia]; out = (int)seg[v] != big; }
           const unsigned long long mk = __ballot(out);
-          if (out) minor[n_min + __popcll(mk & lt_mask)] = (uint16_t)v;
+          if (out) minor[n_min + __popcll(mk & lt_mask)] = (idx_t)v;
           n_min += __popcll(mk);
         }
         wave_sync();
@@ -444,16 +437,16 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
       for (int base = pos; base < n_list; base += 64) {
         const int e = base + lane;
         bool keep_e = false;
-        uint64_t key = 0;
+        uint32_t kw = 0, kp = 0;
         if (e < n_list) {
-          key = list[e];
-          const uint32_t pid = 0xffffffffu - (uint32_t)key;
-          const int sa = seg[pid >> 16], sb = seg[pid & 0xffffu];
+          kw = lw[e]; kp = lp[e];
+          const uint32_t pid = PCOMP - kp;
+          const int sa = seg[pid >> PSH], sb = seg[pid & PMASK];
           keep_e = (sa != sb) && (thr[sa] < level) && (thr[sb] < level);
         }
         const unsigned long long mk = __ballot(keep_e);
         wave_sync();  // all lanes have read their entry before anyone overwrites the front of the list
-        if (keep_e) list[kept + __popcll(mk & lt_mask)] = key;
+        if (keep_e) { const int d = kept + __popcll(mk & lt_mask); lw[d] = kw; lp[d] = (pid_t)kp; }
         kept += __popcll(mk);
         wave_sync();
       }
@@ -472,7 +465,7 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         bool act = false;
         if (v < m) { const int s = seg[v]; act = (ssz[s] >= 2) && (thr[s] < thr0); }
         const unsigned long long mk = __ballot(act);
-        if (act) alist[nb + __popcll(mk & lt_mask)] = (uint16_t)v;
+        if (act) alist[nb + __popcll(mk & lt_mask)] = (idx_t)v;
         nb += __popcll(mk);
       }
       int active_segs = 0;
@@ -496,20 +489,21 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
         for (int base = 0; base < Pb; base += 64) {
           while (ia < nb - 1 && qq >= nb - 1 - ia) { qq -= (nb - 1 - ia); ++ia; }
           bool inr = false;
-          uint64_t key = 0;
+          uint32_t kw = 0, kp = 0;
           if (ia < nb - 1) {
             const int a = alist[ia], b = alist[ia + 1 + qq];
             if (seg[a] != seg[b]) {
               const float w = vm_pair_weight(R(a), R(b), W);
               ++n_evals;
               inr = (w <= thr0);  // heavier edges were examined in phase A; NaN compares false
-              key = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
+              kw = vm_bits(w);
+              kp = PCOMP - (((uint32_t)a << PSH) | (uint32_t)b);
             }
           }
           const unsigned long long mk = __ballot(inr);
           if (inr) {
             const int pos = count + __popcll(mk & lt_mask);
-            if (pos < LCAP) list[pos] = key;
+            if (pos < LCAP) { lw[pos] = kw; lp[pos] = (pid_t)kp; }
           }
           count += __popcll(mk);
           qq += 64;
@@ -532,9 +526,9 @@ __global__ __launch_bounds__(64) void k_localcut_wave(const uint32_t* __restrict
   }
   // ---- result: the segment of vertex 0 (the voxel itself) ----
   {
-    const uint16_t s0 = seg[0];
+    const int s0 = seg[0];
     for (int c = lane; c < m; c += 64)
-      if (seg[c] == s0) crow[loc[c]] = 1;
+      if ((int)seg[c] == s0) crow[c] = 1;
   }
   for (int o = 32; o > 0; o >>= 1) n_evals += __shfl_xor(n_evals, o, 64);
   if (lane == 0) evals_out[u] = (uint32_t)n_evals;  // summed on the host on request: no same-address atomics on the hot path

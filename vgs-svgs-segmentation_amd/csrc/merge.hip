@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                               int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
                                               uint32_t* __restrict__ csize) {
-  const int64_t u = blockIdx.x;
+  const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const int lane = threadIdx.x;
   const uint32_t i = used_ids[u];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_cc_init(const uint32_t* __restrict__ use
                                                 const uint32_t* __restrict__ adj_cnt, int adj_stride, const uint8_t* __restrict__ mutual,
                                                 const int32_t* __restrict__ attach, const uint8_t* __restrict__ owned,
                                                 uint32_t* __restrict__ parent) {
-  const int64_t u = blockIdx.x;
+  const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
                                                      const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent) {
-  const int64_t u = blockIdx.x;
+  const int64_t u = blockIdx.x;  // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
   if (u >= U) return;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
@@ -312,7 +312,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0) {
     if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
-    hipLaunchKernelGGL(k_cross, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+    hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p);
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
@@ -343,7 +343,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
   hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0)
-    hipLaunchKernelGGL(k_cc_init, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
+    hipLaunchKernelGGL(k_cc_init, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   if (U > 0) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0)

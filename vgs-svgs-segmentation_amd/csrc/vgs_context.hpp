@@ -21,6 +21,17 @@
 typedef VgsNode NodeRec;
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
 
+// One-workgroup-per-item kernels: workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only), so
+// item = (b % 8) * ceil(n/8) + b / 8 hands every XCD one contiguous eighth of the Morton-ordered item list and
+// spatial neighbours share an L2.  Launch vgs_xcd_grid(n) workgroups and drop items >= n.
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t vgs_xcd_item(unsigned int b, int64_t n) {
+  const int64_t per = (n + 7) >> 3;
+  return (int64_t)(b & 7u) * per + (int64_t)(b >> 3);
+}
+#endif
+static inline unsigned int vgs_xcd_grid(int64_t n) { return (unsigned int)(((n + 7) >> 3) << 3); }
+
 // grow-only device buffer
 template <typename T>
 struct DevBuf {
