@@ -58,7 +58,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 template <int MAXM, int CAP, bool NODES_LDS>
-__global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__ work, int n_work,
+__global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__ work, int n_work, const unsigned int* __restrict__ n_work_dev,
                                                     const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                     int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                     uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   __shared__ int s_m, s_nlist, s_rdone, s_sel, s_err, s_act[LC_TB / 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= n_work) return;
+  // a hand-over list is launched with a fixed grid while its length is still on the device: n_work_dev, when given,
+  // holds the list length and n_work is the offset of this launch in the list
+  if (n_work_dev) { if ((unsigned int)n_work + blockIdx.x >= *n_work_dev) return; work += n_work; }
+  else if ((int)blockIdx.x >= n_work) return;
   const uint32_t u = work[blockIdx.x];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + (int64_t)u * adj_stride;
@@ -475,7 +478,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
   unsigned int* d_ng = d_nf + 1;
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
-  constexpr int LCAP_A = 448, LCAP_B = 320, LCAP_C = 2048;  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
+  constexpr int LCAP_A = 384, LCAP_B = 232, LCAP_C = 2048;
+  constexpr unsigned int GRID_F = 16384, GRID_G = 1024;  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
@@ -502,20 +506,23 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.grow = 2.25f;
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
-  auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
-    // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond
+  // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the
+  // device (fixed grid of nw workgroups starting at list position `offset`); otherwise nw is the length.
+  auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid, const unsigned int* n_dev = nullptr, unsigned int offset = 0) -> vgs_status {
     if (nw == 0) return VGS_OK;
+    const int arg_n = n_dev ? (int)offset : (int)nw;
     if (mid) {
-      auto kern = k_localcut<SMALL_M, SMALL_CAP, true>;
-      const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, true>();
+      // records through L2 (NODES_LDS = false): 34 KB instead of 42 KB of LDS per workgroup, measured slightly faster
+      auto kern = k_localcut<SMALL_M, SMALL_CAP, false>;
+      const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                          c->node.p, LP, c->conn.p, cnt, c->csize.p);
     } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                          c->node.p, LP, c->conn.p, cnt, c->csize.p);
     }
     return VGS_OK;
@@ -543,9 +550,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2],
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
     vgs_status st = launch_block(ids_d, nabc[3], false);
+    // class C hand-overs: fixed grid, length read on the device (no host round trip)
+    if (st == VGS_OK && nabc[2] > 0) st = launch_block(ids_g, nabc[2] < GRID_G ? nabc[2] : GRID_G, false, d_ng, 0);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
@@ -553,23 +562,32 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // classes A and B have the same LDS footprint, so their workgroups interleave freely; B (heavier) goes first
   if (nabc[1] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
-                       ids_b, (int)nabc[1], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+                       ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
   if (nabc[0] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, (const uint32_t*)nullptr, 0,
-                       ids_a, (int)nabc[0], c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
+  // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
+  // trip before the launch); the host checks the length afterwards.
+  // (A second pass through the wave kernel with a 1024-edge list and 16 rounds was measured: it costs as much as the
+  // workgroup kernel and still hands half of them over.)
+  const unsigned int nab = nabc[0] + nabc[1];
+  const unsigned int grid_f = nab < GRID_F ? nab : GRID_F;
+  {
+    vgs_status st = launch_block(ids_f, grid_f, true, d_nf, 0);
+    if (st != VGS_OK) return st;
+  }
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   unsigned int nfg[2] = {0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nfg, d_nf, 8, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   const unsigned int nf = nfg[0] + nfg[1];
-  if (nfg[0] > 0) {
-    vgs_status st = launch_block(ids_f, nfg[0], true);   // m <= WAVE_B <= SMALL_M
-    if (st != VGS_OK) return st;
-  }
-  if (nfg[1] > 0) {
-    vgs_status st = launch_block(ids_g, nfg[1], false);
+  {
+    // lists longer than their fixed grids (not seen on the benchmark scenes): finish the rest
+    vgs_status st = VGS_OK;
+    if (nfg[0] > grid_f) st = launch_block(ids_f + grid_f, nfg[0] - grid_f, true);
+    if (st == VGS_OK && nfg[1] > GRID_G) st = launch_block(ids_g + GRID_G, nfg[1] - GRID_G, false);
     if (st != VGS_OK) return st;
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
@@ -589,6 +607,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     long long tot = 0;
     for (uint32_t x : ev) tot += x;
     c->counts[VGS_N_PAIRS] = tot;
+  }
+  if (getenv("VGS_DEBUG") && nfg[0] > 0) {
+    std::vector<uint32_t> idf(nfg[0]), ev((size_t)U), ac((size_t)U);
+    VGS_HIP_TRY(c, hipMemcpy(idf.data(), ids_f, idf.size() * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->csize.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(ac.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    double sm = 0, se = 0, sp = 0; uint32_t mn = ~0u, mx = 0;
+    for (uint32_t u : idf) { sm += ac[u]; se += ev[u]; sp += 0.5 * ac[u] * (ac[u] - 1.0); mn = ac[u] < mn ? ac[u] : mn; mx = ac[u] > mx ? ac[u] : mx; }
+    fprintf(stderr, "[vgs] handed-over voxels: %u, m avg %.1f min %u max %u, evaluations avg %.0f of %.0f pairs, slow-path %llu\n", nfg[0], sm / nfg[0], mn, mx, se / nfg[0], sp / nfg[0], h[7]);
   }
   if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
 #ifdef VGS_PROF

@@ -64,6 +64,7 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
 template <int MAXM, int LCAP>
 __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
                                                       const uint32_t* __restrict__ work, int n_work,
+                                                      const unsigned int* __restrict__ n_work_dev,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   __shared__ uint32_t lw[LCAP];
   __shared__ float cx[MAXM], cy[MAXM], cz[MAXM];  // centroids; cx = NaN when the position is unusable (VS:1829)
   __shared__ float thr[MAXM];
+  __shared__ uint32_t claim[MAXM];                // merge: first undecided edge of the step touching a segment (all ones between uses)
   __shared__ uint32_t gid[MAXM];                  // global voxel ids: the few pairs that get a full evaluation read their records through L2
   __shared__ pid_t lp[LCAP];
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
@@ -90,12 +92,15 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   // Morton-ordered work list so that neighbouring voxels share their L2
   // An optional first list (the heavier voxels of the launch) is dealt out the same way before the main list, so
   // that the long-running wavefronts start first and the light ones fill the tail.
+  // A hand-over list is launched with a fixed grid while its length is still on the device (n_work_dev).
+  // It is taken in plain order, so that a list longer than the grid leaves a suffix for the caller.
+  if (n_work_dev) n_work = (int)*n_work_dev;
   const unsigned int nb_first = ((unsigned int)n_first + 7u) & ~7u;
   const bool first = blockIdx.x < nb_first;
   const unsigned int bidx = first ? blockIdx.x : blockIdx.x - nb_first;
   const int n_mine = first ? n_first : n_work;
   const int per_xcd = (n_mine + 7) >> 3;
-  const int widx = (int)(bidx & 7u) * per_xcd + (int)(bidx >> 3);
+  const int widx = n_work_dev ? (int)bidx : (int)(bidx & 7u) * per_xcd + (int)(bidx >> 3);
   if (widx >= n_mine) return;
   const uint32_t u = (first ? work_first : work)[widx];
   const int n = (int)adj_cnt[u];
@@ -120,10 +125,11 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
     return;
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
+  const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);  // cut / size, looked up across lanes
   for (int c = lane; c < m; c += 64) {
     const uint32_t t = (uint32_t)row[c];
     gid[c] = t;
-    seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c;
+    seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c; claim[c] = 0xffffffffu;
     const NodeRec& rc = node[t];
     cx[c] = (rc.flags & VGS_F_POS) ? rc.c[0] : vm_nan();
     cy[c] = rc.c[1];
@@ -167,8 +173,22 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
     }
   };
 
-  // sequential merge of the sorted edge list [0, cnt) down to (not including) weights <= level; returns the position
-  // of the first unprocessed edge; afterwards seg[] maps every vertex to its live representative
+  // Merge of the sorted edge list [0, cnt) down to (not including) weights <= level, in the reference's sequential
+  // order; returns the position of the first unprocessed edge; afterwards seg[] maps every vertex to its live
+  // representative.  64 edges per step, one per lane.  An edge is DECIDED when no earlier undecided edge of the step
+  // touches either of its segments (found with one LDS min-claim per segment): the state it sees is then the state
+  // the sequential scan would show it, so it merges or is rejected for good, and all decided edges of an iteration
+  // act at once on disjoint segments.  Segment state (representative, threshold, size) lives in LDS only.
+  auto cut_over = [&](int nsz) -> float {  // cut / nsz, as vm_cut_threshold divides (called by all lanes)
+    if constexpr (MAXM <= 128) {
+      const int a = ((nsz - 1) & 63) << 2;
+      const float lo = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(cut_tab0)));
+      const float hi = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(cut_tab1)));
+      return nsz > 64 ? hi : lo;
+    } else {
+      return cut / (float)(nsz > 0 ? nsz : 1);
+    }
+  };
   auto merge_list = [&](int cnt, float level) -> int {
     int pos = 0;
     bool reached = false;
@@ -176,43 +196,49 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
       const int e = pos + lane;
       float w = 0.f;
       int sa = 0, sb = 0;
-      bool proc = false;
+      bool alive = false;
       if (e < cnt) {
         w = vm_from_bits(lw[e]);
-        proc = w > level;
+        alive = w > level;
         const uint32_t pid = PCOMP - (uint32_t)lp[e];
         sa = seg[pid >> PSH];
         sb = seg[pid & PMASK];
-        while (rep[sa] != sa) sa = rep[sa];
-        while (rep[sb] != sb) sb = rep[sb];
       }
-      const int nproc = __popcll(__ballot(proc));  // sorted: the processable edges are a prefix of the step
-      float ta = thr[sa], tb = thr[sb];
-      int za = ssz[sa], zb = ssz[sb];
-      bool alive = proc;
+      const int nproc = __popcll(__ballot(alive));  // sorted: the processable edges are a prefix of the step
       while (true) {
-        const bool pass = alive && (sa != sb) && (w > ta) && (w > tb);
-        const unsigned long long mk = __ballot(pass);
-        if (mk == 0ull) break;   // nothing in this step can merge in the current state
-        // the first mergeable edge in order does merge: the state has not changed since the edges before it failed
-        const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)mk) - 1);
-        const float wf = lw_readlane_f(w, f);
-        const int s1 = __builtin_amdgcn_readlane(sa, f), s2 = __builtin_amdgcn_readlane(sb, f);
-        const float t1 = lw_readlane_f(ta, f), t2 = lw_readlane_f(tb, f);
-        const int z1 = __builtin_amdgcn_readlane(za, f), z2 = __builtin_amdgcn_readlane(zb, f);
-        const int keep = (t1 >= t2) ? s1 : s2;   // VS:1972-1983: the segment with the larger threshold survives
-        const int gone = (t1 >= t2) ? s2 : s1;
-        const int nsz = z1 + z2;
-        const float nthr = vm_cut_threshold(wf, cut, nsz);  // seg_int = w (VS:1988)
-        if (sa == gone) sa = keep;
-        if (sb == gone) sb = keep;
-        if (sa == keep) { ta = nthr; za = nsz; }
-        if (sb == keep) { tb = nthr; zb = nsz; }
-        alive = alive && (lane > f);
-        if (lane == 0) { rep[gone] = (idx_t)keep; thr[keep] = nthr; ssz[keep] = (idx_t)nsz; ssz[gone] = 0; }
-        ++merges;
+        if (alive) {
+          int r;
+          while ((r = rep[sa]) != sa) sa = r;
+          while ((r = rep[sb]) != sb) sb = r;
+          alive = sa != sb;  // inside one segment: skipped now and for ever
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
+        wave_sync();
+        bool decided = false;
+        float ta = 0.f, tb = 0.f;
+        int nsz = 1;
+        if (alive) {
+          decided = (claim[sa] == (uint32_t)lane) && (claim[sb] == (uint32_t)lane);
+          ta = thr[sa]; tb = thr[sb];
+          nsz = (int)ssz[sa] + (int)ssz[sb];
+        }
+        wave_sync();
+        if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
+        const float co = cut_over(nsz);
+        const bool pass = decided && (w > ta) && (w > tb);
+        if (pass) {
+          const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
+          const int gone = (ta >= tb) ? sb : sa;
+          rep[gone] = (idx_t)keep;
+          thr[keep] = w - co;                      // = vm_cut_threshold(w, cut, nsz): seg_int = w (VS:1988)
+          ssz[keep] = (idx_t)nsz;
+          ssz[gone] = 0;
+        }
+        merges += __popcll(__ballot(pass));
+        alive = alive && !decided;
+        wave_sync();
       }
-      wave_sync();
       if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
       if (merges >= m - 1) break;  // one segment left
     }
