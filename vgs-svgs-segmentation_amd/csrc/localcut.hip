@@ -414,26 +414,36 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 #include "localcut_wave.hpp"
 
-// split the used voxels into three classes by the number of used neighbours (one atomic per wavefront and class)
-__global__ void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
-                           int max_a, int max_b, int max_c, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
-                           uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d, unsigned int* __restrict__ n_abc) {
+// split the used voxels into four classes by the number of neighbours; order inside a class follows the voxel order.
+// One global atomic per class and 1024 voxels (same-address atomics serialise).
+__global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
+                                                   int max_a, int max_b, int max_c, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
+                                                   uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d, unsigned int* __restrict__ n_abc) {
+  __shared__ unsigned int s_cnt[16][4];   // per wavefront and class: count, then base
+  __shared__ unsigned int s_base[4];
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int cls = -1;
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
     cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3));
   }
-  uint32_t* const outs[4] = {ids_a, ids_b, ids_c, ids_d};
+  unsigned long long mk[4];
   for (int k = 0; k < 4; ++k) {
-    const unsigned long long mk = __ballot(cls == k);
-    if (mk == 0ull) continue;
-    unsigned int base = 0;
-    if (lane == (__ffsll((long long)mk) - 1)) base = atomicAdd(&n_abc[k], (unsigned int)__popcll(mk));
-    base = __shfl(base, __ffsll((long long)mk) - 1, 64);
-    if (cls == k) outs[k][base + __popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)u;
+    mk[k] = __ballot(cls == k);
+    if (lane == 0) s_cnt[wave][k] = (unsigned int)__popcll(mk[k]);
   }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    unsigned int tot = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
+    s_base[k] = tot ? atomicAdd(&n_abc[k], tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t* const outs[4] = {ids_a, ids_b, ids_c, ids_d};
+  for (int k = 0; k < 4; ++k)
+    if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }
 
 static VgsWeightParams make_weight_params(const vgs_params& p) {
@@ -482,7 +492,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
-  hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
+  hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
                      0, WAVE_A, WAVE_B, WAVE_C, ids_a, ids_b, ids_c, ids_d, d_nabc);
   unsigned int nabc[4] = {0, 0, 0, 0};
   VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 16, hipMemcpyDeviceToHost, c->stream));

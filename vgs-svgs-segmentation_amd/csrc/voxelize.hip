@@ -70,23 +70,51 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 struct BoxD { double min[3], max[3]; int defined; };
 
 // smallest index >= start of a finite point outside the box (or any finite point if the box is undefined)
+// Packed xyz (12-byte points) is read as three 16-byte loads per four points; the running answer is polled once per trip.
+__device__ __forceinline__ bool fv_outside(float x, float y, float z, const BoxD& box) {
+  if (!finite3(x, y, z)) return false;
+  return !box.defined || (double)x < box.min[0] || (double)x >= box.max[0] || (double)y < box.min[1] ||
+         (double)y >= box.max[1] || (double)z < box.min[2] || (double)z >= box.max[2];
+}
+
 __global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t start, int64_t n, BoxD box,
                                   unsigned long long* __restrict__ result) {
   unsigned long long best = ~0ull;
-  for (int64_t i = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if ((unsigned long long)i > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    const float* p = xyz + i * stride_f;
-    float x = p[0], y = p[1], z = p[2];
-    if (!finite3(x, y, z)) continue;
-    bool out = !box.defined || (double)x < box.min[0] || (double)x >= box.max[0] || (double)y < box.min[1] ||
-               (double)y >= box.max[1] || (double)z < box.min[2] || (double)z >= box.max[2];
-    if (out) { best = (unsigned long long)i; break; }
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  if (stride_f == 3 && (((uintptr_t)xyz) & 15u) == 0) {
+    // groups of four points = 48 bytes = three float4; group g holds points 4g .. 4g+3
+    const float4* q = (const float4*)xyz;
+    for (int64_t g = (start >> 2) + tid; 4 * g < n; g += nthreads) {
+      if ((unsigned long long)(4 * g) > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      float v[12];
+      if (4 * g + 4 <= n) {
+        const float4 a = q[3 * g], b = q[3 * g + 1], c4 = q[3 * g + 2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c4.x; v[9] = c4.y; v[10] = c4.z; v[11] = c4.w;
+      } else {
+        for (int k = 0; k < 12; ++k) v[k] = (4 * g + k / 3 < n) ? xyz[12 * g + k] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t i = 4 * g + k;
+        if (i >= start && i < n && best == ~0ull && fv_outside(v[3 * k], v[3 * k + 1], v[3 * k + 2], box)) best = (unsigned long long)i;
+      }
+      if (best != ~0ull) break;
+    }
+  } else {
+    for (int64_t i = start + tid; i < n; i += nthreads) {
+      if ((unsigned long long)i > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      const float* p = xyz + i * stride_f;
+      if (fv_outside(p[0], p[1], p[2], box)) { best = (unsigned long long)i; break; }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     unsigned long long other = __shfl_down(best, o, 64);
     best = other < best ? other : best;
   }
-  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(result, best);
+  // (same-address atomics serialise: only a wavefront that improves the answer issues one)
+  if ((threadIdx.x & 63) == 0 && best < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, best);
 }
 
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
@@ -173,7 +201,8 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
     b.defined = box.defined ? 1 : 0;
     if (start < c->N) {
       int64_t work = c->N - start;
-      int blocks = (int)std::min<int64_t>((work + 255) / 256, 2048);
+      int blocks = (int)std::min<int64_t>((work / 4 + 255) / 256 + 1, 4096);
+      if (!b.defined) blocks = std::min(blocks, 8);  // every finite point violates an undefined box: the first one is near `start`
       hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, start, c->N, b, d_res);
     }
     unsigned long long idx = ~0ull;
