@@ -583,7 +583,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // (A second pass through the wave kernel with a 1024-edge list and 16 rounds was measured: it costs as much as the
   // workgroup kernel and still hands half of them over.)
   const unsigned int nab = nabc[0] + nabc[1];
-  const unsigned int grid_f = nab < GRID_F ? nab : GRID_F;
+  // about 1.4 % of the A/B voxels are handed over on the urban scenes; idle workgroups of this kernel are not free
+  const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
   {
     vgs_status st = launch_block(ids_f, grid_f, true, d_nf, 0);
     if (st != VGS_OK) return st;

@@ -83,7 +83,7 @@ __global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t
         s = (s + 1) & mask;
       }
     }
-    nbr[26 * v + o] = t;
+    nbr[(int64_t)o * V + v] = t;   // [26][V]: a wavefront reads one offset of 64 consecutive voxels
     if (t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
   }
   float n[3];
@@ -166,11 +166,14 @@ __global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const 
   float best_d = dist_in[v];
   const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
   const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
+  const int own = best_l;
+  int last = own;
   for (int o = 0; o < 26; ++o) {
-    const int t = nbr[26 * v + o];
+    const int t = nbr[(int64_t)o * V + v];
     if (t < 0) continue;
     const int l = label_in[t];
-    if (l < 0 || l == label_in[v]) continue;
+    if (l < 0 || l == own || l == last) continue;  // the label just tried gives the same distance again
+    last = l;
     const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
     if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
   }
@@ -178,7 +181,7 @@ __global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const 
   dist_out[v] = best_d;
   // the per-supervoxel sums are integers: moving this voxel's contribution from its old owner to the new one gives
   // exactly the sums a full re-accumulation would (and after the first rounds only the frontier moves)
-  const int old_l = label_in[v];
+  const int old_l = own;
   if (best_l != old_l) {
     for (int a = 0; a < 3; ++a) {
       const long long fp = vccs_fix_pos(c[a]), fn = vccs_fix_nrm(n[a]);
