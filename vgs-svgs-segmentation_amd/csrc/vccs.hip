@@ -167,11 +167,16 @@ __global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const 
   const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
   const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
   const int own = best_l;
+  // all 26 neighbour ids, then all 26 labels: independent loads in flight together (the serial walk was latency bound)
+  int nl[26];
+#pragma unroll
+  for (int o = 0; o < 26; ++o) nl[o] = nbr[(int64_t)o * V + v];
+#pragma unroll
+  for (int o = 0; o < 26; ++o) nl[o] = nl[o] >= 0 ? label_in[nl[o]] : -1;
   int last = own;
+#pragma unroll
   for (int o = 0; o < 26; ++o) {
-    const int t = nbr[(int64_t)o * V + v];
-    if (t < 0) continue;
-    const int l = label_in[t];
+    const int l = nl[o];
     if (l < 0 || l == own || l == last) continue;  // the label just tried gives the same distance again
     last = l;
     const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
