@@ -56,6 +56,21 @@ def cpu_baseline(v, xyz_full, params, target_points=150_000):
                       f"flavour (n x n matrix, by-value vectors, std::sort), {dt:.1f} s, {res.pair_evals} pair evaluations"}
 
 
+def profiled_traffic(n_points):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json,
+    written by tools/collect_profiles.sh from FETCH_SIZE + WRITE_SIZE of the same bench command); None if the profile
+    is missing or was taken on another workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t.get("points", -1)) != int(n_points):
+            return None
+        return float(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +143,7 @@ def main():
     for _ in range(args.steps):
         step()
         st = runner.stage_times()
-        kern_ms.append(st["localcut_kernel"])
+        kern_ms.append(st["localcut_bulk"])
         for k, val in st.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + val
     torch.cuda.synchronize(dev)
@@ -145,9 +160,13 @@ def main():
         N, V, E = c["points"], c["voxels"], c["adj"]
         total_points = n_per * world * args.steps
         # algorithmic bytes of one pass: 28 B/point + 48 B/voxel + 4 B/adjacency entry
-        alg_bytes = 28 * N + 48 * V + 4 * E
+        # The dominant kernel is the bulk class of the local cut, one launch per step over class_a of the used voxels:
+        # its share of the run's algorithmic bytes over its own duration (HIP events on its stream, VGS_T_LOCALCUT_BULK).
+        alg_run = 28 * N + 48 * V + 4 * E
+        alg_bytes = int(alg_run * (c["class_a"] / max(c["used"], 1)))
         k_avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        traffic = profiled_traffic(N) if world == 1 else None
         out = {
             "metric": "segmented points/sec (end-to-end VGS)",
             "value": total_points / elapsed,
@@ -164,10 +183,11 @@ def main():
             "config": {"workload": workload, "points_per_gpu": n_per, "voxels": V, "used_voxels": c["used"], "adjacency_entries": E,
                        "segments": c["kept"], "pair_evaluations": c["pairs"],
                        "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles, shared grid, one all-gather of boundary labels"},
-            "roofline": {"bound": "hbm", "kernel": "k_localcut (local affinity graph + threshold-merge cut)",
+            "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,384> (local affinity graph + threshold-merge cut, bulk class)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
-                         "end_to_end_frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
+                         "algorithmic_bytes_per_step": alg_run,
+                         "end_to_end_frac": alg_run / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "pair_evals_per_s": c["pairs"] / (k_avg_ms * 1e-3) if k_avg_ms > 0 else 0.0},
             "stage_ms": {k: val / args.steps for k, val in stage_acc.items()},
         }

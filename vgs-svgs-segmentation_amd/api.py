@@ -108,13 +108,13 @@ class Engine:
         c = np.zeros(_lib.N_COUNTS, dtype=np.int64)
         self._ck(self._L.vgs_get_counts(self._h, _ptr(c)))
         names = ["points", "finite", "voxels", "used", "adj", "clusters", "kept", "pairs", "depth", "isolated", "reattached",
-                 "supervoxels"]
+                 "supervoxels", "handed_over", "class_a", "class_bc", "class_d"]  # 12..15: local-cut scheduling diagnostics
         return {k: int(c[i]) for i, k in enumerate(names)}
 
     def stage_times(self):
         t = np.zeros(_lib.T_COUNT, dtype=np.float64)
         self._ck(self._L.vgs_get_stage_times(self._h, _ptr(t)))
-        names = ["voxelize", "features", "adjacency", "localcut", "merge", "labels", "total", "localcut_kernel", "supervoxel"]
+        names = ["voxelize", "features", "adjacency", "localcut", "merge", "labels", "total", "localcut_kernel", "supervoxel", "localcut_bulk"]
         return {k: float(t[i]) for i, k in enumerate(names)}
 
     def bbox(self):

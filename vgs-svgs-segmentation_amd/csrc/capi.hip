@@ -120,7 +120,7 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
     delete c;
     return VGS_E_HIP;
   }
-  for (int i = 0; i < 10; ++i)
+  for (int i = 0; i < 12; ++i)
     if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
   *out = c;
   return VGS_OK;
@@ -143,7 +143,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
-  for (int i = 0; i < 10; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 12; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);

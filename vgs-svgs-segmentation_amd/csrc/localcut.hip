@@ -574,9 +574,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
                        ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
   if (nabc[0] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, (const uint32_t*)nullptr, 0,
                        ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
   // trip before the launch); the host checks the length afterwards.
@@ -611,6 +613,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
+  VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[10], c->ev[11]));
+  c->times[VGS_T_LOCALCUT_BULK] = kms;
   c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts live in csize until the merge stage reuses it; summed below
   {
     std::vector<uint32_t> ev((size_t)U);

@@ -142,7 +142,7 @@ struct vgs_ctx {
 
   int64_t counts[VGS_N_COUNTS] = {0};
   double times[VGS_T_COUNT] = {0};
-  hipEvent_t ev[10] = {nullptr};
+  hipEvent_t ev[12] = {nullptr};
 
   // SVGS
   DevBuf<int32_t> sv_label;     // per point: supervoxel label (0 = unassigned), what getLabeledCloud returns (SS:283)
