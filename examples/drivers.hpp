@@ -1,0 +1,118 @@
+// examples/drivers.hpp -- the reference's two drivers (`test`:9-86 segmentationVGS, `test`:91-170 segmentationSVGS)
+// written against include/vgs_segmentation.hpp: same objects, same call order, same parameter unpacking from the
+// task vector (0-based line index).  The viewer calls (showColoredClusters) are dropped; saving is left to the caller.
+#ifndef VGS_EXAMPLE_DRIVERS_HPP_
+#define VGS_EXAMPLE_DRIVERS_HPP_
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "vgs_segmentation.hpp"
+
+struct DriverSummary { long points = 0, voxels = 0, supervoxels = 0, clusters = 0, kept = 0, labelled = 0; };
+
+inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>& input_vector,
+                           std::vector<std::vector<int>>& clusters_points_idx, DriverSummary* sum = nullptr) {
+  float voxel_size = 0.15f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f, sig_w = 2.0f,
+        cut_thred = 0.3f;
+  int points_min = 10, adjacency_min = 3, voxels_min = 3;
+  if (input_vector.size() > 50) {  // test:25-37
+    voxel_size = (float)std::atof(input_vector[28].c_str());
+    graph_size = (float)std::atof(input_vector[30].c_str());
+    sig_p = (float)std::atof(input_vector[32].c_str());
+    sig_n = (float)std::atof(input_vector[34].c_str());
+    sig_o = (float)std::atof(input_vector[36].c_str());
+    sig_e = (float)std::atof(input_vector[38].c_str());
+    sig_c = (float)std::atof(input_vector[40].c_str());
+    sig_w = (float)std::atof(input_vector[42].c_str());
+    cut_thred = (float)std::atof(input_vector[44].c_str());
+    points_min = std::atoi(input_vector[46].c_str());
+    adjacency_min = std::atoi(input_vector[48].c_str());
+    voxels_min = std::atoi(input_vector[50].c_str());
+  }
+  double min_x = 0, min_y = 0, min_z = 0, max_x = 0, max_y = 0, max_z = 0;
+
+  // Voxelization (test:51-57)
+  pcl::VoxelBasedSegmentation<pcl::PointXYZ> voxel_structure(voxel_size);
+  voxel_structure.setInputCloud(input_cloud);
+  voxel_structure.getCloudPointNum(input_cloud);
+  voxel_structure.addPointsFromInputCloud();
+  voxel_structure.setVoxelSize(voxel_size, points_min, voxels_min, adjacency_min);
+  voxel_structure.getBoundingBox(min_x, min_y, min_z, max_x, max_y, max_z);
+  voxel_structure.setBoundingBox(min_x, min_y, min_z, max_x, max_y, max_z);
+  // centres (test:60-62)
+  voxel_structure.setVoxelCenters();
+  auto voxel_centers = voxel_structure.getVoxelCenters();
+  const int voxels = voxel_structure.getVoxelNum();
+  // features, adjacency, segmentation (test:65-71)
+  voxel_structure.calcualteVoxelCloudAttributes(input_cloud);
+  voxel_structure.findAllVoxelAdjacency(graph_size);
+  voxel_structure.segmentVoxelCloudWithGraphModel(cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w);
+  // output (test:74-76)
+  std::vector<int32_t> labels = voxel_structure.drawColorMapofPointsinClusters();
+  clusters_points_idx = voxel_structure.getClusterIdx();
+  if (sum) {
+    sum->points = (long)input_cloud->points.size(); sum->voxels = voxels; sum->clusters = voxel_structure.getClusterNum();
+    sum->kept = (long)clusters_points_idx.size();
+    sum->labelled = 0;
+    for (auto& c : clusters_points_idx) sum->labelled += (long)c.size();
+  }
+  (void)voxel_centers; (void)labels;
+  return 0;
+}
+
+inline int segmentationSVGS(PCXYZPtr input_cloud, const std::vector<std::string>& input_vector,
+                            std::vector<std::vector<int>>& clusters_points_idx, DriverSummary* sum = nullptr) {
+  // Task_File_SVGS.txt values
+  float voxel_size = 0.05f, seed_size = 0.25f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f,
+        sig_w = 1.0f, sig_a = 0.0f, sig_b = 0.25f, cut_thred = 0.5f;
+  int points_min = 0, voxels_min = 3, adjacency_min = 3;
+  if (input_vector.size() > 60) {  // test:108-125
+    voxel_size = (float)std::atof(input_vector[28].c_str());
+    seed_size = (float)std::atof(input_vector[30].c_str());
+    graph_size = (float)std::atof(input_vector[32].c_str());
+    sig_p = (float)std::atof(input_vector[34].c_str());
+    sig_n = (float)std::atof(input_vector[36].c_str());
+    sig_o = (float)std::atof(input_vector[38].c_str());
+    sig_e = (float)std::atof(input_vector[40].c_str());
+    sig_c = (float)std::atof(input_vector[42].c_str());
+    sig_w = (float)std::atof(input_vector[44].c_str());
+    sig_a = (float)std::atof(input_vector[46].c_str());
+    sig_b = (float)std::atof(input_vector[48].c_str());
+    sig_c = (float)std::atof(input_vector[50].c_str());  // the reference reuses sig_c for the normal importance (test:120)
+    cut_thred = (float)std::atof(input_vector[52].c_str());
+    points_min = (int)std::atof(input_vector[54].c_str());
+    voxels_min = std::atoi(input_vector[58].c_str());
+    adjacency_min = std::atoi(input_vector[60].c_str());
+  } else {
+    sig_c = 0.75f;  // normal importance of Task_File_SVGS.txt, carried in sig_c as above
+  }
+  double min_x = 0, min_y = 0, min_z = 0, max_x = 0, max_y = 0, max_z = 0;
+
+  pcl::SuperVoxelBasedSegmentation<pcl::PointXYZ> supervoxel_structure(voxel_size);  // test:138
+  supervoxel_structure.setInputCloud(input_cloud);
+  supervoxel_structure.getCloudPointNum(input_cloud);
+  supervoxel_structure.addPointsFromInputCloud();
+  supervoxel_structure.setVoxelSize(voxel_size, points_min);                          // test:144-146
+  supervoxel_structure.setSupervoxelSize(seed_size, voxels_min, points_min, adjacency_min);
+  supervoxel_structure.setGraphSize(seed_size * 2, graph_size);
+  supervoxel_structure.getBoundingBox(min_x, min_y, min_z, max_x, max_y, max_z);      // test:148-149
+  supervoxel_structure.setBoundingBox(min_x, min_y, min_z, max_x, max_y, max_z);
+  supervoxel_structure.setSupervoxelCentersCentroids();                               // test:152-153
+  supervoxel_structure.getVoxelNum();
+  supervoxel_structure.segmentSupervoxelCloudWithGraphModel(sig_a, sig_b, sig_c, cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w);  // test:156
+  std::vector<int32_t> labels = supervoxel_structure.drawColorMapofPointsinClusters();  // test:159-160
+  clusters_points_idx = supervoxel_structure.getClusterIdx();
+  if (sum) {
+    sum->points = (long)input_cloud->points.size(); sum->voxels = supervoxel_structure.getVoxelNum();
+    sum->supervoxels = supervoxel_structure.getSuperVoxelNum(); sum->clusters = supervoxel_structure.getClusterNum();
+    sum->kept = (long)clusters_points_idx.size();
+    sum->labelled = 0;
+    for (auto& c : clusters_points_idx) sum->labelled += (long)c.size();
+  }
+  (void)labels;
+  return 0;
+}
+
+#endif  // VGS_EXAMPLE_DRIVERS_HPP_

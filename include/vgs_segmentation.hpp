@@ -200,6 +200,12 @@ class SuperVoxelBasedSegmentation {
     p_.graph_size = (float)large_resolution;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
   }
+  void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {  // test:145 (inherited from the octree)
+    double b[6];
+    chk(vgs_voxelize(ctx()), "vgs_voxelize");   // the class's own octree at voxel_resolution_
+    chk(vgs_get_bbox(ctx(), b), "vgs_get_bbox");
+    min_x = b[0]; min_y = b[1]; min_z = b[2]; max_x = b[3]; max_y = b[4]; max_z = b[5];
+  }
   void setBoundingBox(double, double, double, double, double, double) {}                 // SS:166
   void setSupervoxelCentersCentroids() {}                                                // SS:178 (own-octree bookkeeping, unused by the result)
   // the supervoxel labelling pcl::SupervoxelClustering would produce may also be supplied by the caller

@@ -30,3 +30,56 @@ def test_cpp_driver_matches_python_engine(gpu, tmp_path):
     c = eng.counts()
     assert (n, voxels, clusters, kept) == (c["points"], c["voxels"], c["clusters"], c["kept"])
     assert labelled == int((eng.point_labels() >= 0).sum())
+
+
+RUN = os.path.join(ROOT, "examples", "vgs_run")
+
+
+def _write_task(path, method, lines):
+    body = ["// header"] * 70
+    for k, v in lines.items():
+        body[k] = str(v)
+    body[24] = str(method)
+    with open(path, "wb") as f:
+        f.write("\r\n".join(body).encode())  # the reference's task files are CRLF
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [2, 3])
+def test_task_file_front_end(gpu, tmp_path, method):
+    """vgs_run: task file -> PCD in -> segmentationVGS / segmentationSVGS (reference `test` call order) -> coloured PCD out."""
+    subprocess.check_call(["make", "-C", CSRC, "-s", "example"])
+    xyz = gpu.scenes.town_scene(60_000)
+    gpu.pcd.write_pcd(tmp_path / "Town_Test.pcd", xyz, mode="binary_compressed")
+    if method == 2:
+        lines = {12: str(tmp_path) + "/", 15: "Town_Test.pcd", 18: str(tmp_path) + "/", 21: "Town_Test_VGS.xyz", 28: 0.15, 30: 0.5, 32: 0.2, 34: 0.2,
+                 36: 0.2, 38: 0.2, 40: 0.2, 42: 2, 44: 0.3, 46: 10, 48: 3, 50: 3}
+        p = gpu.default_params(2)
+    else:
+        lines = {12: str(tmp_path) + "/", 15: "Town_Test.pcd", 18: str(tmp_path) + "/", 21: "Town_Test_SVGS.xyz", 28: 0.05, 30: 0.25, 32: 0.5,
+                 34: 0.2, 36: 0.2, 38: 0.2, 40: 0.2, 42: 0.2, 44: 1, 46: 0, 48: 0.25, 50: 0.75, 52: 0.5, 54: 0, 56: 0, 58: 3, 60: 3}
+        p = gpu.default_params(3)
+    task = tmp_path / "task.txt"
+    _write_task(task, method, lines)
+    out = subprocess.check_output([RUN, str(task), "--seed", "4"], text=True).split()
+    m, n, voxels, svox, clusters, kept, labelled = (int(x) for x in out)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    c = eng.counts()
+    assert (m, n, clusters, kept) == (method, c["points"], c["clusters"], c["kept"])
+    if method == 3:
+        assert svox == c["supervoxels"] and svox > 0
+    else:
+        assert voxels == c["voxels"]
+    off, idx = eng.clusters()
+    assert labelled == len(idx)
+    # the output name gets a .pcd ending (test:78 / test:163); points are listed cluster by cluster, one colour each
+    name = "Town_Test_VGS.pcd" if method == 2 else "Town_Test_SVGS.pcd"
+    f, hdr = gpu.pcd.read_pcd(tmp_path / name)
+    assert hdr["FIELDS"] == ["x", "y", "z", "rgb"] and int(hdr["POINTS"][0]) == labelled
+    got = np.stack([f["x"], f["y"], f["z"]], axis=1)
+    assert np.array_equal(got.view(np.uint32), xyz[idx].view(np.uint32))
+    rgb = f["rgb"].view(np.uint32)
+    for k in range(len(off) - 1):
+        assert len(set(rgb[off[k]:off[k + 1]].tolist())) == 1

@@ -5,6 +5,6 @@ layer: ctypes binding (_lib), the reference's class surface (api), deterministic
 the one-process-per-GPU tiling driver (dist).  The directory name contains '-', so import it through
 the repo-root shim `vgs_svgs_segmentation_amd`.
 """
-from . import _lib, scenes  # noqa: F401
+from . import _lib, pcd, scenes  # noqa: F401
 from ._lib import VgsError, VgsParams, build  # noqa: F401
 from .api import Engine, SuperVoxelBasedSegmentation, VoxelBasedSegmentation, default_params, parse_task_file, segmentation_vgs  # noqa: F401
