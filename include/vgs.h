@@ -158,6 +158,15 @@ vgs_status vgs_get_boundary(vgs_ctx* ctx, int64_t* n_records, uint64_t* code, in
 vgs_status vgs_get_owned_roots(vgs_ctx* ctx, int64_t* n_roots, int32_t* root, int32_t* owned_voxels);
 /* final labels: label[k] for local root root[k] (-1 = dropped); points of halo voxels and of unlisted roots get -1 */
 vgs_status vgs_apply_root_labels(vgs_ctx* ctx, const int32_t* root, const int32_t* label, int64_t n_roots);
+/* Compact form of the two calls above, everything but the border stays on the GPU: the boundary records without
+ * duplicates (one per boundary voxel: code, local root, number of owned voxels of that root), and the number of
+ * local components that touch no boundary record and pass the `> voxels_min` filter on their own (their labels are
+ * local_base + rank in ascending root order).  Two-call protocol: code == NULL computes and returns the counts. */
+vgs_status vgs_get_boundary_roots(vgs_ctx* ctx, int64_t* n_records, uint64_t* code, int32_t* root, int32_t* owned_voxels,
+                                  int64_t* n_kept_local);
+/* final labels of a tile: label[k] for boundary root root[k] (-1 = dropped), local_base + rank for the kept
+ * components without boundary records, -1 for everything else and for the points of halo voxels */
+vgs_status vgs_apply_tile_labels(vgs_ctx* ctx, int32_t local_base, const int32_t* root, const int32_t* label, int64_t n_roots);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,8 @@ SYMBOLS = [
     ("vgs_get_boundary", C.c_int, [_P, _P, _P, _P]),
     ("vgs_get_owned_roots", C.c_int, [_P, _P, _P, _P]),
     ("vgs_apply_root_labels", C.c_int, [_P, _P, _P, C.c_int64]),
+    ("vgs_get_boundary_roots", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("vgs_apply_tile_labels", C.c_int, [_P, C.c_int32, _P, _P, C.c_int64]),
 ]
 
 _LIB = None

@@ -142,6 +142,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
+  c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   for (int i = 0; i < 12; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

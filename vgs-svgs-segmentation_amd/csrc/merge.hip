@@ -291,6 +291,7 @@ static VgsWeightParams make_weight_params_m(const vgs_params& p) {
 
 vgs_status vgs_stage_merge(vgs_ctx* c) {
   const int64_t V = c->V, U = c->U, N = c->N;
+  c->bnd_unique = -1;  // tile protocol results belong to the previous segmentation
   c->counts[VGS_N_CLUSTERS] = 0; c->counts[VGS_N_KEPT] = 0; c->counts[VGS_N_ISOLATED] = 0; c->counts[VGS_N_REATTACHED] = 0;
   VGS_HIP_TRY(c, c->pt_label.ensure(N > 0 ? N : 1));
   if (V == 0) {

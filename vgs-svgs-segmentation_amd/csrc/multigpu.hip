@@ -8,6 +8,8 @@
 #include <cstring>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "vgs_context.hpp"
 
 __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float res_f, float min_x, float min_y, double lo_x, double lo_y,
@@ -85,6 +87,51 @@ __global__ void k_point_labels2(const uint32_t* __restrict__ perm, const uint32_
   if (j >= N) return;
   const uint32_t v = pt_vox[j];
   label[perm[j]] = (v == 0xffffffffu) ? -1 : vox_label[v];
+}
+
+// ---- compact tile protocol ----------------------------------------------------------------------------------
+__global__ void k_bnd_heads(const uint64_t* __restrict__ code_sorted, int64_t n, uint32_t* __restrict__ head) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) head[k] = (k == 0 || code_sorted[k] != code_sorted[k - 1]) ? 1u : 0u;
+}
+
+// one record per boundary voxel; marks the roots they name
+__global__ void k_bnd_compact(const uint64_t* __restrict__ code_sorted, const int32_t* __restrict__ root_sorted, const uint32_t* __restrict__ head,
+                              const uint32_t* __restrict__ scan_incl, int64_t n, const uint32_t* __restrict__ csz,
+                              uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root, int32_t* __restrict__ out_cnt,
+                              uint8_t* __restrict__ broot) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n || !head[k]) return;
+  const uint32_t pos = scan_incl[k] - 1u;
+  const int32_t r = root_sorted[k];
+  out_code[pos] = code_sorted[k];
+  out_root[pos] = r;
+  out_cnt[pos] = (int32_t)csz[r];
+  broot[r] = 1;
+}
+
+// kept components that no boundary record names: flag per voxel id (their rank = exclusive scan of the flags)
+__global__ void k_local_kept_flags(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ csz, const uint8_t* __restrict__ broot,
+                                   int64_t V, int voxels_min, uint32_t* __restrict__ flag) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  flag[v] = (parent[v] == (uint32_t)v && !broot[v] && (int)csz[v] > voxels_min) ? 1u : 0u;
+}
+
+__global__ void k_tile_root_labels(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank_excl, int64_t V, int32_t local_base,
+                                   int32_t* __restrict__ root_label) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  root_label[v] = flag[v] ? local_base + (int32_t)rank_excl[v] : -1;
+}
+
+__global__ void k_scatter_labels(const int32_t* __restrict__ root, const int32_t* __restrict__ label, int64_t n, int64_t V,
+                                 int32_t* __restrict__ root_label, unsigned int* __restrict__ bad) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int32_t r = root[k];
+  if (r < 0 || r >= V) { atomicOr(bad, 1u); return; }
+  root_label[r] = label[k];
 }
 
 extern "C" {
@@ -170,6 +217,105 @@ vgs_status vgs_get_boundary(vgs_ctx* c, int64_t* n_records, uint64_t* code, int3
   }
   c->err = "vgs_get_boundary: record buffer overflow";
   return VGS_E_NOMEM;
+}
+
+vgs_status vgs_get_boundary_roots(vgs_ctx* c, int64_t* n_records, uint64_t* code, int32_t* root, int32_t* owned_voxels, int64_t* n_kept_local) {
+  if (!c || !n_records) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED || !c->have_region) { c->err = "vgs_get_boundary_roots: segment a context with an owned region first"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t V = c->V;
+  const int TB = 256;
+  if (!code || c->bnd_unique < 0) {
+    // raw records (both endpoints of every crossing connection), then one per voxel
+    int64_t n_raw = 0;
+    vgs_status st = vgs_get_boundary(c, &n_raw, nullptr, nullptr);   // leaves the records in bnd_code / bnd_root on the device
+    if (st != VGS_OK) return st;
+    VGS_HIP_TRY(c, c->broot.ensure(V > 0 ? V : 1));
+    VGS_HIP_TRY(c, hipMemsetAsync(c->broot.p, 0, V > 0 ? V : 1, c->stream));
+    int64_t n_unique = 0;
+    if (n_raw > 0) {
+      const size_t n = (size_t)n_raw;
+      VGS_HIP_TRY(c, c->bnd_code2.ensure(2 * n)); VGS_HIP_TRY(c, c->bnd_root2.ensure(2 * n)); VGS_HIP_TRY(c, c->bnd_cnt.ensure(n));
+      VGS_HIP_TRY(c, c->head_flag.ensure(n + 1)); VGS_HIP_TRY(c, c->kept_rank.ensure(n + 1));
+      uint64_t* code_sorted = c->bnd_code2.p + n;   // second halves: sort outputs
+      int32_t* root_sorted = c->bnd_root2.p + n;
+      size_t sort_bytes = 0, scan_bytes = 0;
+      VGS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, c->bnd_code.p, code_sorted, c->bnd_root.p, root_sorted, n, 0, 64, c->stream));
+      VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->kept_rank.p, n, rocprim::plus<uint32_t>(), c->stream));
+      VGS_HIP_TRY(c, c->sort_tmp.ensure(std::max(sort_bytes, scan_bytes)));
+      VGS_HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, sort_bytes, c->bnd_code.p, code_sorted, c->bnd_root.p, root_sorted, n, 0, 64, c->stream));
+      hipLaunchKernelGGL(k_bnd_heads, dim3((unsigned)((n + TB - 1) / TB)), dim3(TB), 0, c->stream, code_sorted, (int64_t)n, c->head_flag.p);
+      VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, c->kept_rank.p, n, rocprim::plus<uint32_t>(), c->stream));
+      hipLaunchKernelGGL(k_bnd_compact, dim3((unsigned)((n + TB - 1) / TB)), dim3(TB), 0, c->stream, code_sorted, root_sorted, c->head_flag.p,
+                         c->kept_rank.p, (int64_t)n, c->csz.p, c->bnd_code2.p, c->bnd_root2.p, c->bnd_cnt.p, c->broot.p);
+      uint32_t last = 0;
+      VGS_HIP_TRY(c, hipMemcpyAsync(&last, c->kept_rank.p + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      n_unique = (int64_t)last;
+    }
+    // kept components without boundary records: flags in head_flag[0, V), exclusive ranks in kept_rank[0, V]
+    int64_t kept_local = 0;
+    if (V > 0) {
+      VGS_HIP_TRY(c, c->head_flag.ensure(V + 1)); VGS_HIP_TRY(c, c->kept_rank.ensure(V + 1));
+      hipLaunchKernelGGL(k_local_kept_flags, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p, c->csz.p, c->broot.p, V,
+                         c->P.voxels_min, c->head_flag.p);
+      size_t scan_bytes = 0;
+      VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+      VGS_HIP_TRY(c, c->sort_tmp.ensure(scan_bytes));
+      VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+      uint32_t last_rank = 0, last_flag = 0;
+      VGS_HIP_TRY(c, hipMemcpyAsync(&last_rank, c->kept_rank.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      VGS_HIP_TRY(c, hipMemcpyAsync(&last_flag, c->head_flag.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      kept_local = (int64_t)last_rank + last_flag;
+    }
+    VGS_HIP_TRY(c, hipGetLastError());
+    c->bnd_unique = n_unique;
+    c->bnd_kept_local = kept_local;
+  }
+  *n_records = c->bnd_unique;
+  if (n_kept_local) *n_kept_local = c->bnd_kept_local;
+  const size_t n = (size_t)c->bnd_unique;
+  if (code && n) VGS_HIP_TRY(c, hipMemcpy(code, c->bnd_code2.p, n * 8, hipMemcpyDeviceToHost));
+  if (root && n) VGS_HIP_TRY(c, hipMemcpy(root, c->bnd_root2.p, n * 4, hipMemcpyDeviceToHost));
+  if (owned_voxels && n) VGS_HIP_TRY(c, hipMemcpy(owned_voxels, c->bnd_cnt.p, n * 4, hipMemcpyDeviceToHost));
+  return VGS_OK;
+}
+
+vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* root, const int32_t* label, int64_t n_roots) {
+  if (!c || (n_roots > 0 && (!root || !label))) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED || c->bnd_unique < 0) { c->err = "vgs_apply_tile_labels: vgs_get_boundary_roots first"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t V = c->V, N = c->N;
+  if (V == 0) return VGS_OK;
+  const int TB = 256;
+  VGS_HIP_TRY(c, c->root_label.ensure(V));
+  hipLaunchKernelGGL(k_tile_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->head_flag.p, c->kept_rank.p, V, local_base,
+                     c->root_label.p);
+  if (n_roots > 0) {
+    // labels of the boundary roots: small upload, scattered on the device
+    VGS_HIP_TRY(c, c->bnd_root2.ensure(2 * (size_t)n_roots + 2)); VGS_HIP_TRY(c, c->counters.ensure(64));
+    int32_t* d_root = c->bnd_root2.p;
+    int32_t* d_label = c->bnd_root2.p + n_roots;
+    unsigned int* d_bad = (unsigned int*)(c->counters.p + 33);
+    VGS_HIP_TRY(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    VGS_HIP_TRY(c, hipMemcpyAsync(d_root, root, (size_t)n_roots * 4, hipMemcpyHostToDevice, c->stream));
+    VGS_HIP_TRY(c, hipMemcpyAsync(d_label, label, (size_t)n_roots * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scatter_labels, dim3((unsigned)((n_roots + TB - 1) / TB)), dim3(TB), 0, c->stream, d_root, d_label, n_roots, V,
+                       c->root_label.p, d_bad);
+    unsigned int bad = 0;
+    VGS_HIP_TRY(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) { c->err = "vgs_apply_tile_labels: root out of range"; return VGS_E_ARG; }
+  }
+  hipLaunchKernelGGL(k_apply_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p,
+                     c->have_region ? c->owned.p : nullptr, c->root_label.p, V, c->vox_label.p);
+  hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
+                     c->pt_label.p);
+  VGS_HIP_TRY(c, hipGetLastError());
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->bnd_unique = -1;  // bnd_root2 was reused
+  return VGS_OK;
 }
 
 vgs_status vgs_get_owned_roots(vgs_ctx* c, int64_t* n_roots, int32_t* root, int32_t* owned_voxels) {

@@ -165,6 +165,10 @@ struct vgs_ctx {
   DevBuf<uint64_t> bnd_code;    // boundary records
   DevBuf<int32_t> bnd_root;
   DevBuf<int32_t> root_label;   // per voxel id: label of the component rooted there
+  DevBuf<uint64_t> bnd_code2;   // compact protocol: unique boundary voxels (code, root, owned count of the root)
+  DevBuf<int32_t> bnd_root2, bnd_cnt;
+  DevBuf<uint8_t> broot;        // per voxel id: 1 = root named by a boundary record
+  int64_t bnd_unique = -1, bnd_kept_local = 0;  // results of the last vgs_get_boundary_roots (-1 = not computed)
 };
 
 #define VGS_HIP_TRY(ctx, expr)                                                                       \

@@ -88,6 +88,61 @@ def merge_boundary(records, roots, voxels_min):
     return labels, int(kept_ids.size)
 
 
+def merge_boundary_compact(records, kept_local, voxels_min):
+    """Global segments from the compact per-rank results (vgs_get_boundary_roots).
+
+    records[r] = (codes uint64[], local_roots int32[], owned_counts int32[]): one entry per boundary voxel of rank r,
+    with the number of owned voxels of the local component it belongs to.  kept_local[r] = number of components of
+    rank r that touch no boundary voxel and pass the size filter on their own (labelled on the GPU as
+    base[r] + rank).  Returns (base[r] for every rank, per-rank (unique local roots, labels) of the boundary
+    components, total number of kept segments).  Only the border leaves the GPUs: the work here is O(boundary voxels).
+    Deterministic: every rank computes the same tables from the same gathered inputs.
+    """
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    world = len(records)
+    kept_local = np.asarray(kept_local, dtype=np.int64)
+    base = np.concatenate([[0], np.cumsum(kept_local)[:-1]]).astype(np.int64) if world else np.zeros(0, np.int64)
+    next_label = int(kept_local.sum())
+    node_id, node_cnt, rec_code, rec_node = [], [], [], []
+    offset = 0
+    per_rank = []
+    for r in range(world):
+        code, root, cnt = records[r]
+        uroot, first, inv = np.unique(root, return_index=True, return_inverse=True)
+        per_rank.append((uroot.astype(np.int32), offset))
+        node_cnt.append(cnt[first].astype(np.int64))
+        rec_code.append(code.astype(np.uint64))
+        rec_node.append(inv.astype(np.int64) + offset)
+        offset += uroot.size
+    n = offset
+    if n == 0:
+        return base, [(np.zeros(0, np.int32), np.zeros(0, np.int32)) for _ in range(world)], next_label
+    node_cnt = np.concatenate(node_cnt)
+    rec_code = np.concatenate(rec_code)
+    rec_node = np.concatenate(rec_node)
+    order = np.argsort(rec_code, kind="stable")
+    c_sorted, p_sorted = rec_code[order], rec_node[order]
+    same = c_sorted[1:] == c_sorted[:-1]
+    a, b = p_sorted[:-1][same], p_sorted[1:][same]
+    g = coo_matrix((np.ones(a.size, dtype=np.int8), (a, b)), shape=(n, n))
+    ncomp, comp = connected_components(g, directed=False)
+    total = np.bincount(comp, weights=node_cnt, minlength=ncomp).astype(np.int64)
+    keep = total > voxels_min
+    # dense labels after the local ones, in order of the first node of each kept component
+    first_node = np.full(ncomp, n, dtype=np.int64)
+    np.minimum.at(first_node, comp, np.arange(n))
+    kept_ids = np.nonzero(keep)[0]
+    label_of = np.full(ncomp, -1, dtype=np.int64)
+    label_of[kept_ids[np.argsort(first_node[kept_ids], kind="stable")]] = next_label + np.arange(kept_ids.size)
+    out = []
+    for r in range(world):
+        uroot, off = per_rank[r]
+        out.append((uroot, label_of[comp[off:off + uroot.size]].astype(np.int32)))
+    return base, out, next_label + int(kept_ids.size)
+
+
 def all_gather_varlen(dist, arr, device=None):
     """all_gather of 1-D numpy arrays of different lengths (one size exchange + one padded payload exchange)."""
     import torch
@@ -181,33 +236,45 @@ class TiledSegmenter:
         self.engine._ck(L.vgs_set_grid(self.engine._h, C.byref(g)))
 
     def run(self):
+        import os, time
+        dbg = bool(os.environ.get("VGS_DEBUG")) and self.rank == 0
+        tt = [time.perf_counter()]
+        def mark(name):
+            if dbg:
+                tt.append(time.perf_counter())
+                print(f"[tiles] {name} {1e3 * (tt[-1] - tt[-2]):.2f} ms", flush=True)
         eng, L = self.engine, self.engine._L
         self._chain_grid()
+        mark("grid chain")
         eng.voxelize(); eng.features(); eng.adjacency(); eng.segment()
-        n = C.c_int64(0)
-        eng._ck(L.vgs_get_boundary(eng._h, C.byref(n), None, None))
-        code = np.zeros(max(n.value, 1), dtype=np.uint64)
-        root = np.zeros(max(n.value, 1), dtype=np.int32)
+        mark("four stages")
+        # only the border leaves the GPU: unique boundary voxels (code, local root, owned voxels of that root) and the
+        # number of components that are local to this tile
+        n, nkl = C.c_int64(0), C.c_int64(0)
+        eng._ck(L.vgs_get_boundary_roots(eng._h, C.byref(n), None, None, None, C.byref(nkl)))
+        rec = np.zeros((3, max(n.value, 1)), dtype=np.int64)
         if n.value:
-            eng._ck(L.vgs_get_boundary(eng._h, C.byref(n), _ptr(code), _ptr(root)))
-        code, root = code[: n.value], root[: n.value]
-        nr = C.c_int64(0)
-        eng._ck(L.vgs_get_owned_roots(eng._h, C.byref(nr), None, None))
-        rt = np.zeros(max(nr.value, 1), dtype=np.int32)
-        oc = np.zeros(max(nr.value, 1), dtype=np.int32)
-        if nr.value:
-            eng._ck(L.vgs_get_owned_roots(eng._h, C.byref(nr), _ptr(rt), _ptr(oc)))
-        rt, oc = rt[: nr.value], oc[: nr.value]
-        # the one data-path collective: boundary records + per-root owned counts of every rank
-        codes = all_gather_varlen(self.dist, code.view(np.int64), self.coll_device)
-        rroots = all_gather_varlen(self.dist, root, self.coll_device)
-        allrt = all_gather_varlen(self.dist, rt, self.coll_device)
-        alloc = all_gather_varlen(self.dist, oc, self.coll_device)
-        records = [(c.view(np.uint64), r) for c, r in zip(codes, rroots)]
-        roots = list(zip(allrt, alloc))
-        labels, self.kept = merge_boundary(records, roots, self.p.voxels_min)
-        mine = np.ascontiguousarray(labels[self.rank])
-        eng._ck(L.vgs_apply_root_labels(eng._h, _ptr(np.ascontiguousarray(rt)), _ptr(mine), rt.size))
+            code = np.zeros(n.value, dtype=np.uint64)
+            root = np.zeros(n.value, dtype=np.int32)
+            cnt = np.zeros(n.value, dtype=np.int32)
+            eng._ck(L.vgs_get_boundary_roots(eng._h, C.byref(n), _ptr(code), _ptr(root), _ptr(cnt), C.byref(nkl)))
+            rec[0, :n.value] = code.view(np.int64); rec[1, :n.value] = root; rec[2, :n.value] = cnt
+        mark(f"boundary download ({n.value} boundary voxels, {nkl.value} local segments)")
+        # the one data-path exchange: a fixed-size header (record count, local segment count) and the records
+        payload = np.concatenate([[n.value, nkl.value], rec[:, :n.value].reshape(-1)]).astype(np.int64)
+        gathered = all_gather_varlen(self.dist, payload, self.coll_device)
+        mark("all-gather")
+        records, kept_local = [], []
+        for g in gathered:
+            m = int(g[0]); kept_local.append(int(g[1]))
+            body = g[2:2 + 3 * m].reshape(3, m)
+            records.append((body[0].view(np.uint64), body[1].astype(np.int32), body[2].astype(np.int32)))
+        base, blabels, self.kept = merge_boundary_compact(records, kept_local, self.p.voxels_min)
+        mark("merge_boundary")
+        broot, blab = blabels[self.rank]
+        eng._ck(L.vgs_apply_tile_labels(eng._h, int(base[self.rank]), _ptr(np.ascontiguousarray(broot)), _ptr(np.ascontiguousarray(blab)),
+                                        broot.size))
+        mark("apply labels")
 
     def point_labels(self):
         """Labels of this rank's own points (halo points belong to other ranks)."""
