@@ -36,19 +36,34 @@ def _worker(rank, world, path, port, out_path):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import vgs_svgs_segmentation_amd as v
-    from vgs_svgs_segmentation_amd.dist import all_gather_varlen, merge_boundary, tile_regions
+    from vgs_svgs_segmentation_amd.dist import all_gather_varlen, merge_boundary_compact, tile_regions
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     d = np.load(path)
     regions = tile_regions((world, 1), float(d["pitch"]))
     owned, root, rec, roots = _emulate_rank(rank, regions, d["centers"], d["used"], d["off"], d["idx"], int(d["voxels_min"]))
-    codes = all_gather_varlen(dist, rec[0].view(np.int64))
-    rroots = all_gather_varlen(dist, rec[1])
-    allrt = all_gather_varlen(dist, roots[0])
-    alloc = all_gather_varlen(dist, roots[1])
-    labels, kept = merge_boundary([(c.view(np.uint64), r) for c, r in zip(codes, rroots)], list(zip(allrt, alloc)), int(d["voxels_min"]))
-    lab_of_root = dict(zip(roots[0].tolist(), labels[rank].tolist()))
+    # the compact protocol of TiledSegmenter.run: unique boundary voxels (code, root, owned voxels of the root), the
+    # number of kept local segments, ONE packed all-gather, the O(boundary) merge, labels = base + rank for the rest
+    vmin = int(d["voxels_min"])
+    ucode, first = np.unique(rec[0], return_index=True)
+    broot = rec[1][first]
+    cnt_of = dict(zip(roots[0].tolist(), roots[1].tolist()))
+    bcnt = np.array([cnt_of.get(int(x), 0) for x in broot], dtype=np.int64)
+    is_b = np.isin(roots[0], broot)
+    local_kept = (~is_b) & (roots[1] > vmin)
+    payload = np.concatenate([[ucode.size, int(local_kept.sum())], ucode.view(np.int64), broot.astype(np.int64), bcnt]).astype(np.int64)
+    gathered = all_gather_varlen(dist, payload)
+    records, kept_local = [], []
+    for g in gathered:
+        m = int(g[0]); kept_local.append(int(g[1]))
+        body = g[2:2 + 3 * m].reshape(3, m)
+        records.append((body[0].view(np.uint64), body[1].astype(np.int32), body[2].astype(np.int32)))
+    base, blabels, kept = merge_boundary_compact(records, kept_local, vmin)
+    lab = np.full(roots[0].size, -1, dtype=np.int64)
+    lab[local_kept] = base[rank] + np.arange(int(local_kept.sum()))
+    lab[np.searchsorted(roots[0], blabels[rank][0])] = blabels[rank][1]
+    lab_of_root = dict(zip(roots[0].tolist(), lab.tolist()))
     vox_label = np.array([lab_of_root[int(x)] if o else -2 for x, o in zip(root, owned)], dtype=np.int64)
     np.savez(out_path % rank, vox_label=vox_label, kept=kept)
     dist.barrier()
@@ -101,3 +116,47 @@ def test_merge_boundary_small_example(vgs):
     labels, kept = merge_boundary([rec0, rec1], [roots0, roots1], voxels_min=3)
     assert kept == 1
     assert labels[0].tolist() == [0, -1] and labels[1].tolist() == [-1, 0]   # 10+3 kept, 2+1 dropped
+
+
+def test_compact_merge_equals_full_merge():
+    """merge_boundary_compact (only boundary voxels leave the GPU, local segments are labelled on the device as
+    base + rank) gives the same partition and the same kept count as merge_boundary over all roots."""
+    from vgs_svgs_segmentation_amd.dist import merge_boundary, merge_boundary_compact
+    rng = np.random.default_rng(5)
+    world, vmin = 3, 3
+    for trial in range(20):
+        roots, full_records, compact_records, kept_local, local_sets = [], [], [], [], []
+        n_codes = 40
+        for r in range(world):
+            nr = int(rng.integers(5, 30))
+            rt = np.sort(rng.choice(1000, nr, replace=False)).astype(np.int32)
+            oc = rng.integers(0, 6, nr).astype(np.int32)
+            roots.append((rt, oc))
+            # boundary voxels of this rank: a random subset of shared codes, each belonging to one of its roots
+            nb = int(rng.integers(0, 15))
+            codes = rng.choice(n_codes, nb, replace=False).astype(np.uint64)
+            broots = rt[rng.integers(0, nr, nb)]
+            dup = rng.integers(0, nb, 2 * nb) if nb else np.zeros(0, np.int64)      # the full protocol repeats records
+            full_records.append((np.concatenate([codes, codes[dup]]), np.concatenate([broots, broots[dup]]).astype(np.int32)))
+            cnt = oc[np.searchsorted(rt, broots)]
+            compact_records.append((codes, broots.astype(np.int32), cnt.astype(np.int32)))
+            is_b = np.isin(rt, broots)
+            loc = (~is_b) & (oc > vmin)
+            kept_local.append(int(loc.sum()))
+            local_sets.append(loc)
+        old_labels, old_kept = merge_boundary(full_records, roots, vmin)
+        base, blabels, new_kept = merge_boundary_compact(compact_records, kept_local, vmin)
+        assert new_kept == old_kept
+        new_labels = []
+        for r in range(world):
+            rt, _ = roots[r]
+            lab = np.full(rt.size, -1, dtype=np.int64)
+            lab[local_sets[r]] = base[r] + np.arange(kept_local[r])          # what vgs_apply_tile_labels does on the device
+            ur, ul = blabels[r]
+            lab[np.searchsorted(rt, ur)] = ul
+            new_labels.append(lab)
+        a, b = np.concatenate(old_labels), np.concatenate(new_labels)
+        assert np.array_equal(a < 0, b < 0)
+        # same partition: the label pairs are a bijection
+        pairs = set(zip(a[a >= 0].tolist(), b[b >= 0].tolist()))
+        assert len(pairs) == len({x for x, _ in pairs}) == len({y for _, y in pairs})
