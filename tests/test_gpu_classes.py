@@ -1,0 +1,63 @@
+"""Parity of the large-neighbourhood classes of the local cut, which the default scenes hardly reach: class C (129..512
+neighbours, one wavefront per voxel with 16-bit indices and a 2048-edge list) and class D (> 512 neighbours, the
+workgroup-per-voxel kernel), plus the hand-over paths.  Same bar as tests/test_gpu_parity.py: connect lists and labels
+identical to the oracle in DevMath + lean flavour."""
+import numpy as np
+import pytest
+
+from helpers import canonical_labels, oracle_params, ragged_sets
+
+pytestmark = pytest.mark.gpu
+
+
+def _slab(n, size, thick, seed):
+    """points filling a slab of the given thickness: every voxel has neighbours in several layers"""
+    rng = np.random.default_rng(seed)
+    xyz = np.empty((n, 3), dtype=np.float64)
+    xyz[:, 0] = rng.uniform(-size / 2, size / 2, n)
+    xyz[:, 1] = rng.uniform(-size / 2, size / 2, n)
+    xyz[:, 2] = 1.0 + rng.uniform(0, thick, n) + 0.01 * np.sin(7.0 * xyz[:, 0])
+    return xyz.astype(np.float32)
+
+
+CASES = [
+    # name, cloud factory, parameters, expected class counts (a, b+c, d) predicate
+    ("plane_r10", lambda v: v.scenes.pc_scene(40_000), dict(voxel_size=0.05, graph_size=0.5), lambda a, bc, d: bc > 1000),
+    ("slab_r10", lambda v: _slab(60_000, 0.85, 0.11, 7), dict(voxel_size=0.05, graph_size=0.5), lambda a, bc, d: d > 100),
+    ("slab_r6", lambda v: _slab(120_000, 2.0, 0.25, 8), dict(voxel_size=0.08, graph_size=0.5), lambda a, bc, d: bc > 300),
+]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def run(request, gpu, oracle):
+    name, make, kw, pred = request.param
+    xyz = make(gpu)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    return dict(name=name, eng=eng, ref=ref, pred=pred)
+
+
+def test_case_reaches_the_class(run):
+    c = run["eng"].counts()
+    assert run["pred"](c["class_a"], c["class_bc"], c["class_d"]), c
+
+
+@pytest.mark.parametrize("which", ["connect_cut", "connect_final"])
+def test_connect_lists_exact(run, which):
+    off, idx = run["eng"].lists(which)
+    roff, ridx = run["ref"].lists(which)
+    assert np.array_equal(off, roff)
+    assert ragged_sets(off, idx) == ragged_sets(roff, ridx)
+
+
+def test_labels_identical(run):
+    eng, ref = run["eng"], run["ref"]
+    c = eng.counts()
+    assert c["clusters"] == ref.clusters_num and c["kept"] == ref.kept_clusters
+    pl_ref, nc_ref = ref.labels()
+    root, _ = eng.node_labels()
+    np.testing.assert_array_equal(canonical_labels(root), canonical_labels(nc_ref))
+    np.testing.assert_array_equal(eng.point_labels(), pl_ref)

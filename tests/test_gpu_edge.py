@@ -1,0 +1,106 @@
+"""Edge cases of the hot path against the oracle: empty and degenerate clouds, non-finite points, padded points,
+clouds far from the origin whose bounding box grows in every direction, and the documented limits."""
+import numpy as np
+import pytest
+
+from helpers import canonical_labels, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(gpu, oracle, xyz, **kw):
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    ref = oracle.run_vgs(np.ascontiguousarray(xyz[:, :3]), oracle_params(oracle, p))
+    return eng, ref
+
+
+def _same(eng, ref):
+    c = eng.counts()
+    assert (c["voxels"], c["clusters"], c["kept"]) == (ref.V, ref.clusters_num, ref.kept_clusters)
+    pl_ref, nc_ref = ref.labels()
+    np.testing.assert_array_equal(eng.point_labels(), pl_ref)
+    root, _ = eng.node_labels()
+    np.testing.assert_array_equal(canonical_labels(root), canonical_labels(nc_ref))
+
+
+def test_empty_cloud(gpu):
+    eng = gpu.Engine(gpu.default_params(2))
+    eng.set_points(np.zeros((0, 3), np.float32))
+    eng.run()
+    c = eng.counts()
+    assert (c["points"], c["voxels"], c["clusters"], c["kept"]) == (0, 0, 0, 0)
+    assert eng.point_labels().size == 0
+
+
+def test_only_non_finite_points(gpu):
+    xyz = np.full((100, 3), np.nan, np.float32)
+    xyz[::3, 1] = np.inf
+    eng = gpu.Engine(gpu.default_params(2))
+    eng.set_points(xyz)
+    eng.run()
+    c = eng.counts()
+    assert (c["points"], c["finite"], c["voxels"], c["kept"]) == (100, 0, 0, 0)
+    assert (eng.point_labels() == -1).all()
+
+
+@pytest.mark.parametrize("n", [1, 5, 11, 40])
+def test_tiny_clouds(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    xyz = (rng.standard_normal((n, 3)) * 0.05 + np.array([2.0, -1.0, 0.5])).astype(np.float32)
+    _same(*_both(gpu, oracle, xyz))
+
+
+def test_duplicate_points_and_sparse_voxels(gpu, oracle):
+    rng = np.random.default_rng(9)
+    base = (rng.standard_normal((300, 3)) * np.array([3.0, 3.0, 0.02])).astype(np.float32)
+    xyz = np.concatenate([base, base[:150], base[:150], np.tile(base[:1], (50, 1))])   # repeated points, one voxel with 50 copies
+    _same(*_both(gpu, oracle, xyz))
+
+
+def test_non_finite_points_are_skipped(gpu, oracle):
+    xyz = gpu.scenes.town_scene(30_000).copy()
+    xyz[::97, 0] = np.nan
+    xyz[5::211, 2] = np.inf
+    xyz[0] = np.nan                       # the first point defines the octree box: here the first FINITE one does
+    eng, ref = _both(gpu, oracle, xyz)
+    _same(eng, ref)
+    bad = ~np.isfinite(xyz).all(axis=1)
+    assert (eng.point_labels()[bad] == -1).all() and eng.counts()["finite"] == int((~bad).sum())
+
+
+def test_padded_points_give_the_same_result(gpu):
+    xyz = gpu.scenes.town_scene(40_000)
+    a = gpu.Engine(gpu.default_params(2)); a.set_points(xyz); a.run()
+    xyz4 = np.concatenate([xyz, np.ones((xyz.shape[0], 1), np.float32)], axis=1)      # pcl::PointXYZ: 16-byte points
+    b = gpu.Engine(gpu.default_params(2)); b.set_points(xyz4); b.run()
+    np.testing.assert_array_equal(a.point_labels(), b.point_labels())
+
+
+@pytest.mark.parametrize("shift", [(-140.0, 120.0, 3.0), (149.0, -149.0, -2.0)])
+def test_far_from_origin_and_growth_in_all_directions(gpu, oracle, shift):
+    xyz = gpu.scenes.town_scene(40_000).copy()
+    rng = np.random.default_rng(4)
+    xyz = xyz[rng.permutation(xyz.shape[0])]      # the box grows towards every side as points arrive
+    xyz += np.array(shift, np.float32)
+    eng, ref = _both(gpu, oracle, xyz)
+    t, rt = eng.voxel_table(), ref.voxel_table()
+    assert np.array_equal(t["key"], rt["key"]) and np.array_equal(t["start"], rt["start"])
+    _same(eng, ref)
+
+
+def test_limits_are_reported_not_silently_wrong(gpu):
+    xyz = gpu.scenes.town_scene(5_000)
+    rng = np.random.default_rng(1)
+    dense = (rng.uniform(0, 1, (20_000, 3)) * np.array([0.3, 0.3, 0.04])).astype(np.float32)   # 44 points per 0.02 m voxel
+    eng = gpu.Engine(gpu.default_params(2, voxel_size=0.02, graph_size=0.5))          # ball of radius 25 voxels > 8192 offsets
+    eng.set_points(dense)
+    with pytest.raises(gpu.VgsError) as e:
+        eng.run()
+    assert "UNSUPPORTED" in str(e.value)
+    far = xyz.copy(); far[-1] = (3.0e6, 0, 0)                                         # octree depth would exceed 21 at 0.15 m
+    eng2 = gpu.Engine(gpu.default_params(2)); eng2.set_points(far)
+    with pytest.raises(gpu.VgsError):
+        eng2.run()
