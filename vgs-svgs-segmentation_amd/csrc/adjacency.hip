@@ -27,14 +27,22 @@
 // 10 M points) was served from the fabric, and the used flag no longer costs a 64-byte node read per neighbour.
 struct Brick { unsigned long long key; unsigned long long occ; unsigned long long used; uint32_t first; uint32_t pad; };
 
-__device__ __forceinline__ uint32_t hash_slot(uint64_t code, uint32_t hbits) {
-  return (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> (64 - hbits));
+// the packed brick coordinates are highly regular: fold the three fields with odd multipliers before the final multiply
+__device__ __forceinline__ uint32_t hash_slot(uint64_t key, uint32_t hbits) {
+  const uint32_t bx = (uint32_t)key & 0x1fffffu, by = (uint32_t)(key >> 21) & 0x1fffffu, bz = (uint32_t)(key >> 42);
+  uint32_t h = bx * 0x9E3779B1u + by * 0x85EBCA77u + bz * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  return (h * 0x2C1B3C6Du) >> (32 - hbits);
 }
 
-__global__ void k_brick_heads(const uint64_t* __restrict__ vox_code, int64_t V, uint32_t* __restrict__ head) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  head[v] = (v == 0 || (vox_code[v - 1] >> 6) != (vox_code[v] >> 6)) ? 1u : 0u;
+// A brick is named by its lattice coordinates (voxel key >> 2 per axis) packed 21 bits each, + 1 so that 0 means empty;
+// a voxel's bit inside the brick is the low 6 bits of its Morton code (z0 y0 x0 z1 y1 x1 from bit 0).  Both are cheap
+// to form from (nx, ny, nz): the neighbour search never spreads a full Morton code.
+__device__ __forceinline__ unsigned long long brick_key(uint32_t nx, uint32_t ny, uint32_t nz) {
+  return (((unsigned long long)(nz >> 2) << 42) | ((unsigned long long)(ny >> 2) << 21) | (unsigned long long)(nx >> 2)) + 1ull;
+}
+__device__ __forceinline__ int brick_local(uint32_t nx, uint32_t ny, uint32_t nz) {
+  return (int)((nz & 1u) | ((ny & 1u) << 1) | ((nx & 1u) << 2) | ((nz & 2u) << 2) | ((ny & 2u) << 3) | ((nx & 2u) << 4));
 }
 
 // every voxel finds (or creates) its brick's slot and ORs its bits in; the brick's first voxel is the smallest id
@@ -43,8 +51,8 @@ __global__ void k_brick_insert(const uint64_t* __restrict__ vox_code, const Node
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t code = vox_code[v];
-  const unsigned long long key = (code >> 6) + 1ull;  // 0 = empty
-  const unsigned long long bit = 1ull << (code & 63ull);
+  const unsigned long long key = brick_key(vm_compact21(code >> 2), vm_compact21(code >> 1), vm_compact21(code));  // 0 = empty
+  const unsigned long long bit = 1ull << (code & 63ull);  // == brick_local of the same coordinates
   const uint32_t mask = (1u << hbits) - 1u;
   uint32_t s = hash_slot(key, hbits);
   while (true) {
@@ -58,8 +66,8 @@ __global__ void k_brick_insert(const uint64_t* __restrict__ vox_code, const Node
 }
 
 // voxel id in lattice cell (nx, ny, nz), -1 if empty; *is_used tells whether that voxel has > points_min points
-__device__ __forceinline__ int brick_find(const Brick* __restrict__ table, uint32_t hbits, uint64_t code, bool* is_used) {
-  const unsigned long long key = (code >> 6) + 1ull;
+__device__ __forceinline__ int brick_find(const Brick* __restrict__ table, uint32_t hbits, uint32_t nx, uint32_t ny, uint32_t nz, bool* is_used) {
+  const unsigned long long key = brick_key(nx, ny, nz);
   const uint32_t mask = (1u << hbits) - 1u;
   uint32_t s = hash_slot(key, hbits);
   while (true) {
@@ -69,7 +77,7 @@ __device__ __forceinline__ int brick_find(const Brick* __restrict__ table, uint3
     s = (s + 1) & mask;
   }
   const unsigned long long occ = table[s].occ;
-  const int local = (int)(code & 63ull);
+  const int local = brick_local(nx, ny, nz);
   if (!((occ >> local) & 1ull)) return -1;
   *is_used = ((table[s].used >> local) & 1ull) != 0;
   const unsigned long long above = (local == 63) ? 0ull : (occ >> (local + 1));
@@ -80,12 +88,13 @@ __device__ __forceinline__ int brick_find(const Brick* __restrict__ table, uint3
 template <int CAP, bool FULL>
 __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids,
                                                   int64_t U, const Brick* __restrict__ bricks,
-                                                  uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int depth,
+                                                  uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int R, int depth,
                                                   float res_f, float min_x, float min_y, float min_z, float r2,
                                                   const NodeRec* __restrict__ node, int adj_stride,
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                   uint32_t* __restrict__ adj_mused) {
   __shared__ uint64_t lst[CAP];
+  __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
   const int lane = threadIdx.x;
   const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
@@ -94,6 +103,12 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
   const float cx = vm_voxel_center(kx, res_f, min_x), cy = vm_voxel_center(ky, res_f, min_y), cz = vm_voxel_center(kz, res_f, min_z);
   const uint32_t lim = 1u << depth;
+  if (lane < 2 * R + 1) {  // keys that wrap below 0 give a meaningless centre, but such cells fail the range test
+    ctab[0][lane] = vm_voxel_center(kx + (uint32_t)(lane - R), res_f, min_x);
+    ctab[1][lane] = vm_voxel_center(ky + (uint32_t)(lane - R), res_f, min_y);
+    ctab[2][lane] = vm_voxel_center(kz + (uint32_t)(lane - R), res_f, min_z);
+  }
+  __syncthreads();
   int cnt = 0, mused = 0;
   for (int base = 0; base < n_off; base += 64) {
     const int o = base + lane;
@@ -105,11 +120,11 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
       const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
       const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;  // wraps past 0 fail the range test
       if (nx < lim && ny < lim && nz < lim) {
-        const int t = brick_find(bricks, hbits, vm_morton(nx, ny, nz), &is_used);
+        const int t = brick_find(bricks, hbits, nx, ny, nz, &is_used);
         if (t >= 0) {
-          const float tx = cx - vm_voxel_center(nx, res_f, min_x);
-          const float ty = cy - vm_voxel_center(ny, res_f, min_y);
-          const float tz = cz - vm_voxel_center(nz, res_f, min_z);
+          const float tx = cx - ctab[0][dx + R];
+          const float ty = cy - ctab[1][dy + R];
+          const float tz = cz - ctab[2][dz + R];
           const float d2 = (tx * tx + ty * ty) + tz * tz;
           if (d2 < r2) {
             keep = true;
@@ -192,6 +207,7 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
       }
   std::sort(offs.begin(), offs.end());
   c->n_off = (int)offs.size();
+  c->adj_R = R;
   std::vector<int32_t> packed(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
@@ -207,8 +223,9 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
 #define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
   hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
-                     (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
+                     (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall)
+  if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
   if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }
   else if (c->n_off <= 8192) { if (full) LAUNCH_ADJ(8192, true); else LAUNCH_ADJ(8192, false); }
   else { c->err = "neighbour ball larger than 8192 lattice offsets (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }

@@ -122,6 +122,7 @@ struct vgs_ctx {
   uint32_t hbits = 0;
   DevBuf<int32_t> offsets;  // packed dx,dy,dz
   int n_off = 0;
+  int adj_R = 0;   // largest |offset| per axis of the ball table
   int adj_stride = 0;
   DevBuf<uint64_t> adj_key;
   DevBuf<uint32_t> adj_cnt, adj_mused;  // per used voxel: stored row length, number of ALL neighbours
