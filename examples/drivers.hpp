@@ -17,19 +17,11 @@ inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>&
   float voxel_size = 0.15f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f, sig_w = 2.0f,
         cut_thred = 0.3f;
   int points_min = 10, adjacency_min = 3, voxels_min = 3;
-  if (input_vector.size() > 50) {  // test:25-37
-    voxel_size = (float)std::atof(input_vector[28].c_str());
-    graph_size = (float)std::atof(input_vector[30].c_str());
-    sig_p = (float)std::atof(input_vector[32].c_str());
-    sig_n = (float)std::atof(input_vector[34].c_str());
-    sig_o = (float)std::atof(input_vector[36].c_str());
-    sig_e = (float)std::atof(input_vector[38].c_str());
-    sig_c = (float)std::atof(input_vector[40].c_str());
-    sig_w = (float)std::atof(input_vector[42].c_str());
-    cut_thred = (float)std::atof(input_vector[44].c_str());
-    points_min = std::atoi(input_vector[46].c_str());
-    adjacency_min = std::atoi(input_vector[48].c_str());
-    voxels_min = std::atoi(input_vector[50].c_str());
+  if (input_vector.size() > 50) {  // the twelve numbers sit on every second line from 28 on (test:25-37)
+    auto num = [&](size_t line) { return std::atof(input_vector[line].c_str()); };
+    float* const f[] = {&voxel_size, &graph_size, &sig_p, &sig_n, &sig_o, &sig_e, &sig_c, &sig_w, &cut_thred};
+    for (size_t k = 0; k < 9; ++k) *f[k] = (float)num(28 + 2 * k);
+    points_min = (int)num(46); adjacency_min = (int)num(48); voxels_min = (int)num(50);
   }
   double min_x = 0, min_y = 0, min_z = 0, max_x = 0, max_y = 0, max_z = 0;
 
@@ -68,23 +60,13 @@ inline int segmentationSVGS(PCXYZPtr input_cloud, const std::vector<std::string>
   float voxel_size = 0.05f, seed_size = 0.25f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f,
         sig_w = 1.0f, sig_a = 0.0f, sig_b = 0.25f, cut_thred = 0.5f;
   int points_min = 0, voxels_min = 3, adjacency_min = 3;
-  if (input_vector.size() > 60) {  // test:108-125
-    voxel_size = (float)std::atof(input_vector[28].c_str());
-    seed_size = (float)std::atof(input_vector[30].c_str());
-    graph_size = (float)std::atof(input_vector[32].c_str());
-    sig_p = (float)std::atof(input_vector[34].c_str());
-    sig_n = (float)std::atof(input_vector[36].c_str());
-    sig_o = (float)std::atof(input_vector[38].c_str());
-    sig_e = (float)std::atof(input_vector[40].c_str());
-    sig_c = (float)std::atof(input_vector[42].c_str());
-    sig_w = (float)std::atof(input_vector[44].c_str());
-    sig_a = (float)std::atof(input_vector[46].c_str());
-    sig_b = (float)std::atof(input_vector[48].c_str());
-    sig_c = (float)std::atof(input_vector[50].c_str());  // the reference reuses sig_c for the normal importance (test:120)
-    cut_thred = (float)std::atof(input_vector[52].c_str());
-    points_min = (int)std::atof(input_vector[54].c_str());
-    voxels_min = std::atoi(input_vector[58].c_str());
-    adjacency_min = std::atoi(input_vector[60].c_str());
+  if (input_vector.size() > 60) {  // every second line from 28 on (test:108-125)
+    auto num = [&](size_t line) { return std::atof(input_vector[line].c_str()); };
+    float* const f[] = {&voxel_size, &seed_size, &graph_size, &sig_p, &sig_n, &sig_o, &sig_e, &sig_c, &sig_w, &sig_a, &sig_b};
+    for (size_t k = 0; k < 11; ++k) *f[k] = (float)num(28 + 2 * k);
+    sig_c = (float)num(50);  // the reference reuses sig_c for the normal importance (test:120): the convexity sigma of line 42 is lost
+    cut_thred = (float)num(52);
+    points_min = (int)num(54); voxels_min = (int)num(58); adjacency_min = (int)num(60);
   } else {
     sig_c = 0.75f;  // normal importance of Task_File_SVGS.txt, carried in sig_c as above
   }
