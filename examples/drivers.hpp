@@ -42,7 +42,8 @@ inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>&
   voxel_structure.findAllVoxelAdjacency(graph_size);
   voxel_structure.segmentVoxelCloudWithGraphModel(cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w);
   // output (test:74-76)
-  std::vector<int32_t> labels = voxel_structure.drawColorMapofPointsinClusters();
+  PCXYZRGBPtr clustered_cloud(new PCXYZRGB);
+  voxel_structure.drawColorMapofPointsinClusters(clustered_cloud);
   clusters_points_idx = voxel_structure.getClusterIdx();
   if (sum) {
     sum->points = (long)input_cloud->points.size(); sum->voxels = voxels; sum->clusters = voxel_structure.getClusterNum();
@@ -50,7 +51,7 @@ inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>&
     sum->labelled = 0;
     for (auto& c : clusters_points_idx) sum->labelled += (long)c.size();
   }
-  (void)voxel_centers; (void)labels;
+  (void)voxel_centers;
   return 0;
 }
 
@@ -84,7 +85,8 @@ inline int segmentationSVGS(PCXYZPtr input_cloud, const std::vector<std::string>
   supervoxel_structure.setSupervoxelCentersCentroids();                               // test:152-153
   supervoxel_structure.getVoxelNum();
   supervoxel_structure.segmentSupervoxelCloudWithGraphModel(sig_a, sig_b, sig_c, cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w);  // test:156
-  std::vector<int32_t> labels = supervoxel_structure.drawColorMapofPointsinClusters();  // test:159-160
+  PCXYZRGBPtr clustered_cloud(new PCXYZRGB);
+  supervoxel_structure.drawColorMapofPointsinClusters(clustered_cloud);               // test:159-160
   clusters_points_idx = supervoxel_structure.getClusterIdx();
   if (sum) {
     sum->points = (long)input_cloud->points.size(); sum->voxels = supervoxel_structure.getVoxelNum();
@@ -93,7 +95,6 @@ inline int segmentationSVGS(PCXYZPtr input_cloud, const std::vector<std::string>
     sum->labelled = 0;
     for (auto& c : clusters_points_idx) sum->labelled += (long)c.size();
   }
-  (void)labels;
   return 0;
 }
 

@@ -27,17 +27,6 @@
 
 #include "vgs_segmentation.hpp"
 
-namespace pcl {
-struct PointXYZRGB {  // x, y, z, padding, then the colour packed as PCL packs it: 0x00RRGGBB in one 32-bit word
-  float x, y, z, pad;
-  uint32_t rgba;
-  float pad2[3];
-  PointXYZRGB() : x(0), y(0), z(0), pad(1.0f), rgba(0), pad2{0, 0, 0} {}
-};
-}  // namespace pcl
-typedef pcl::PointCloud<pcl::PointXYZRGB> PCXYZRGB;
-typedef pcl::PointCloud<pcl::PointXYZRGB>::Ptr PCXYZRGBPtr;
-
 namespace vgs_io {
 
 struct PcdField { std::string name; int size = 4; char type = 'F'; int count = 1; int offset = 0; };
@@ -196,16 +185,7 @@ inline void write_pcd_header(std::ostream& f, bool rgb, size_t n, bool binary) {
   f << "WIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA " << (binary ? "binary" : "ascii") << "\n";
 }
 
-// one colour per cluster from a 64-bit LCG (Knuth's MMIX constants), seeded: reproducible files
-struct Palette {
-  uint64_t s;
-  explicit Palette(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) {}
-  uint32_t next() {
-    s = s * 6364136223846793005ull + 1442695040888963407ull;
-    const uint32_t v = (uint32_t)(s >> 33);
-    return v & 0x00ffffffu;  // 0x00RRGGBB
-  }
-};
+typedef vgs_color::Palette Palette;  // the seeded per-cluster colours (vgs_segmentation.hpp)
 
 }  // namespace vgs_io
 
@@ -251,23 +231,9 @@ inline int saveColoredClusters(const std::string& fileoutpath_name, PCXYZRGBPtr 
   return f.good() ? 0 : -1;
 }
 
-// cluster by cluster, member by member, like the reference (point_clouds_IO.cpp:39-61); points of no cluster are absent
 inline PCXYZRGBPtr colorClusters(PCXYZPtr input_cloud, const std::vector<std::vector<int>>& clusters_points_idx, uint64_t seed = 0) {
   PCXYZRGBPtr out(new PCXYZRGB);
-  vgs_io::Palette pal(seed);
-  size_t total = 0;
-  for (const auto& c : clusters_points_idx) total += c.size();
-  out->points.reserve(total);
-  for (const auto& c : clusters_points_idx) {
-    const uint32_t colour = pal.next();
-    for (int idx : c) {
-      pcl::PointXYZRGB q;
-      const pcl::PointXYZ& p = input_cloud->points[(size_t)idx];
-      q.x = p.x; q.y = p.y; q.z = p.z; q.rgba = colour;
-      out->points.push_back(q);
-    }
-  }
-  out->width = (uint32_t)out->points.size(); out->height = 1;
+  vgs_color::color_clusters(*input_cloud, clusters_points_idx, seed, *out);
   return out;
 }
 

@@ -31,6 +31,13 @@ struct PointXYZ {  // 16 bytes like pcl::PointXYZ (x, y, z, padding)
   PointXYZ(float x_, float y_, float z_) : x(x_), y(y_), z(z_), pad(1.0f) {}
 };
 
+struct PointXYZRGB {  // x, y, z, padding, then the colour packed as PCL packs it: 0x00RRGGBB in one 32-bit word
+  float x, y, z, pad;
+  uint32_t rgba;
+  float pad2[3];
+  PointXYZRGB() : x(0), y(0), z(0), pad(1.0f), rgba(0), pad2{0, 0, 0} {}
+};
+
 template <typename PointT>
 struct PointCloud {
   typedef std::shared_ptr<PointCloud<PointT>> Ptr;
@@ -43,6 +50,39 @@ struct PointCloud {
 
 typedef pcl::PointCloud<pcl::PointXYZ>::Ptr PCXYZPtr;
 typedef pcl::PointCloud<pcl::PointXYZ> PCXYZ;
+typedef pcl::PointCloud<pcl::PointXYZRGB> PCXYZRGB;
+typedef pcl::PointCloud<pcl::PointXYZRGB>::Ptr PCXYZRGBPtr;
+
+namespace vgs_color {
+// one colour per cluster from a 64-bit LCG (Knuth's MMIX constants), seeded: the reference draws its colours with
+// rand() after srand(time(0)) (VS:960, point_clouds_IO.cpp:36), so its files differ from run to run; these do not
+struct Palette {
+  uint64_t s;
+  explicit Palette(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) {}
+  uint32_t next() {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(s >> 33) & 0x00ffffffu;  // 0x00RRGGBB
+  }
+};
+// cluster by cluster, member by member (VS:963-1009, point_clouds_IO.cpp:39-61); points of no cluster are absent
+inline void color_clusters(const PCXYZ& in, const std::vector<std::vector<int>>& clusters, uint64_t seed, PCXYZRGB& out) {
+  Palette pal(seed);
+  size_t total = 0;
+  for (const auto& c : clusters) total += c.size();
+  out.points.clear();
+  out.points.reserve(total);
+  for (const auto& c : clusters) {
+    const uint32_t colour = pal.next();
+    for (int idx : c) {
+      pcl::PointXYZRGB q;
+      const pcl::PointXYZ& p = in.points[(size_t)idx];
+      q.x = p.x; q.y = p.y; q.z = p.z; q.rgba = colour;
+      out.points.push_back(q);
+    }
+  }
+  out.width = (uint32_t)out.points.size(); out.height = 1;
+}
+}  // namespace vgs_color
 
 namespace pcl {
 
@@ -142,6 +182,11 @@ class VoxelBasedSegmentation {
     drawn_ = true;
     return lab;
   }
+  // the reference's signature (VS:947): the kept clusters as a coloured cloud, one colour each (seeded palette)
+  void drawColorMapofPointsinClusters(const PCXYZRGBPtr& colored_cloud, uint64_t seed = 0) {
+    drawn_ = true;
+    if (colored_cloud && cloud_) vgs_color::color_clusters(*cloud_, getClusterIdx(), seed, *colored_cloud);
+  }
 
   vgs_ctx* ctx() { return ctx_.get(); }
 
@@ -226,6 +271,9 @@ class SuperVoxelBasedSegmentation {
     chk(vgs_get_point_labels(ctx(), lab.data()), "vgs_get_point_labels");
     lab.pop_back();
     return lab;
+  }
+  void drawColorMapofPointsinClusters(const PCXYZRGBPtr& colored_cloud, uint64_t seed = 0) {  // the reference's signature (SS:613)
+    if (colored_cloud && cloud_) vgs_color::color_clusters(*cloud_, getClusterIdx(), seed, *colored_cloud);
   }
   vgs_ctx* ctx() { return ctx_.get(); }
 
