@@ -489,7 +489,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_ng = d_nf + 1;
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
   constexpr int LCAP_A = 384, LCAP_B = 232, LCAP_C = 2048;
-  constexpr unsigned int GRID_F = 16384, GRID_G = 1024;  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
+  constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
+  constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
@@ -560,7 +561,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
-      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
     vgs_status st = launch_block(ids_d, nabc[3], false);
     // class C hand-overs: fixed grid, length read on the device (no host round trip)

@@ -62,8 +62,14 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
 // (wavefronts per CU) on URB10M), so the footprint is cut to 5 KB per wavefront = the 32-wavefronts-per-CU cap:
 // centroids SoA without a flag word (an unusable position is a NaN x), one-byte vertex/segment indices up to 256
 // vertices, and the edge list as two arrays (weight bits, complemented pair id) instead of one 8-byte key.
-template <int MAXM, int LCAP>
-__global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
+//
+// NW > 1: NW wavefronts per voxel share the LDS arrays (large neighbourhoods: 34 KB per voxel would otherwise leave one
+// wavefront per SIMD).  Wavefront 0 runs the algorithm; the others wait at a workgroup barrier for the three heavy,
+// order-free sections -- pair enumeration, weight evaluation, sort -- take their share, and wait again.  The merge and
+// the bookkeeping between shells stay on wavefront 0.  Candidates are then appended through an LDS counter, so their
+// order in the list depends on timing; the sort that follows removes that (keys are unique).
+template <int MAXM, int LCAP, int NW = 1>
+__global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2)) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
                                                       const uint32_t* __restrict__ work, int n_work,
                                                       const unsigned int* __restrict__ n_work_dev,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
@@ -87,8 +93,13 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
   __shared__ idx_t alist[MAXM];  // vertices whose segment can still merge (ascending)
   __shared__ idx_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
+  __shared__ int sh_i[16];       // NW > 1: command and arguments of the current section, its results
+  __shared__ float sh_f[2];
+  enum { SH_CMD = 0, SH_NLIST, SH_NACT, SH_NMIN, SH_BIG, SH_MINOR, SH_FINAL, SH_MERGED, SH_PACT, SH_COUNT, SH_DROPPED, SH_CNT };
+  enum { CMD_QUIT = 0, CMD_ENUM, CMD_EVAL, CMD_SORT };
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto blk_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_sync(); };
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
   // Morton-ordered work list so that neighbouring voxels share their L2
   // An optional first list (the heavier voxels of the launch) is dealt out the same way before the main list, so
@@ -122,12 +133,12 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   auto R = [&](int v) -> const NodeRec& { return node[gid[v]]; };
   const int m = n;
   if (m > MAXM) {  // classification guarantees this does not happen; hand over to the general kernel anyway
-    if (lane == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
+    if (threadIdx.x == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
     return;
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
   const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);  // cut / size, looked up across lanes
-  for (int c = lane; c < m; c += 64) {
+  for (int c = (int)threadIdx.x; c < m; c += 64 * NW) {
     const uint32_t t = (uint32_t)row[c];
     gid[c] = t;
     seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c; claim[c] = 0xffffffffu;
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
     cy[c] = rc.c[1];
     cz[c] = rc.c[2];
   }
-  wave_sync();
+  blk_sync();
 
   LW_ACC(0);  // gather
   if (P.shell0 < 0.0f) return;  // diagnostics: gather-only run
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
   // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
   // real one that never move, so cnt need not be a power of two and nothing is padded.
-  auto sort_list = [&](int cnt) {
+  auto sort_section = [&](int cnt) {   // all wavefronts of the workgroup
     int np = 64;
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {
@@ -156,23 +167,195 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
       const uint32_t xp = lp[lo], yp = lp[hi];
       if ((xw < yw) || (xw == yw && xp < yp)) { lw[lo] = yw; lw[hi] = xw; lp[lo] = (pid_t)yp; lp[hi] = (pid_t)xp; }
     };
-    wave_sync();
+    blk_sync();
     for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
-      for (int t = lane; t < (np >> 1); t += 64) {
+      for (int t = (int)threadIdx.x; t < (np >> 1); t += 64 * NW) {
         const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
         cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
       }
-      wave_sync();
+      blk_sync();
       for (int sl = sbit - 2; sl >= 0; --sl) {
         const int strd = 1 << sl;
-        for (int t = lane; t < (np >> 1); t += 64) {
+        for (int t = (int)threadIdx.x; t < (np >> 1); t += 64 * NW) {
           const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
           cmpx(lo, lo + strd);
         }
-        wave_sync();
+        blk_sync();
       }
     }
   };
+
+  // ---- the two other shared sections ----
+  // candidates of one shell: pids appended behind the n_list carried edges; returns the count (NW == 1) or adds to sh_i[SH_COUNT]
+  auto enum_section = [&](int n_list, int n_act, int n_min, int big, bool use_minor, bool final_round, bool merged, int Pact,
+                          float cut_lo, float cut_hi) -> int {
+    int count = 0;
+    auto append = [&](bool inr, uint32_t pid) {
+      const unsigned long long mk = __ballot(inr);
+      int base;
+      if constexpr (NW == 1) {
+        base = count;
+        count += __popcll(mk);
+      } else {
+        int b = 0;
+        if (mk != 0ull && lane == 0) b = atomicAdd(&sh_i[SH_COUNT], __popcll(mk));
+        base = __builtin_amdgcn_readfirstlane(b);
+      }
+      if (inr) {
+        const int pos = n_list + base + __popcll(mk & lt_mask);
+        if (pos < LCAP) lp[pos] = (pid_t)pid;
+      }
+    };
+    if (use_minor) {
+      // pairs (x, y): x outside the largest segment, y any active vertex of another segment; a pair of two
+      // outside vertices is taken once (x < y)
+      for (int ix = wave; ix < n_min; ix += NW) {
+        const int x = minor[ix];
+        const float pxx = cx[x], pxy = cy[x], pxz = cz[x];
+        const int sx = seg[x];
+        for (int base = 0; base < n_act; base += 64) {
+          const int iy = base + lane;
+          bool inr = false;
+          uint32_t pid = 0;
+          if (iy < n_act) {
+            const int y = alist[iy];
+            const int sy = seg[y];
+            if (sy != sx && (sy == big || x < y)) {
+              const float dx = pxx - cx[y], dy = pxy - cy[y], dz = pxz - cz[y];  // (a-b)^2 == (b-a)^2: order-free
+              float d2 = (dx * dx + dy * dy) + dz * dz;
+              d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
+              inr = (d2 >= cut_lo) && (final_round || d2 < cut_hi);
+              pid = (x < y) ? (((uint32_t)x << PSH) | (uint32_t)y) : (((uint32_t)y << PSH) | (uint32_t)x);
+            }
+          }
+          append(inr, pid);
+        }
+      }
+    } else {
+      // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
+      // LDS reads of a trip are issued together
+      // pair p (row-major over ia < ib) is decoded arithmetically, counting from the END of the triangle:
+      // q = P-1-p lies in row r = floor((sqrt(8q+1)-1)/2) from the end (8q+1 < 2^24: exact in float at the row starts)
+      const bool ident = (n_act == m);  // alist is still the identity
+      for (int base = 256 * wave; base < Pact; base += 256 * NW) {
+        int va[4], vb[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t p = (uint32_t)(base + 64 * k + lane);
+          ok[k] = p < (uint32_t)Pact;
+          const uint32_t q = ok[k] ? ((uint32_t)Pact - 1u - p) : 0u;
+          // raw v_sqrt_f32 (1 ulp) is enough: the two compares below repair an off-by-one row
+          uint32_t r = (uint32_t)((__builtin_amdgcn_sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
+          r += (((r + 1u) * (r + 2u)) >> 1) <= q ? 1u : 0u;
+          r -= ((r * (r + 1u)) >> 1) > q ? 1u : 0u;
+          const int ia = n_act - 2 - (int)r;
+          const int ib = n_act - 1 - (int)(q - ((r * (r + 1u)) >> 1));
+          va[k] = ident ? ia : (int)alist[ia];
+          vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
+        }
+        float ax[4], ay[4], az[4], bx[4], by[4], bz[4];
+        bool diff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ax[k] = cx[va[k]]; ay[k] = cy[va[k]]; az[k] = cz[va[k]];
+          bx[k] = cx[vb[k]]; by[k] = cy[vb[k]]; bz[k] = cz[vb[k]];
+          diff[k] = ok[k] && (!merged || seg[va[k]] != seg[vb[k]]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dx = ax[k] - bx[k], dy = ay[k] - by[k], dz = az[k] - bz[k];
+          float d2 = (dx * dx + dy * dy) + dz * dz;
+          d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
+          const bool inr = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
+          append(inr, ((uint32_t)va[k] << PSH) | (uint32_t)vb[k]);
+        }
+      }
+    }
+    return count;
+  };
+  // full weight of the candidates [n_list, n_list + count); NaN (Q3) and weights <= thr0 (fact S) become dropped
+  // entries; returns their number (NW == 1) or adds it to sh_i[SH_DROPPED]
+  auto eval_section = [&](int n_list, int count) -> int {
+    int dropped = 0;
+    for (int base = n_list + 64 * wave; base < n_list + count; base += 64 * NW) {
+      const int e = base + lane;
+      bool drop = false;
+      if (e < n_list + count) {
+        const uint32_t pid = (uint32_t)lp[e];
+        const NodeRec& A = R(pid >> PSH);
+        const NodeRec& B = R(pid & PMASK);
+        // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
+        const float ub = vm_weight_bound_da(A, B, W);
+        float w = 0.0f;
+        if (!(ub <= thr0)) w = vm_pair_weight(A, B, W);
+        drop = !(w > thr0);
+        lw[e] = drop ? 0u : vm_bits(w);
+        lp[e] = drop ? (pid_t)0 : (pid_t)(PCOMP - pid);
+      }
+      dropped += __popcll(__ballot(drop));
+    }
+    if constexpr (NW > 1) { if (lane == 0 && dropped) atomicAdd(&sh_i[SH_DROPPED], dropped); }
+    return dropped;
+  };
+
+  // ---- wavefronts 1 .. NW-1: serve the sections until wavefront 0 is done ----
+  if constexpr (NW > 1) {
+    if (wave != 0) {
+      while (true) {
+        __syncthreads();
+        const int cmd = sh_i[SH_CMD];
+        if (cmd == CMD_QUIT) return;
+        if (cmd == CMD_ENUM)
+          enum_section(sh_i[SH_NLIST], sh_i[SH_NACT], sh_i[SH_NMIN], sh_i[SH_BIG], sh_i[SH_MINOR] != 0, sh_i[SH_FINAL] != 0, sh_i[SH_MERGED] != 0,
+                       sh_i[SH_PACT], sh_f[0], sh_f[1]);
+        else if (cmd == CMD_EVAL)
+          eval_section(sh_i[SH_NLIST], sh_i[SH_CNT]);
+        else
+          sort_section(sh_i[SH_CNT]);
+        __syncthreads();
+      }
+    }
+  }
+  // ---- wavefront 0: calls into the sections (alone when NW == 1) ----
+  auto run_enum = [&](int n_list, int n_act, int n_min, int big, bool use_minor, bool final_round, bool merged, int Pact, float cut_lo,
+                      float cut_hi) -> int {
+    if constexpr (NW == 1) {
+      return enum_section(n_list, n_act, n_min, big, use_minor, final_round, merged, Pact, cut_lo, cut_hi);
+    } else {
+      if (lane == 0) {
+        sh_i[SH_CMD] = CMD_ENUM; sh_i[SH_NLIST] = n_list; sh_i[SH_NACT] = n_act; sh_i[SH_NMIN] = n_min; sh_i[SH_BIG] = big;
+        sh_i[SH_MINOR] = use_minor; sh_i[SH_FINAL] = final_round; sh_i[SH_MERGED] = merged; sh_i[SH_PACT] = Pact; sh_i[SH_COUNT] = 0;
+        sh_f[0] = cut_lo; sh_f[1] = cut_hi;
+      }
+      __syncthreads();
+      enum_section(n_list, n_act, n_min, big, use_minor, final_round, merged, Pact, cut_lo, cut_hi);
+      __syncthreads();
+      return sh_i[SH_COUNT];
+    }
+  };
+  auto run_eval = [&](int n_list, int count) -> int {
+    if constexpr (NW == 1) {
+      return eval_section(n_list, count);
+    } else {
+      if (lane == 0) { sh_i[SH_CMD] = CMD_EVAL; sh_i[SH_NLIST] = n_list; sh_i[SH_CNT] = count; sh_i[SH_DROPPED] = 0; }
+      __syncthreads();
+      eval_section(n_list, count);
+      __syncthreads();
+      return sh_i[SH_DROPPED];
+    }
+  };
+  auto sort_list = [&](int cnt) {
+    if constexpr (NW == 1) {
+      sort_section(cnt);
+    } else {
+      if (lane == 0) { sh_i[SH_CMD] = CMD_SORT; sh_i[SH_CNT] = cnt; }
+      __syncthreads();
+      sort_section(cnt);
+      __syncthreads();
+    }
+  };
+  auto master = [&]() {
 
   // Merge of the sorted edge list [0, cnt) down to (not including) weights <= level, in the reference's sequential
   // order; returns the position of the first unprocessed edge; afterwards seg[] maps every vertex to its live
@@ -292,83 +475,7 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
       const int Pact = use_minor ? n_min * n_act : n_act * (n_act - 1) / 2;   // (upper bound of) candidate pairs
       // once every pair between the still-active vertices fits in the list there is no point in further shells
       const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
-      int count = 0;
-      if (use_minor) {
-        // pairs (x, y): x outside the largest segment, y any active vertex of another segment; a pair of two
-        // outside vertices is taken once (x < y)
-        for (int ix = 0; ix < n_min; ++ix) {
-          const int x = minor[ix];
-          const float pxx = cx[x], pxy = cy[x], pxz = cz[x];
-          const int sx = seg[x];
-          for (int base = 0; base < n_act; base += 64) {
-            const int iy = base + lane;
-            bool inr = false;
-            uint32_t pid = 0;
-            if (iy < n_act) {
-              const int y = alist[iy];
-              const int sy = seg[y];
-              if (sy != sx && (sy == big || x < y)) {
-                const float dx = pxx - cx[y], dy = pxy - cy[y], dz = pxz - cz[y];  // (a-b)^2 == (b-a)^2: order-free
-                float d2 = (dx * dx + dy * dy) + dz * dz;
-                d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
-                inr = (d2 >= cut_lo) && (final_round || d2 < cut_hi);
-                pid = (x < y) ? (((uint32_t)x << PSH) | (uint32_t)y) : (((uint32_t)y << PSH) | (uint32_t)x);
-              }
-            }
-            const unsigned long long mk = __ballot(inr);
-            if (inr) {
-              const int pos = n_list + count + __popcll(mk & lt_mask);
-              if (pos < LCAP) lp[pos] = (pid_t)pid;
-            }
-            count += __popcll(mk);
-          }
-        }
-      } else {
-        // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
-        // LDS reads of a trip are issued together
-        // pair p (row-major over ia < ib) is decoded arithmetically, counting from the END of the triangle:
-        // q = P-1-p lies in row r = floor((sqrt(8q+1)-1)/2) from the end (8q+1 < 2^24: exact in float at the row starts)
-        const bool ident = (n_act == m);  // alist is still the identity
-        for (int base = 0; base < Pact; base += 256) {
-          int va[4], vb[4];
-          bool ok[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t p = (uint32_t)(base + 64 * k + lane);
-            ok[k] = p < (uint32_t)Pact;
-            const uint32_t q = ok[k] ? ((uint32_t)Pact - 1u - p) : 0u;
-            // raw v_sqrt_f32 (1 ulp) is enough: the two compares below repair an off-by-one row
-            uint32_t r = (uint32_t)((__builtin_amdgcn_sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
-            r += (((r + 1u) * (r + 2u)) >> 1) <= q ? 1u : 0u;
-            r -= ((r * (r + 1u)) >> 1) > q ? 1u : 0u;
-            const int ia = n_act - 2 - (int)r;
-            const int ib = n_act - 1 - (int)(q - ((r * (r + 1u)) >> 1));
-            va[k] = ident ? ia : (int)alist[ia];
-            vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
-          }
-          float ax[4], ay[4], az[4], bx[4], by[4], bz[4];
-          bool diff[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            ax[k] = cx[va[k]]; ay[k] = cy[va[k]]; az[k] = cz[va[k]];
-            bx[k] = cx[vb[k]]; by[k] = cy[vb[k]]; bz[k] = cz[vb[k]];
-            diff[k] = ok[k] && (merges == 0 || seg[va[k]] != seg[vb[k]]);
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float dx = ax[k] - bx[k], dy = ay[k] - by[k], dz = az[k] - bz[k];
-            float d2 = (dx * dx + dy * dy) + dz * dz;
-            d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
-            const bool inr = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
-            const unsigned long long mk = __ballot(inr);
-            if (inr) {
-              const int pos = n_list + count + __popcll(mk & lt_mask);
-              if (pos < LCAP) lp[pos] = (pid_t)(((uint32_t)va[k] << PSH) | (uint32_t)vb[k]);
-            }
-            count += __popcll(mk);
-          }
-        }
-      }
+      const int count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
       LW_ACC(1);  // enumerate
       if (P.dbg_stop == 1) return;
       LW_CNT(8, 1);  // rounds
@@ -383,24 +490,7 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
       shrink = 0;
       wave_sync();
       // ---- 2. full weight of the shell's pairs; NaN (Q3) and weights <= thr0 (fact S) are not stored ----
-      int dropped = 0;
-      for (int base = n_list; base < n_list + count; base += 64) {
-        const int e = base + lane;
-        bool drop = false;
-        if (e < n_list + count) {
-          const uint32_t pid = (uint32_t)lp[e];
-          const NodeRec& A = R(pid >> PSH);
-          const NodeRec& B = R(pid & PMASK);
-          // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
-          const float ub = vm_weight_bound_da(A, B, W);
-          float w = 0.0f;
-          if (!(ub <= thr0)) w = vm_pair_weight(A, B, W);
-          drop = !(w > thr0);
-          lw[e] = drop ? 0u : vm_bits(w);
-          lp[e] = drop ? (pid_t)0 : (pid_t)(PCOMP - pid);
-        }
-        dropped += __popcll(__ballot(drop));
-      }
+      const int dropped = run_eval(n_list, count);
       if (lane == 0) n_evals += (unsigned long long)count;
       n_list += count;
       LW_ACC(2);  // evaluate
@@ -563,6 +653,12 @@ __global__ __launch_bounds__(64, MAXM <= 255 ? LW_WAVES : 2) void k_localcut_wav
   if (lane == 0 && dbg_out) { long long tnow = clock64(); dbg_out[4 * (size_t)u + 0] = (uint32_t)m; dbg_out[4 * (size_t)u + 1] = (uint32_t)prof[8]; dbg_out[4 * (size_t)u + 2] = (uint32_t)((tnow - t_start) >> 4); dbg_out[4 * (size_t)u + 3] = (uint32_t)n_evals; }
   if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }
 #endif
+  };  // master
+  master();
+  if constexpr (NW > 1) {
+    if (lane == 0) sh_i[SH_CMD] = CMD_QUIT;
+    __syncthreads();
+  }
 }
 
 #endif
