@@ -1,6 +1,6 @@
 """Parity of the large-neighbourhood classes of the local cut, which the default scenes hardly reach: class C (129..512
-neighbours, one wavefront per voxel with 16-bit indices and a 2048-edge list) and class D (> 512 neighbours, the
-workgroup-per-voxel kernel), plus the hand-over paths.  Same bar as tests/test_gpu_parity.py: connect lists and labels
+neighbours, four wavefronts per voxel, 16-bit indices, 2048-edge list), class D (513..1024 neighbours, eight wavefronts
+per voxel) and beyond (the workgroup-per-voxel kernel with histogram rounds), plus the hand-over paths.  Same bar as tests/test_gpu_parity.py: connect lists and labels
 identical to the oracle in DevMath + lean flavour."""
 import numpy as np
 import pytest
@@ -38,6 +38,24 @@ def run(request, gpu, oracle):
     eng.run()
     ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
     return dict(name=name, eng=eng, ref=ref, pred=pred)
+
+
+def test_hand_over_from_the_wide_kernels(gpu, oracle, monkeypatch):
+    """VGS_DBG_MAXM makes the multi-wavefront kernels hand over neighbourhoods above 600 voxels, as they do on their own
+    above 1024: the workgroup kernel with its histogram rounds must give the same lists."""
+    monkeypatch.setenv("VGS_DBG_MAXM", "600")
+    name, make, kw, _ = CASES[1]
+    xyz = make(gpu)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    assert eng.counts()["handed_over"] > 100
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    for which in ("connect_cut", "connect_final"):
+        off, idx = eng.lists(which)
+        roff, ridx = ref.lists(which)
+        assert np.array_equal(off, roff) and ragged_sets(off, idx) == ragged_sets(roff, ridx)
 
 
 def test_case_reaches_the_class(run):

@@ -115,12 +115,13 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+      hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     g_create_err = "vgs_create: hipSetDevice/hipStreamCreate failed";
     delete c;
     return VGS_E_HIP;
   }
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 14; ++i)
     if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
   *out = c;
   return VGS_OK;
@@ -144,10 +145,11 @@ void vgs_destroy(vgs_ctx* c) {
   c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
-  for (int i = 0; i < 12; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   delete c;
 }
 

@@ -490,7 +490,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
   constexpr int LCAP_A = 384, LCAP_B = 232, LCAP_C = 2048;
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
-  constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
+  constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)
+  constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
@@ -517,6 +518,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.grow = 2.25f;
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
+  WP.dbg_max_m = getenv("VGS_DBG_MAXM") ? atoi(getenv("VGS_DBG_MAXM")) : 0;
   // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the
   // device (fixed grid of nw workgroups starting at list position `offset`); otherwise nw is the length.
   auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid, const unsigned int* n_dev = nullptr, unsigned int offset = 0) -> vgs_status {
@@ -558,14 +560,25 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipEventRecord(c->ev[9], c->stream3));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[9], 0));
   {
+    // class D (more than 512 neighbours) on its own stream: eight wavefronts per voxel up to 1024 neighbours; beyond
+    // that the kernel hands the voxel over (list g) to the workgroup kernel with its histogram rounds
+    if (nabc[3] > 0) {
+      VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev[2], 0));
+      hipLaunchKernelGGL((k_localcut_wave<WAVE_D, LCAP_D, NW_D>), dim3(((nabc[3] + 7) / 8) * 8), dim3(64 * NW_D), 0, c->stream4, (const uint32_t*)nullptr, 0,
+                         ids_d, (int)nabc[3], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
+                         ids_g, d_ng, c->csize.p, dbg_buf);
+      VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
+      VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows both C and D
+    }
     hipStream_t main_stream = c->stream;
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
-    vgs_status st = launch_block(ids_d, nabc[3], false);
-    // class C hand-overs: fixed grid, length read on the device (no host round trip)
-    if (st == VGS_OK && nabc[2] > 0) st = launch_block(ids_g, nabc[2] < GRID_G ? nabc[2] : GRID_G, false, d_ng, 0);
+    // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
+    vgs_status st = VGS_OK;
+    const unsigned int ncd = nabc[2] + nabc[3];
+    if (ncd > 0) st = launch_block(ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }

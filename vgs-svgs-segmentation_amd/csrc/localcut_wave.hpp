@@ -52,6 +52,7 @@ struct LwParams {
   float grow;       // shell growth factor (in squared distance)
   int dbg_stop;     // diagnostics: leave the first round after step N (0 = run normally)
   int max_rounds;   // shells a wavefront works through before it hands the voxel over (classes A/B)
+  int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
 };
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // ---- the neighbourhood in adjacency order (the adjacency stage already dropped inert unused voxels) ----
   auto R = [&](int v) -> const NodeRec& { return node[gid[v]]; };
   const int m = n;
-  if (m > MAXM) {  // classification guarantees this does not happen; hand over to the general kernel anyway
+  if (m > MAXM || (P.dbg_max_m > 0 && m > P.dbg_max_m)) {  // beyond this kernel's arrays: hand over to the general kernel
     if (threadIdx.x == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
     return;
   }

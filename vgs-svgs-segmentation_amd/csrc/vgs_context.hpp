@@ -84,6 +84,7 @@ struct vgs_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // side streams: the heavy local-cut classes overlap the light one
   hipStream_t stream3 = nullptr;
+  hipStream_t stream4 = nullptr;
   std::string err;
   int stage = ST_NONE;
 
@@ -143,7 +144,7 @@ struct vgs_ctx {
 
   int64_t counts[VGS_N_COUNTS] = {0};
   double times[VGS_T_COUNT] = {0};
-  hipEvent_t ev[12] = {nullptr};
+  hipEvent_t ev[14] = {nullptr};
 
   // SVGS
   DevBuf<int32_t> sv_label;     // per point: supervoxel label (0 = unassigned), what getLabeledCloud returns (SS:283)
