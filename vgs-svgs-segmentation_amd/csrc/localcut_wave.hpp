@@ -43,6 +43,10 @@
 #ifndef LW_WAVES
 #define LW_WAVES 7
 #endif
+// pairs per lane and trip of the pair enumeration (their LDS reads are issued together); 4 spills 6 registers at 72
+#ifndef LW_TRIP
+#define LW_TRIP 3
+#endif
 
 struct LwParams {
   LcParams lc;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
 
   LW_ACC(0);  // gather
   if (P.shell0 < 0.0f) return;  // diagnostics: gather-only run
-  unsigned long long n_evals = 0;
+  unsigned int n_evals = 0;   // pair evaluations of this voxel (wave-uniform)
   int merges = 0;
   bool bail = false;
 
@@ -233,16 +237,16 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         }
       }
     } else {
-      // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; 4 pairs per trip so that the
+      // each lane walks pairs p = lane, lane + 64, ... in row-major (ia, ib) order; LW_TRIP pairs per trip so that the
       // LDS reads of a trip are issued together
       // pair p (row-major over ia < ib) is decoded arithmetically, counting from the END of the triangle:
       // q = P-1-p lies in row r = floor((sqrt(8q+1)-1)/2) from the end (8q+1 < 2^24: exact in float at the row starts)
       const bool ident = (n_act == m);  // alist is still the identity
-      for (int base = 256 * wave; base < Pact; base += 256 * NW) {
-        int va[4], vb[4];
-        bool ok[4];
+      for (int base = 64 * LW_TRIP * wave; base < Pact; base += 64 * LW_TRIP * NW) {
+        int va[LW_TRIP], vb[LW_TRIP];
+        bool ok[LW_TRIP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < LW_TRIP; ++k) {
           const uint32_t p = (uint32_t)(base + 64 * k + lane);
           ok[k] = p < (uint32_t)Pact;
           const uint32_t q = ok[k] ? ((uint32_t)Pact - 1u - p) : 0u;
@@ -255,16 +259,16 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           va[k] = ident ? ia : (int)alist[ia];
           vb[k] = ident ? ib : (int)alist[ib];   // va < vb: alist is ascending
         }
-        float ax[4], ay[4], az[4], bx[4], by[4], bz[4];
-        bool diff[4];
+        float ax[LW_TRIP], ay[LW_TRIP], az[LW_TRIP], bx[LW_TRIP], by[LW_TRIP], bz[LW_TRIP];
+        bool diff[LW_TRIP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < LW_TRIP; ++k) {
           ax[k] = cx[va[k]]; ay[k] = cy[va[k]]; az[k] = cz[va[k]];
           bx[k] = cx[vb[k]]; by[k] = cy[vb[k]]; bz[k] = cz[vb[k]];
           diff[k] = ok[k] && (!merged || seg[va[k]] != seg[vb[k]]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < LW_TRIP; ++k) {
           const float dx = ax[k] - bx[k], dy = ay[k] - by[k], dz = az[k] - bz[k];
           float d2 = (dx * dx + dy * dy) + dz * dz;
           d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       wave_sync();
       // ---- 2. full weight of the shell's pairs; NaN (Q3) and weights <= thr0 (fact S) are not stored ----
       const int dropped = run_eval(n_list, count);
-      if (lane == 0) n_evals += (unsigned long long)count;
+      n_evals += (unsigned int)count;
       n_list += count;
       LW_ACC(2);  // evaluate
       if (P.dbg_stop == 2) return;
@@ -606,18 +610,19 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         int ia = 0, qq = lane;
         for (int base = 0; base < Pb; base += 64) {
           while (ia < nb - 1 && qq >= nb - 1 - ia) { qq -= (nb - 1 - ia); ++ia; }
-          bool inr = false;
+          bool inr = false, evaluated = false;
           uint32_t kw = 0, kp = 0;
           if (ia < nb - 1) {
             const int a = alist[ia], b = alist[ia + 1 + qq];
             if (seg[a] != seg[b]) {
               const float w = vm_pair_weight(R(a), R(b), W);
-              ++n_evals;
+              evaluated = true;
               inr = (w <= thr0);  // heavier edges were examined in phase A; NaN compares false
               kw = vm_bits(w);
               kp = PCOMP - (((uint32_t)a << PSH) | (uint32_t)b);
             }
           }
+          n_evals += (unsigned int)__popcll(__ballot(evaluated));
           const unsigned long long mk = __ballot(inr);
           if (inr) {
             const int pos = count + __popcll(mk & lt_mask);
@@ -648,8 +653,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     for (int c = lane; c < m; c += 64)
       if ((int)seg[c] == s0) crow[c] = 1;
   }
-  for (int o = 32; o > 0; o >>= 1) n_evals += __shfl_xor(n_evals, o, 64);
-  if (lane == 0) evals_out[u] = (uint32_t)n_evals;  // summed on the host on request: no same-address atomics on the hot path
+  if (lane == 0) evals_out[u] = n_evals;  // summed on the host on request: no same-address atomics on the hot path
 #ifdef VGS_PROF
   if (lane == 0 && dbg_out) { long long tnow = clock64(); dbg_out[4 * (size_t)u + 0] = (uint32_t)m; dbg_out[4 * (size_t)u + 1] = (uint32_t)prof[8]; dbg_out[4 * (size_t)u + 2] = (uint32_t)((tnow - t_start) >> 4); dbg_out[4 * (size_t)u + 3] = (uint32_t)n_evals; }
   if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }
