@@ -497,13 +497,34 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       // ---- 2. full weight of the shell's pairs; NaN (Q3) and weights <= thr0 (fact S) are not stored ----
       const int dropped = run_eval(n_list, count);
       n_evals += (unsigned int)count;
-      n_list += count;
+      auto sort_len = [](int c) { int np = 64; while (np < c) np <<= 1; return np; };
+      if (dropped > 0 && sort_len(n_list + count - dropped) < sort_len(n_list + count)) {
+        // close the gaps before sorting when that halves the sort network (its length is the next power of two):
+        // ascending and in place, a write never passes the read position
+        wave_sync();
+        int kept = n_list;
+        for (int base = n_list; base < n_list + count; base += 64) {
+          const int e = base + lane;
+          uint32_t kw = 0, kp = 0;
+          if (e < n_list + count) { kw = lw[e]; kp = lp[e]; }
+          const bool live = kp != 0u;   // a dropped entry is (0, 0); a real one has lp >= 1
+          const unsigned long long mk = __ballot(live);
+          wave_sync();
+          if (live) { const int d = kept + __popcll(mk & lt_mask); lw[d] = kw; lp[d] = (pid_t)kp; }
+          kept += __popcll(mk);
+          wave_sync();
+        }
+        n_list = kept;
+        sort_list(n_list);
+      } else {
+        n_list += count;
+        sort_list(n_list);
+        n_list -= dropped;  // dropped entries sort to the end
+      }
       LW_ACC(2);  // evaluate
       if (P.dbg_stop == 2) return;
-      // ---- 3. sort, 4. merge down to the level ----
-      sort_list(n_list);
+      // ---- 3. (sorted above) 4. merge down to the level ----
       LW_CNT(9, n_list);
-      n_list -= dropped;
       LW_ACC(3);  // sort
       if (P.dbg_stop == 3) return;
       const float level = final_round ? -1.0f : vm_weight_bound_d(cut_hi, W);
