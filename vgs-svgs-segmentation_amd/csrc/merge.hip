@@ -32,7 +32,7 @@ struct MgParams {
 __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_ids, const uint32_t* __restrict__ used_rank, int64_t U,
                                               const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                               int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
-                                              uint32_t* __restrict__ csize) {
+                                              uint32_t* __restrict__ csize, uint32_t* __restrict__ parent) {
   const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const int lane = threadIdx.x;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   for (int k = lane; k < n; k += 64) len += crow[k] ? 1 : 0;
   for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
   int kept = 0;
+  uint32_t best = i;  // first hook of the union-find (see k_cc_init): smallest mutual neighbour below i
   for (int k = lane; k < n; k += 64) {
     uint8_t mflag = 0;
     if (crow[k]) {
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
         if (ut != 0xffffffffu) {
           const uint64_t want = (key & 0xffffffff00000000ull) | (uint64_t)i;
           const uint64_t* trow = adj_key + (int64_t)ut * adj_stride;
-          int lo = 0, hi = (int)adj_cnt[ut] - 1, found = -1;
+          const int nt = (int)adj_cnt[ut];
+          int lo = 0, hi = nt - 1, found = -1;
           while (lo <= hi) {
             const int mid = (lo + hi) >> 1;
             const uint64_t kk = trow[mid];
@@ -68,12 +70,17 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
           if (found >= 0 && conn[(int64_t)ut * adj_stride + found]) mflag = 1;
         }
       }
+      if (mflag && t < best) best = t;
     }
     mrow[k] = mflag;
     kept += mflag;
   }
   for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
   if (lane == 0) csize[i] = (uint32_t)kept;
+  if (parent) {  // single-tile runs: the hook needs no ownership test, so it is taken here instead of re-reading the row
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
+    if (lane == 0) parent[i] = best;
+  }
 }
 
 // ------------------------------------------------------------------ closestCheck
@@ -319,8 +326,9 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0) {
     if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
+    hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, c->conn.p, mutual, c->csize.p);
+                       c->adj_stride, c->conn.p, mutual, c->csize.p, c->have_region ? nullptr : c->parent.p);
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
     unsigned int* d_ncand = (unsigned int*)(c->counters.p + 0);
@@ -348,8 +356,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   }
   // connected components
   if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
-  hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
-  if (U > 0)
+  if (U == 0) hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+  if (U > 0 && c->have_region)
     hipLaunchKernelGGL(k_cc_init, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   if (U > 0) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
