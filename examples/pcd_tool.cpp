@@ -1,5 +1,5 @@
 // examples/pcd_tool.cpp -- host-only exerciser of include/point_clouds_io.hpp (no GPU, no libvgs_hip.so):
-//   pcd_tool convert <in.pcd> <out.pcd> [ascii|binary]      read any supported PCD, write x y z
+//   pcd_tool convert <in.pcd|in.ply> <out.pcd> [ascii|binary] read any supported PCD or PLY, write x y z
 //   pcd_tool colour <in.pcd> <clusters.txt> <out.pcd> <seed> clusters.txt: one cluster per line, point indices
 //   pcd_tool task <task file>                                 print "<lines> <method> <input name> <output name>"
 #include <cstdio>
@@ -13,7 +13,9 @@ int main(int argc, char** argv) {
   const std::string cmd = argv[1];
   if (cmd == "convert" && argc >= 4) {
     PCXYZPtr c(new PCXYZ);
-    if (inputPointCloudData(argv[2], c) != 0) return 1;
+    const std::string in = argv[2];
+    const bool ply = in.size() > 4 && in.substr(in.size() - 4) == ".ply";
+    if ((ply ? inputPointCloudData2(in, c) : inputPointCloudData(in, c)) != 0) return 1;
     const bool binary = argc > 4 && std::string(argv[4]) == "binary";
     return outputPointCloudData(argv[3], c, binary) == 0 ? 0 : 1;
   }

@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
     out_file = task[18] + name;
   }
   PCXYZPtr cloud(new PCXYZ);
-  if (inputPointCloudData(in_file, cloud) != 0) return 1;
+  const bool ply = in_file.size() > 4 && in_file.substr(in_file.size() - 4) == ".ply";
+  if ((ply ? inputPointCloudData2(in_file, cloud) : inputPointCloudData(in_file, cloud)) != 0) return 1;
   std::vector<std::vector<int>> clusters;
   DriverSummary sum;
   try {

@@ -2,6 +2,7 @@
 // reference's point_clouds_IO.h / point_clouds_IO.cpp do through pcl::io, on this repo's own cloud types.
 //
 //   inputPointCloudData(name, cloud)        point_clouds_IO.h:64-79   PCD reader: DATA ascii | binary | binary_compressed
+//   inputPointCloudData2(name, cloud)       point_clouds_IO.h:81-95   PLY reader: ascii | binary_little_endian | binary_big_endian
 //   outputPointCloudData(name, cloud)       point_clouds_IO.h:98-108  PCD writer (ascii like pcl::io::savePCDFile's default,
 //                                                                      or binary)
 //   saveColoredClusters(name, cloud, idx)   point_clouds_IO.cpp:23-70 XYZRGB PCD, one colour per cluster
@@ -10,7 +11,7 @@
 // Differences from the reference, on purpose:
 //   * colours come from a SEEDED generator (the reference calls srand(time(0)), point_clouds_IO.cpp:36): the same
 //     clusters give the same file; pass another seed for another palette;
-//   * the PLY reader (point_clouds_IO.h:81-95) and the VTK viewer (point_clouds_IO.cpp:79-145) are not provided;
+//   * the VTK viewer (point_clouds_IO.cpp:79-145) is not provided;
 //   * a file that cannot be read returns -1 with a message on stderr (the reference prints PCL_ERROR and returns -1).
 // Host-only, header-only, no GPU code: usable with or without libvgs_hip.so.
 #ifndef POINT_CLOUDS_IO_HPP_
@@ -178,6 +179,90 @@ inline int read_pcd_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
   return 0;
 }
 
+// PLY: the vertex element's x, y, z properties (any scalar type); ascii, binary_little_endian and binary_big_endian;
+// list properties inside the vertex element are not supported, other elements (faces) are ignored
+inline int read_ply_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts, std::string& err) {
+  std::ifstream f(name, std::ios::binary);
+  if (!f.is_open()) { err = "cannot open " + name; return -1; }
+  std::string line;
+  if (!std::getline(f, line) || line.substr(0, 3) != "ply") { err = "not a PLY file"; return -1; }
+  struct Prop { std::string name; int size; char kind; };  // kind: f float, i signed, u unsigned
+  auto type_of = [](const std::string& t, Prop& p) -> bool {
+    static const struct { const char* n; int size; char kind; } T[] = {
+        {"float", 4, 'f'}, {"float32", 4, 'f'}, {"double", 8, 'f'}, {"float64", 8, 'f'}, {"char", 1, 'i'}, {"int8", 1, 'i'},
+        {"uchar", 1, 'u'}, {"uint8", 1, 'u'}, {"short", 2, 'i'}, {"int16", 2, 'i'}, {"ushort", 2, 'u'}, {"uint16", 2, 'u'},
+        {"int", 4, 'i'}, {"int32", 4, 'i'}, {"uint", 4, 'u'}, {"uint32", 4, 'u'}};
+    for (const auto& e : T) if (t == e.n) { p.size = e.size; p.kind = e.kind; return true; }
+    return false;
+  };
+  std::string format;
+  std::vector<Prop> props;
+  size_t n = 0;
+  bool in_vertex = false, seen_vertex = false, vertex_first = true, ended = false;
+  while (std::getline(f, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+    std::istringstream ss(line);
+    std::string key;
+    ss >> key;
+    if (key == "format") ss >> format;
+    else if (key == "element") {
+      std::string el; size_t cnt = 0;
+      ss >> el >> cnt;
+      in_vertex = (el == "vertex");
+      if (in_vertex) { n = cnt; seen_vertex = true; } else if (!seen_vertex && cnt > 0) vertex_first = false;
+    } else if (key == "property" && in_vertex) {
+      std::string t; ss >> t;
+      if (t == "list") { err = "PLY: list property in the vertex element"; return -1; }
+      Prop p; ss >> p.name;
+      if (!type_of(t, p)) { err = "PLY: unknown property type " + t; return -1; }
+      props.push_back(p);
+    } else if (key == "end_header") { ended = true; break; }
+  }
+  if (!ended || !seen_vertex) { err = "PLY header has no vertex element"; return -1; }
+  if (!vertex_first) { err = "PLY: an element precedes the vertices"; return -1; }
+  int ix = -1, iy = -1, iz = -1, stride = 0;
+  std::vector<int> off(props.size());
+  for (size_t k = 0; k < props.size(); ++k) {
+    off[k] = stride; stride += props[k].size;
+    if (props[k].name == "x") ix = (int)k; else if (props[k].name == "y") iy = (int)k; else if (props[k].name == "z") iz = (int)k;
+  }
+  if (ix < 0 || iy < 0 || iz < 0) { err = "PLY vertex element has no x / y / z"; return -1; }
+  pts.assign(n, pcl::PointXYZ());
+  if (format == "ascii") {
+    for (size_t i = 0; i < n; ++i) {
+      if (!std::getline(f, line)) { err = "PLY ascii body is short"; return -1; }
+      const char* s = line.c_str(); char* e = nullptr;
+      double xyz[3] = {0, 0, 0};
+      for (size_t k = 0; k < props.size(); ++k) {
+        const double v = std::strtod(s, &e);
+        if (e == s) { err = "PLY ascii row " + std::to_string(i) + " is short"; return -1; }
+        s = e;
+        if ((int)k == ix) xyz[0] = v; else if ((int)k == iy) xyz[1] = v; else if ((int)k == iz) xyz[2] = v;
+      }
+      pts[i] = pcl::PointXYZ((float)xyz[0], (float)xyz[1], (float)xyz[2]);
+    }
+  } else if (format == "binary_little_endian" || format == "binary_big_endian") {
+    const bool swap = (format == "binary_big_endian");
+    std::vector<unsigned char> buf(n * (size_t)stride);
+    f.read((char*)buf.data(), (std::streamsize)buf.size());
+    if ((size_t)f.gcount() != buf.size()) { err = "PLY binary body is truncated"; return -1; }
+    auto val = [&](const unsigned char* p, const Prop& pr) -> double {
+      unsigned char b[8];
+      for (int k = 0; k < pr.size; ++k) b[k] = swap ? p[pr.size - 1 - k] : p[k];
+      PcdField fd; fd.size = pr.size; fd.type = pr.kind == 'f' ? 'F' : (pr.kind == 'i' ? 'I' : 'U');
+      return pcd_value(b, fd);
+    };
+    for (size_t i = 0; i < n; ++i) {
+      const unsigned char* p = buf.data() + i * (size_t)stride;
+      pts[i] = pcl::PointXYZ((float)val(p + off[ix], props[ix]), (float)val(p + off[iy], props[iy]), (float)val(p + off[iz], props[iz]));
+    }
+  } else {
+    err = "unsupported PLY format '" + format + "'";
+    return -1;
+  }
+  return 0;
+}
+
 inline void write_pcd_header(std::ostream& f, bool rgb, size_t n, bool binary) {
   f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\n";
   if (rgb) f << "FIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n";
@@ -197,6 +282,16 @@ inline int inputPointCloudData(const std::string& dataName, PCXYZPtr dataCloud) 
     std::fprintf(stderr, "Couldn't read the PCD file! (%s)\n", err.c_str());
     return -1;
   }
+  return 0;
+}
+
+inline int inputPointCloudData2(const std::string& dataName, PCXYZPtr dataCloud) {  // point_clouds_IO.h:81 (PLY)
+  std::string err;
+  if (!dataCloud || vgs_io::read_ply_xyz(dataName, dataCloud->points, err) != 0) {
+    std::fprintf(stderr, "Couldn't read the PLY file! (%s)\n", err.c_str());
+    return -1;
+  }
+  dataCloud->width = (uint32_t)dataCloud->points.size(); dataCloud->height = 1;
   return 0;
 }
 

@@ -55,6 +55,34 @@ def test_cpp_reader_and_writer_against_numpy(tool, pcd, tmp_path, mode, out_mode
     assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), xyz.view(np.uint32))   # bit exact, %.9g included
 
 
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_reader(tool, pcd, tmp_path, fmt):
+    """PLY vertices (point_clouds_IO.h:81-95): mixed property types and order, a face element after the vertices."""
+    xyz = _cloud(300, 21)
+    n = xyz.shape[0]
+    inten = np.arange(n, dtype=np.uint8)
+    hdr = (f"ply\nformat {fmt} 1.0\ncomment test\nelement vertex {n}\nproperty uchar intensity\nproperty double z\nproperty float x\n"
+           "property float y\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n")
+    src = tmp_path / "in.ply"
+    with open(src, "wb") as f:
+        f.write(hdr.encode())
+        if fmt == "ascii":
+            for k in range(n):
+                f.write(f"{int(inten[k])} {float(xyz[k, 2]):.17g} {float(xyz[k, 0]):.9g} {float(xyz[k, 1]):.9g}\n".encode())
+            f.write(b"3 0 1 2\n")
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            rec = np.zeros(n, dtype=[("i", "u1"), ("z", e + "f8"), ("x", e + "f4"), ("y", e + "f4")])
+            rec["i"], rec["z"], rec["x"], rec["y"] = inten, xyz[:, 2].astype(np.float64), xyz[:, 0], xyz[:, 1]
+            f.write(rec.tobytes())
+            f.write(bytes([3]) + np.array([0, 1, 2], dtype=e + "i4").tobytes())
+    dst = tmp_path / "out.pcd"
+    subprocess.check_call([tool, "convert", str(src), str(dst), "binary"])
+    got, _ = pcd.read_pcd(dst)
+    out = np.stack([got["x"], got["y"], got["z"]], axis=1)
+    assert np.array_equal(out.view(np.uint32), xyz.view(np.uint32))
+
+
 def test_reader_rejects_bad_files(tool, pcd, tmp_path):
     bad = tmp_path / "bad.pcd"
     bad.write_text("FIELDS x y\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2\n")
