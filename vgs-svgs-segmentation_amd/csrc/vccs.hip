@@ -23,6 +23,7 @@
 
 #include "vgs_context.hpp"
 #include "vccs_common.h"
+#include "brick_table.hpp"
 
 // ---------------------------------------------------------------- voxel attributes
 __global__ void k_vccs_centroid(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
@@ -36,34 +37,15 @@ __global__ void k_vccs_centroid(const float* __restrict__ xs, const float* __res
   cen[3 * v + 0] = sx / cnt; cen[3 * v + 1] = sy / cnt; cen[3 * v + 2] = sz / cnt;
 }
 
-__device__ __forceinline__ uint32_t vc_hash_slot(uint64_t code, uint32_t hbits) {
-  return (uint32_t)((code * 0x9E3779B97F4A7C15ull) >> (64 - hbits));
-}
-
-__global__ void k_vccs_hash_insert(const uint64_t* __restrict__ vox_code, int64_t V, unsigned long long* __restrict__ hkey,
-                                   uint32_t* __restrict__ hval, uint32_t hbits) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  const unsigned long long key = vox_code[v] + 1ull;
-  const uint32_t mask = (1u << hbits) - 1u;
-  uint32_t s = vc_hash_slot(key, hbits);
-  while (true) {
-    unsigned long long prev = atomicCAS(&hkey[s], 0ull, key);
-    if (prev == 0ull) { hval[s] = (uint32_t)v; return; }
-    s = (s + 1) & mask;
-  }
-}
-
-// 26-neighbour table (offset order of vccs_common.h) and the voxel normal from the neighbourhood's centroids
-__global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t V, int depth, const uint64_t* __restrict__ hkey,
-                                  const uint32_t* __restrict__ hval, uint32_t hbits, const float* __restrict__ cen,
-                                  int32_t* __restrict__ nbr, float* __restrict__ nrm) {
+// 26-neighbour table (offset order of vccs_common.h) and the voxel normal from the neighbourhood's centroids.
+// Neighbours are looked up in the brick table (a few MB, L2 resident) instead of a per-voxel hash.
+__global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t V, int depth, const Brick* __restrict__ bricks, uint32_t hbits,
+                                  const float* __restrict__ cen, int32_t* __restrict__ nbr, float* __restrict__ nrm) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t code = vox_code[v];
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
   const uint32_t lim = 1u << depth;
-  const uint32_t mask = (1u << hbits) - 1u;
   float pts[27 * 3];
   int np = 0;
   pts[0] = cen[3 * v]; pts[1] = cen[3 * v + 1]; pts[2] = cen[3 * v + 2];
@@ -73,16 +55,7 @@ __global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t
     vccs_offset(o, &dx, &dy, &dz);
     const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;
     int t = -1;
-    if (nx < lim && ny < lim && nz < lim) {
-      const uint64_t key = vm_morton(nx, ny, nz) + 1ull;
-      uint32_t s = vc_hash_slot(key, hbits);
-      while (true) {
-        const uint64_t k = hkey[s];
-        if (k == key) { t = (int)hval[s]; break; }
-        if (k == 0ull) break;
-        s = (s + 1) & mask;
-      }
-    }
+    if (nx < lim && ny < lim && nz < lim) { bool unused_flag; t = brick_find(bricks, hbits, nx, ny, nz, &unused_flag); }
     nbr[(int64_t)o * V + v] = t;   // [26][V]: a wavefront reads one offset of 64 consecutive voxels
     if (t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
   }
@@ -258,13 +231,8 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   VGS_HIP_TRY(c, cen.ensure(3 * V)); VGS_HIP_TRY(c, nrm.ensure(3 * V)); VGS_HIP_TRY(c, dist.ensure(2 * V));
   VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
-  uint32_t hbits = 4;
-  while ((1ull << hbits) < (uint64_t)(2 * V)) ++hbits;
-  const size_t H = (size_t)1 << hbits;
-  VGS_HIP_TRY(c, c->hkey.ensure(H)); VGS_HIP_TRY(c, c->hval.ensure(H));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->hkey.p, 0, H * 8, c->stream));
-  hipLaunchKernelGGL(k_vccs_hash_insert, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, (unsigned long long*)c->hkey.p, c->hval.p, hbits);
-  hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, c->hkey.p, c->hval.p, hbits, cen.p,
+  { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
+  hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
                      c->vc_nbr.p, nrm.p);
   // ---- seeds: one per occupied seed_res cell, snapped to the voxel nearest to the cell centre ----
   const float seed = c->P.seed_size;
