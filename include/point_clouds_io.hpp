@@ -125,6 +125,15 @@ inline int read_pcd_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
   }
   if (fx < 0 || fy < 0 || fz < 0) { err = "PCD file has no x / y / z fields"; return -1; }
   const size_t n = (size_t)h.points;
+  {
+    // a corrupt header must not turn into a huge allocation: every point takes at least two bytes of the file
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const uint64_t left = (uint64_t)(f.tellg() - here);
+    f.seekg(here);
+    if (h.data != "binary_compressed" && (uint64_t)n > left) { err = "PCD header announces more points than the file can hold"; return -1; }
+    if (h.data == "binary_compressed" && (uint64_t)n > 64u * left + 64u) { err = "PCD header announces more points than the file can hold"; return -1; }
+  }
   pts.assign(n, pcl::PointXYZ());
   if (h.data == "ascii") {
     std::string line;
@@ -227,6 +236,13 @@ inline int read_ply_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
     if (props[k].name == "x") ix = (int)k; else if (props[k].name == "y") iy = (int)k; else if (props[k].name == "z") iz = (int)k;
   }
   if (ix < 0 || iy < 0 || iz < 0) { err = "PLY vertex element has no x / y / z"; return -1; }
+  {
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const uint64_t left = (uint64_t)(f.tellg() - here);
+    f.seekg(here);
+    if ((uint64_t)n > left) { err = "PLY header announces more vertices than the file can hold"; return -1; }
+  }
   pts.assign(n, pcl::PointXYZ());
   if (format == "ascii") {
     for (size_t i = 0; i < n; ++i) {
