@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                   uint32_t* __restrict__ adj_mused) {
   __shared__ uint64_t lst[CAP];
+  __shared__ uint8_t gl[CAP];    // integer squared length of each survivor's lattice offset (the table is sorted by it)
   __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
   const int lane = threadIdx.x;
   const int64_t u = vgs_xcd_item(blockIdx.x, U);
@@ -46,11 +47,14 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   }
   __syncthreads();
   int cnt = 0, mused = 0;
+  const float res2 = res_f * res_f;
+  bool in_band = true;  // every float d2 lies within half a lattice step^2 of its offset's integer length: groups do not interleave
   for (int base = 0; base < n_off; base += 64) {
     const int o = base + lane;
     bool keep = false;
     uint64_t key64 = 0;
     bool is_used = false;
+    int norm = 0;
     if (o < n_off) {
       const int32_t pk = offsets[o];
       const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
@@ -65,6 +69,8 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
           if (d2 < r2) {
             keep = true;
             key64 = ((uint64_t)vm_bits(d2) << 32) | (uint32_t)t;
+            norm = dx * dx + dy * dy + dz * dz;
+            in_band = in_band && (fabsf(d2 - (float)norm * res2) < 0.49f * res2) && (norm < 256);
           }
         }
       }
@@ -72,11 +78,29 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
     const unsigned long long mall = __ballot(keep);
     const bool store = FULL ? keep : (keep && is_used);
     const unsigned long long m = __ballot(store);
-    if (store) lst[cnt + __popcll(m & ((1ull << lane) - 1ull))] = key64;
+    if (store) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); lst[pos] = key64; gl[pos] = (uint8_t)norm; }
     cnt += __popcll(m);
     mused += __popcll(mall);
   }
-  // bitonic sort ascending on the next power of two >= cnt
+  uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  __syncthreads();
+  if (__ballot(!in_band) == 0ull) {
+    // The survivors arrive grouped by the integer length of their offset, and the groups cannot interleave in float d2:
+    // only the order inside a group (a handful of entries: equal lengths, keys differ in rounding and id) is open.  Each
+    // entry counts the smaller keys of its group and goes straight to its final slot of the row.
+    for (int p = lane; p < cnt; p += 64) {
+      const uint64_t key = lst[p];
+      const int g = gl[p];
+      int first = p, rank = 0;
+      for (int q = p - 1; q >= 0 && gl[q] == g; --q) { first = q; rank += lst[q] < key ? 1 : 0; }
+      for (int q = p + 1; q < cnt && gl[q] == g; ++q) rank += lst[q] < key ? 1 : 0;
+      row[first + rank] = key;
+    }
+    if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
+    return;
+  }
+  // general case (coordinates so large that the rounding of the centres rivals the lattice step): bitonic sort
+  // ascending on the next power of two >= cnt
   int np = 64;
   while (np < cnt) np <<= 1;
   for (int k = cnt + lane; k < np; k += 64) lst[k] = ~0ull;
@@ -93,7 +117,6 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
       __syncthreads();
     }
   }
-  uint64_t* row = adj_key + (int64_t)u * adj_stride;
   for (int k = lane; k < cnt; k += 64) row[k] = lst[k];
   if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }  // stored entries, all neighbours
 }
