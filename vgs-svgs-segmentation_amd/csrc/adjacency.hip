@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   float res_f, float min_x, float min_y, float min_z, float r2,
                                                   const NodeRec* __restrict__ node, int adj_stride,
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
-                                                  uint32_t* __restrict__ adj_mused) {
+                                                  uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
+                                                  const int32_t* __restrict__ nvals) {
   __shared__ uint64_t lst[CAP];
   __shared__ uint8_t gl[CAP];    // integer squared length of each survivor's lattice offset (the table is sorted by it)
   __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
@@ -97,8 +98,23 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
       row[first + rank] = key;
     }
     if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
+    if (gtab) {
+      // start of every length group in the row (lower bound of the length in the grouped list); entry ngroups = cnt
+      uint16_t* gt = gtab + (int64_t)u * gstride;
+      for (int r = lane; r <= ngroups; r += 64) {
+        int lo = 0, hi = cnt;
+        if (r < ngroups) {
+          const int want = nvals[r];
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)gl[mid] < want) lo = mid + 1; else hi = mid; }
+        } else {
+          lo = cnt;
+        }
+        gt[r] = (uint16_t)lo;
+      }
+    }
     return;
   }
+  if (gtab) for (int r = lane; r <= ngroups; r += 64) gtab[(int64_t)u * gstride + r] = 0xffffu;  // no group table for this row
   // general case (coordinates so large that the rounding of the centres rivals the lattice step): bitonic sort
   // ascending on the next power of two >= cnt
   int np = 64;
@@ -159,6 +175,20 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
   VGS_HIP_TRY(c, hipMemcpy(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   c->adj_stride = c->n_off;
+  // distinct integer lengths of the offsets (ascending) and the index of each length
+  std::vector<int32_t> nvals;
+  std::vector<uint8_t> nrank(256, 0xff);
+  for (const auto& o : offs)
+    if (nvals.empty() || nvals.back() != o.first) nvals.push_back(o.first);
+  c->adj_ngroups = (int)nvals.size();
+  c->adj_gstride = (c->adj_ngroups + 2) & ~1;   // ngroups + 1 entries, even
+  c->adj_have_gtab = (c->adj_ngroups <= 250 && nvals.back() < 256);
+  if (c->adj_have_gtab) {
+    for (size_t k = 0; k < nvals.size(); ++k) nrank[(size_t)nvals[k]] = (uint8_t)k;
+    VGS_HIP_TRY(c, c->adj_nvals.ensure(nvals.size())); VGS_HIP_TRY(c, c->adj_nrank.ensure(256));
+    VGS_HIP_TRY(c, hipMemcpy(c->adj_nvals.p, nvals.data(), nvals.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    VGS_HIP_TRY(c, hipMemcpy(c->adj_nrank.p, nrank.data(), 256, hipMemcpyHostToDevice));
+  }
   return VGS_OK;
 }
 
@@ -167,10 +197,15 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   const int64_t U = c->U;
   const float res_f = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
+  uint16_t* gt = nullptr;   // group tables only for the rows the pipeline keeps
+  if (out_key == c->adj_key.p && c->adj_have_gtab) {
+    VGS_HIP_TRY(c, c->adj_gtab.ensure((size_t)U * c->adj_gstride));
+    gt = c->adj_gtab.p;
+  }
 #define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
   hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
-                     c->adj_stride, out_key, out_cnt, out_nall)
+                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
   if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }
   else if (c->n_off <= 8192) { if (full) LAUNCH_ADJ(8192, true); else LAUNCH_ADJ(8192, false); }

@@ -32,7 +32,8 @@ struct MgParams {
 __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_ids, const uint32_t* __restrict__ used_rank, int64_t U,
                                               const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                               int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
-                                              uint32_t* __restrict__ csize, uint32_t* __restrict__ parent) {
+                                              uint32_t* __restrict__ csize, uint32_t* __restrict__ parent,
+                                              const uint16_t* __restrict__ gtab, int gstride, const uint8_t* __restrict__ nrank, float inv_res2) {
   const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const int lane = threadIdx.x;
@@ -45,6 +46,13 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   int len = 0;
   for (int k = lane; k < n; k += 64) len += crow[k] ? 1 : 0;
   for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
+  // rows of the voxel lattice carry a table of where each group of equal offset length starts: the reverse entry has
+  // the same length, so only that group (a handful of entries) is searched instead of the whole row
+  const bool own_tab = gtab && gtab[u * gstride] != 0xffffu;
+  __shared__ uint32_t s_rank4[64];   // length -> group index (256 bytes)
+  if (gtab) s_rank4[lane] = ((const uint32_t*)nrank)[lane];
+  __syncthreads();
+  const uint8_t* s_rank = (const uint8_t*)s_rank4;
   int kept = 0;
   uint32_t best = i;  // first hook of the union-find (see k_cc_init): smallest mutual neighbour below i
   for (int k = lane; k < n; k += 64) {
@@ -59,8 +67,20 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
         if (ut != 0xffffffffu) {
           const uint64_t want = (key & 0xffffffff00000000ull) | (uint64_t)i;
           const uint64_t* trow = adj_key + (int64_t)ut * adj_stride;
-          const int nt = (int)adj_cnt[ut];
-          int lo = 0, hi = nt - 1, found = -1;
+          int lo = 0, hi = -1, found = -1;
+          bool ranged = false;
+          if (own_tab) {
+            const int len2 = (int)(vm_from_bits((uint32_t)(key >> 32)) * inv_res2 + 0.5f);  // integer offset length (exact: the row is in band)
+            const int r = len2 < 256 ? (int)s_rank[len2] : 255;
+            if (r != 255) {
+              const uint16_t* gt = gtab + (int64_t)ut * gstride;
+              const uint32_t g0 = gt[r], g1 = gt[r + 1];
+              if (g0 != 0xffffu) { lo = (int)g0; hi = (int)g1 - 1; ranged = true; }   // 0xffff: t's row has no table
+            } else {
+              ranged = true;  // a length that no offset has: not in any row
+            }
+          }
+          if (!ranged) { lo = 0; hi = (int)adj_cnt[ut] - 1; }
           while (lo <= hi) {
             const int mid = (lo + hi) >> 1;
             const uint64_t kk = trow[mid];
@@ -328,7 +348,9 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
     hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, c->conn.p, mutual, c->csize.p, c->have_region ? nullptr : c->parent.p);
+                       c->adj_stride, c->conn.p, mutual, c->csize.p, c->have_region ? nullptr : c->parent.p,
+                       (c->P.method == 2 && c->adj_have_gtab) ? c->adj_gtab.p : nullptr, c->adj_gstride, c->adj_nrank.p,
+                       1.0f / (c->P.voxel_size * c->P.voxel_size));
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
     unsigned int* d_ncand = (unsigned int*)(c->counters.p + 0);

@@ -122,6 +122,13 @@ struct vgs_ctx {
   DevBuf<uint32_t> hval;
   uint32_t hbits = 0;
   DevBuf<int32_t> offsets;  // packed dx,dy,dz
+  // per adjacency row: start position of every group of equal integer offset length (crossValidation searches only
+  // inside the group of the wanted distance); adj_nvals = the distinct lengths, adj_nrank[length] = its index
+  DevBuf<uint16_t> adj_gtab;
+  DevBuf<int32_t> adj_nvals;
+  DevBuf<uint8_t> adj_nrank;
+  int adj_ngroups = 0, adj_gstride = 0;
+  bool adj_have_gtab = false;
   int n_off = 0;
   int adj_R = 0;   // largest |offset| per axis of the ball table
   int adj_stride = 0;
