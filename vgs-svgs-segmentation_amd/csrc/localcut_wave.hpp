@@ -283,6 +283,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // entries; returns their number (NW == 1) or adds it to sh_i[SH_DROPPED]
   auto eval_section = [&](int n_list, int count) -> int {
     int dropped = 0;
+    // In clutter, proximity + normal angle alone often prove w <= thr0 and save the full evaluation; on smooth surfaces
+    // four of five candidates survive and the bound is pure overhead.  It is switched on for the rest of the shell as
+    // soon as a batch loses more than half of its candidates.
+    bool screen = false;
     for (int base = n_list + 64 * wave; base < n_list + count; base += 64 * NW) {
       const int e = base + lane;
       bool drop = false;
@@ -290,15 +294,15 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         const uint32_t pid = (uint32_t)lp[e];
         const NodeRec& A = R(pid >> PSH);
         const NodeRec& B = R(pid & PMASK);
-        // proximity + normal angle alone often prove w <= thr0 (clutter): skip the full evaluation then
-        const float ub = vm_weight_bound_da(A, B, W);
         float w = 0.0f;
-        if (!(ub <= thr0)) w = vm_pair_weight(A, B, W);
+        if (!screen || !(vm_weight_bound_da(A, B, W) <= thr0)) w = vm_pair_weight(A, B, W);
         drop = !(w > thr0);
         lw[e] = drop ? 0u : vm_bits(w);
         lp[e] = drop ? (pid_t)0 : (pid_t)(PCOMP - pid);
       }
-      dropped += __popcll(__ballot(drop));
+      const int nd = __popcll(__ballot(drop));
+      dropped += nd;
+      screen = screen || (2 * nd > 64);
     }
     if constexpr (NW > 1) { if (lane == 0 && dropped) atomicAdd(&sh_i[SH_DROPPED], dropped); }
     return dropped;
