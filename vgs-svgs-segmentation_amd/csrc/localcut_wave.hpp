@@ -444,21 +444,21 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     return pos;
   };
 
-  // ---- can the voxel itself ever merge?  While it is a singleton it needs an incident edge heavier than thr0 ----
-  bool isolated = false;
-  if (m >= 2) {
+  // ---- can the voxel itself ever merge?  While it is a singleton it needs an incident edge heavier than thr0.  On
+  // surfaces vertex 0 joins a segment in the first shell, so the test is only made when it has not (after shell one).
+  auto never_merges = [&]() -> bool {
     bool any = false;
     for (int base = 1; base < m; base += 64) {
       const int x = base + lane;
       if (x < m) {
-        // the cheap bound alone: "not provably isolated" just means the voxel takes the normal path below
+        // the cheap bound alone: "not provably isolated" just means the voxel takes the normal path
         const float ub = vm_weight_bound_da(R(0), R(x), W);
         any = any || !(ub <= thr0);
       }
     }
-    isolated = (__ballot(any) == 0ull);
-  }
-  if (m >= 2 && !isolated) {
+    return __ballot(any) == 0ull;
+  };
+  if (m >= 2) {
     // =========================== phase A: edges heavier than a singleton's threshold ===========================
     int n_list = 0;      // edges carried in the list (sorted, all lighter than the previous level, heavier than thr0)
     int n_act = m;       // vertices still able to merge; pairs are enumerated among them only
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       if (P.dbg_stop == 4) return;
       if (merges >= m - 1) break;
       if (final_round || !(level > thr0)) { phase_a_complete = true; break; }
+      if (rounds == 1 && ssz[seg[0]] == 1 && never_merges()) break;  // the voxel stays alone: its connect list is itself
       // ---- 5. freeze (fact F) and carry ----
       int n_new = 0;
       for (int base = 0; base < n_act; base += 64) {
