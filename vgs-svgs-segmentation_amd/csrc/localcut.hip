@@ -516,6 +516,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
   WP.grow = 2.25f;
+  WP.cap_frac = getenv("VGS_CAPFRAC") ? (float)atof(getenv("VGS_CAPFRAC")) : 0.7f;
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
   WP.dbg_max_m = getenv("VGS_DBG_MAXM") ? atoi(getenv("VGS_DBG_MAXM")) : 0;

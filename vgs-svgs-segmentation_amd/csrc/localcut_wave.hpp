@@ -54,6 +54,7 @@ struct LwParams {
   float d2_all;     // squared distance no pair of one neighbourhood can reach: last shell is open ended
   float shell0;     // first shell = shell0 * r2_graph / m
   float grow;       // shell growth factor (in squared distance)
+  float cap_frac;   // the first shell is sized for at most this fraction of the list
   int dbg_stop;     // diagnostics: leave the first round after step N (0 = run normally)
   int max_rounds;   // shells a wavefront works through before it hands the voxel over (classes A/B)
   int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
@@ -465,10 +466,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     int n_min = 0, big = -1;  // later rounds: candidate pairs all involve a vertex outside the largest active segment
     float cut_lo = 0.0f;
     // first shell: about shell0/2 pairs per vertex on a surface (pairs within d of each other ~ m^2 d^2 / (2 R^2)),
-    // but never more than ~60 % of the list
+    // but never more than cap_frac of the list
     float cut_hi = P.shell0 * P.r2_graph / (float)m;
     {
-      const float cap = 2.0f * (0.6f * (float)LCAP) * P.r2_graph / ((float)m * (float)m);
+      const float cap = 2.0f * (P.cap_frac * (float)LCAP) * P.r2_graph / ((float)m * (float)m);
       cut_hi = cut_hi < cap ? cut_hi : cap;
     }
     int shrink = 0;
