@@ -9,11 +9,15 @@
 #include <vector>
 
 #include "vgs_segmentation.hpp"
+#include "vgs_debug_export.hpp"
 
 struct DriverSummary { long points = 0, voxels = 0, supervoxels = 0, clusters = 0, kept = 0, labelled = 0; };
 
+// debug_prefix: when not empty, the reference's three voxel drawings (VS:510, 654, 1016) are written as
+// <prefix>_voxels.ply, <prefix>_clustered_voxels.ply, <prefix>_normals.ply
 inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>& input_vector,
-                           std::vector<std::vector<int>>& clusters_points_idx, DriverSummary* sum = nullptr) {
+                           std::vector<std::vector<int>>& clusters_points_idx, DriverSummary* sum = nullptr,
+                           const std::string& debug_prefix = std::string()) {
   float voxel_size = 0.15f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f, sig_w = 2.0f,
         cut_thred = 0.3f;
   int points_min = 10, adjacency_min = 3, voxels_min = 3;
@@ -52,6 +56,16 @@ inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>&
     for (auto& c : clusters_points_idx) sum->labelled += (long)c.size();
   }
   (void)voxel_centers;
+  if (!debug_prefix.empty()) {
+    pcl::PolygonMesh::Ptr colored_voxels(new pcl::PolygonMesh), clustered_voxels(new pcl::PolygonMesh), normes_voxels(new pcl::PolygonMesh);
+    drawColorMapofVoxels(voxel_structure.ctx(), voxel_size, colored_voxels);
+    drawColorMapofClusteredVoxels(voxel_structure.ctx(), voxel_size, clustered_voxels);
+    drawNormofVoxels(voxel_structure.ctx(), voxel_size, normes_voxels);
+    if (savePolygonMeshPLY(debug_prefix + "_voxels.ply", *colored_voxels) != 0 ||
+        savePolygonMeshPLY(debug_prefix + "_clustered_voxels.ply", *clustered_voxels) != 0 ||
+        savePolygonMeshPLY(debug_prefix + "_normals.ply", *normes_voxels) != 0)
+      return -1;
+  }
   return 0;
 }
 

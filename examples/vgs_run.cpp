@@ -2,7 +2,8 @@
 // (Task_File_VGS.txt / Task_File_SVGS.txt layout), dispatch on its "Method" entry (line 24: 2 = VGS, 3 = SVGS), load
 // the input PCD, segment, write the coloured clusters as PCD -- what `main` around the reference's `test` drivers does
 // with input_vector[12]/[15] (input path / name) and [18]/[21] (output path / name), minus the viewer.
-//   usage: vgs_run <task file> [--in <file.pcd>] [--out <file.pcd>] [--seed <n>] [--ascii]
+//   usage: vgs_run <task file> [--in <file.pcd|.ply>] [--out <file.pcd>] [--seed <n>] [--ascii] [--debug-meshes <prefix>]
+// --debug-meshes (VGS only) also writes the reference's voxel drawings as <prefix>_voxels.ply, _clustered_voxels.ply, _normals.ply.
 // --in / --out replace the path + name entries of the task file (the shipped ones hold Windows paths).
 // Prints "<method> <points> <voxels> <supervoxels> <all clusters> <kept clusters> <labelled points>".
 #include <cstdio>
@@ -16,7 +17,7 @@
 
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: %s <task file> [--in file.pcd] [--out file.pcd] [--seed n] [--ascii]\n", argv[0]); return 2; }
-  std::string in_file, out_file;
+  std::string in_file, out_file, debug_prefix;
   uint64_t seed = 0;
   bool ascii = false;
   for (int a = 2; a < argc; ++a) {
@@ -24,6 +25,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[a], "--out") && a + 1 < argc) out_file = argv[++a];
     else if (!std::strcmp(argv[a], "--seed") && a + 1 < argc) seed = std::strtoull(argv[++a], nullptr, 10);
     else if (!std::strcmp(argv[a], "--ascii")) ascii = true;
+    else if (!std::strcmp(argv[a], "--debug-meshes") && a + 1 < argc) debug_prefix = argv[++a];
     else { std::fprintf(stderr, "unknown argument %s\n", argv[a]); return 2; }
   }
   const std::vector<std::string> task = inputTaskTxtFile(argv[1]);
@@ -43,7 +45,7 @@ int main(int argc, char** argv) {
   std::vector<std::vector<int>> clusters;
   DriverSummary sum;
   try {
-    if (method == 2) segmentationVGS(cloud, task, clusters, &sum);
+    if (method == 2) { if (segmentationVGS(cloud, task, clusters, &sum, debug_prefix) != 0) { std::fprintf(stderr, "cannot write the debug meshes\n"); return 1; } }
     else segmentationSVGS(cloud, task, clusters, &sum);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

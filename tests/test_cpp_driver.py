@@ -83,3 +83,39 @@ def test_task_file_front_end(gpu, tmp_path, method):
     rgb = f["rgb"].view(np.uint32)
     for k in range(len(off) - 1):
         assert len(set(rgb[off[k]:off[k + 1]].tolist())) == 1
+
+
+@pytest.mark.gpu
+def test_debug_meshes(gpu, tmp_path):
+    """vgs_run --debug-meshes: the reference's voxel drawings (voxel_segmentation.h:510, 654, 1016) as PLY."""
+    subprocess.check_call(["make", "-C", CSRC, "-s", "example"])
+    xyz = gpu.scenes.town_scene(40_000)
+    gpu.pcd.write_pcd(tmp_path / "in.pcd", xyz, mode="binary")
+    lines = {12: str(tmp_path) + "/", 15: "in.pcd", 18: str(tmp_path) + "/", 21: "out.pcd", 28: 0.15, 30: 0.5, 32: 0.2, 34: 0.2, 36: 0.2, 38: 0.2,
+             40: 0.2, 42: 2, 44: 0.3, 46: 10, 48: 3, 50: 3}
+    _write_task(tmp_path / "task.txt", 2, lines)
+    subprocess.check_call([RUN, str(tmp_path / "task.txt"), "--debug-meshes", str(tmp_path / "dbg")], stdout=subprocess.DEVNULL)
+    eng = gpu.Engine(gpu.default_params(2)); eng.set_points(xyz); eng.run()
+    used = eng.attributes()["used"].astype(bool)
+    _, kept = eng.node_labels()
+
+    def header(path):
+        h = {}
+        with open(path) as f:
+            for line in f:
+                w = line.split()
+                if w[0] == "element":
+                    h[w[1]] = int(w[2])
+                if w[0] == "end_header":
+                    break
+        return h
+    hv = header(tmp_path / "dbg_voxels.ply")
+    assert hv == {"vertex": 8 * int(used.sum()), "face": 6 * int(used.sum())}
+    hc = header(tmp_path / "dbg_clustered_voxels.ply")
+    assert hc["vertex"] == 8 * int((kept >= 0).sum())
+    hn = header(tmp_path / "dbg_normals.ply")
+    assert hn == {"vertex": 2 * int(used.sum()), "edge": int(used.sum())}
+    # the PLY reader of point_clouds_io.hpp takes the vertices of these files back
+    subprocess.check_call([os.path.join(ROOT, "examples", "pcd_tool"), "convert", str(tmp_path / "dbg_voxels.ply"), str(tmp_path / "v.pcd"), "binary"])
+    f, _ = gpu.pcd.read_pcd(tmp_path / "v.pcd")
+    assert f["x"].size == hv["vertex"]
