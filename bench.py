@@ -57,7 +57,7 @@ def cpu_baseline(v, xyz_full, params, target_points=150_000):
 
 
 def profiled_traffic(n_points):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json,
+    """HBM bytes (and VALU wave instructions) per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json,
     written by tools/collect_profiles.sh from FETCH_SIZE + WRITE_SIZE of the same bench command); None if the profile
     is missing or was taken on another workload."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
@@ -66,9 +66,9 @@ def profiled_traffic(n_points):
             t = json.load(f)
         if int(t.get("points", -1)) != int(n_points):
             return None
-        return float(t["hbm_bytes_per_launch"])
+        return float(t["hbm_bytes_per_launch"]), t.get("valu_wave_instructions_per_launch")
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def main():
@@ -166,7 +166,9 @@ def main():
         alg_bytes = int(alg_run * (c["class_a"] / max(c["used"], 1)))
         k_avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        traffic = profiled_traffic(N) if world == 1 else None
+        traffic, valu = profiled_traffic(N) if world == 1 else (None, None)
+        # the kernel is VALU-issue bound: wave64 instructions take 4 cycles on the 1024 16-lane SIMDs (2.4 GHz peak clock)
+        valu_frac = (valu * 4.0 / 1024.0 / 2.4e9) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
         out = {
             "metric": "segmented points/sec (end-to-end VGS)",
             "value": total_points / elapsed,
@@ -186,6 +188,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,384> (local affinity graph + threshold-merge cut, bulk class)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
+                         "valu_issue_frac": valu_frac,
                          "algorithmic_bytes_per_step": alg_run,
                          "end_to_end_frac": alg_run / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "pair_evals_per_s": c["pairs"] / (k_avg_ms * 1e-3) if k_avg_ms > 0 else 0.0},

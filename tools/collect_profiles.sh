@@ -34,8 +34,9 @@ dom = [k for k in acc if k.startswith("void k_localcut_wave<96")]
 if dom:
     k = dom[0]
     fetch_kb = acc[k]["FETCH_SIZE"] / calls[(k, "FETCH_SIZE")]; write_kb = acc[k]["WRITE_SIZE"] / calls[(k, "WRITE_SIZE")]
+    valu = acc[k]["SQ_INSTS_VALU"] / calls[(k, "SQ_INSTS_VALU")] if (k, "SQ_INSTS_VALU") in calls else None
     json.dump({"kernel": k[:40], "points": 10000000, "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
-               "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0,
+               "hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0, "valu_wave_instructions_per_launch": valu,
                "note": "FETCH_SIZE + WRITE_SIZE (KB) from separate rocprofv3 --pmc passes of the bench command; raw counters, no 2x wide-load correction (the kernel gathers 8-byte row entries and 16-byte record quarters, not 16 B/lane streams)"},
               open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 PY
