@@ -1,0 +1,101 @@
+"""BASELINE.json's full-size configurations, checked through properties that need no oracle (the CPU oracle takes
+hours there): determinism, idempotence, label / voxel / cluster bookkeeping that must hold for any input, and -- where
+the lists fit in host memory -- the mutual-connection and connected-component structure of the result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_twice(gpu, xyz, p, svgs=False):
+    a = gpu.Engine(p); a.set_points(xyz)
+    if svgs:
+        a.supervoxels()
+    a.run()
+    la = a.point_labels()
+    a.run()                                    # idempotent on the same context
+    assert np.array_equal(la, a.point_labels())
+    b = gpu.Engine(p); b.set_points(xyz)       # deterministic across contexts (atomics, hand-over order, stream timing)
+    if svgs:
+        b.supervoxels()
+    b.run()
+    assert np.array_equal(la, b.point_labels())
+    return a, la
+
+
+def _bookkeeping(eng, labels, voxels_min, filtered=True):
+    c = eng.counts()
+    kept = c["kept"]
+    assert labels.min() >= -1 and labels.max() == kept - 1
+    assert np.array_equal(np.unique(labels[labels >= 0]), np.arange(kept))        # every kept cluster owns points
+    pv = eng.point_voxel()
+    root, node_kept = eng.node_labels()
+    ok = pv >= 0
+    assert np.array_equal(labels[ok], node_kept[pv[ok]])                           # a point carries its voxel's label
+    assert (labels[~ok] == -1).all()
+    assert (root[root] == root).all() and (root <= np.arange(root.size)).all()     # roots are fixed points, smallest id of the cluster
+    sizes = np.bincount(root, minlength=root.size)
+    assert c["clusters"] == int((sizes > 0).sum())
+    if filtered:                                                                   # VS:969: clusters with > voxels_min voxels are kept
+        assert np.array_equal(node_kept >= 0, sizes[root] > voxels_min)
+    off, idx = eng.clusters()                                                      # getClusterIdx partitions the labelled points
+    assert len(off) == kept + 1 and off[-1] == int((labels >= 0).sum())
+    assert np.array_equal(np.sort(idx), np.nonzero(labels >= 0)[0])
+    for k in (0, kept // 2, kept - 1):
+        assert (labels[idx[off[k]:off[k + 1]]] == k).all()
+    return root
+
+
+def _graph_structure(eng, root):
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    V = root.size
+    off, idx = eng.lists("connect_cross")
+    src = np.repeat(np.arange(V), np.diff(off))
+    multi = np.diff(off)[src] > 1                                                  # lists of length <= 1 are left alone (VS:2120)
+    a, b = src[multi], idx[multi]
+    fwd = set(zip(a.tolist(), b.tolist()))
+    assert all((y, x) in fwd for x, y in list(fwd)[:200000] if x != y and (np.diff(off)[y] > 1))   # crossValidation: mutual
+    off, idx = eng.lists("connect_final")
+    src = np.repeat(np.arange(V), np.diff(off))
+    g = coo_matrix((np.ones(idx.size, np.int8), (src, idx)), shape=(V, V))
+    n_comp, comp = connected_components(g, directed=False)
+    first = np.full(n_comp, V, dtype=np.int64)
+    np.minimum.at(first, comp, np.arange(V))
+    assert np.array_equal(first[comp], root)                                       # clusters = components of the final connections
+
+
+def test_config2_pc1m(gpu):
+    xyz = gpu.scenes.pc_scene(1_000_000)
+    p = gpu.default_params(2, voxel_size=0.05)
+    eng, labels = _run_twice(gpu, xyz, p)
+    root = _bookkeeping(eng, labels, p.voxels_min)
+    _graph_structure(eng, root)
+    c = eng.counts()
+    assert c["class_bc"] > 30_000 and c["class_d"] > 0                             # the wide-neighbourhood kernels carry this config
+
+
+def test_config3_urb10m(gpu):
+    xyz = gpu.scenes.urban_scene(10_000_000)
+    p = gpu.default_params(2, voxel_size=0.1)
+    eng, labels = _run_twice(gpu, xyz, p)
+    _bookkeeping(eng, labels, p.voxels_min)
+    c = eng.counts()
+    assert c["points"] == 10_000_000 and c["voxels"] > 500_000 and 100 < c["kept"] < 5000
+    assert (labels >= 0).mean() > 0.7                                              # the scene is mostly large surfaces (trees and clutter drop out)
+
+
+def test_config4_svgs10m(gpu):
+    xyz = gpu.scenes.urban_scene(10_000_000)
+    p = gpu.default_params(3)
+    eng, labels = _run_twice(gpu, xyz, p, svgs=True)
+    c = eng.counts()
+    assert c["supervoxels"] > 50_000
+    sv, mx = eng.supervoxel_labels()
+    assert sv.min() >= 0 and sv.max() <= mx and mx == c["supervoxels"] + 1          # labels 1..max_label, the last one is not a node (SS:313)
+    # every point of one supervoxel carries one segment label (label == max_label is dropped by the reference, SS:313)
+    ok = (sv > 0) & (sv < mx)
+    first = np.full(mx + 1, -2, dtype=np.int64)
+    first[sv[ok]] = labels[ok]
+    assert np.array_equal(first[sv[ok]], labels[ok])
+    assert (labels[~ok] == -1).all()
