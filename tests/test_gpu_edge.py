@@ -104,3 +104,38 @@ def test_limits_are_reported_not_silently_wrong(gpu):
     eng2 = gpu.Engine(gpu.default_params(2)); eng2.set_points(far)
     with pytest.raises(gpu.VgsError):
         eng2.run()
+
+
+def test_dense_volume_adjacency_second_pass(gpu, oracle):
+    """A solid block of points: the search ball (radius 8 voxels, 2109 lattice cells) is full, more neighbours than the
+    first adjacency pass holds (2048), so the rows go through the second pass; the lists must equal the oracle's."""
+    rng = np.random.default_rng(12)
+    xyz = (rng.uniform(0, 1, (400_000, 3)) * np.array([1.3, 1.3, 1.3]) + np.array([1.0, -2.0, 0.2])).astype(np.float32)
+    p = gpu.default_params(2, voxel_size=0.0625, graph_size=0.5)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.voxelize(); eng.features(); eng.adjacency()
+    ref = oracle.run_vgs_adjacency(xyz, oracle_params(oracle, p)) if hasattr(oracle, "run_vgs_adjacency") else None
+    off, idx = eng.lists("adjacency")
+    n = np.diff(off)
+    assert n.max() > 2048                     # the case is what it claims to be
+    if ref is not None:
+        roff, ridx = ref.lists("adjacency")
+        assert np.array_equal(off, roff) and np.array_equal(idx, ridx)
+    else:
+        # independent check with a KD-tree on the voxel centres (float32 centres, FLANN's d2 < float(r*r) predicate)
+        from scipy.spatial import cKDTree
+        cen = eng.voxel_centers().astype(np.float64)
+        used = eng.attributes()["used"].astype(bool)
+        tree = cKDTree(cen)
+        probe = np.nonzero(used)[0][:: max(1, used.sum() // 300)]
+        for v in probe:
+            cand = np.array(tree.query_ball_point(cen[v], 0.5 + 1e-4), dtype=np.int64)
+            d = (cen[cand].astype(np.float32) - cen[v].astype(np.float32))
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            want = cand[d2 < np.float32(0.25)]
+            got = idx[off[v]:off[v + 1]]
+            assert set(got.tolist()) == set(want.tolist())
+            gd = (cen[got].astype(np.float32) - cen[v].astype(np.float32))
+            gd2 = (gd[:, 0] * gd[:, 0] + gd[:, 1] * gd[:, 1]) + gd[:, 2] * gd[:, 2]
+            assert (np.diff(gd2) >= 0).all()  # getOneVoxelAdjacency order: ascending distance

@@ -29,13 +29,17 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   const NodeRec* __restrict__ node, int adj_stride,
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                   uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
-                                                  const int32_t* __restrict__ nvals) {
+                                                  const int32_t* __restrict__ nvals, const uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo,
+                                                  uint32_t* __restrict__ redo_out) {
+  // redo != null: second pass over the rows that did not fit the first pass's list (their number is read on the device);
+  // redo_out != null: first pass, rows with more than CAP survivors are appended there instead of being written
   __shared__ uint64_t lst[CAP];
   __shared__ uint8_t gl[CAP];    // integer squared length of each survivor's lattice offset (the table is sorted by it)
   __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
   const int lane = threadIdx.x;
-  const int64_t u = vgs_xcd_item(blockIdx.x, U);
-  if (u >= U) return;
+  int64_t u;
+  if (redo) { if (blockIdx.x >= *n_redo) return; u = (int64_t)redo[blockIdx.x]; }
+  else { u = vgs_xcd_item(blockIdx.x, U); if (u >= U) return; }
   const uint32_t i = used_ids[u];
   const uint64_t code = vox_code[i];
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
@@ -79,12 +83,16 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
     const unsigned long long mall = __ballot(keep);
     const bool store = FULL ? keep : (keep && is_used);
     const unsigned long long m = __ballot(store);
-    if (store) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); lst[pos] = key64; gl[pos] = (uint8_t)norm; }
+    if (store) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); if (pos < CAP) { lst[pos] = key64; gl[pos] = (uint8_t)norm; } }
     cnt += __popcll(m);
     mused += __popcll(mall);
   }
   uint64_t* row = adj_key + (int64_t)u * adj_stride;
   __syncthreads();
+  if (cnt > CAP) {  // dense volumetric neighbourhood: the pass with the full-size list takes this row
+    if (lane == 0 && redo_out) redo_out[atomicAdd(n_redo, 1u)] = (uint32_t)u;
+    return;
+  }
   if (__ballot(!in_band) == 0ull) {
     // The survivors arrive grouped by the integer length of their offset, and the groups cannot interleave in float d2:
     // only the order inside a group (a handful of entries: equal lengths, keys differ in rounding and id) is open.  Each
@@ -202,13 +210,23 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     VGS_HIP_TRY(c, c->adj_gtab.ensure((size_t)U * c->adj_gstride));
     gt = c->adj_gtab.p;
   }
-#define LAUNCH_ADJ(CAPV, FULLV)                                                                                              \
-  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,    \
+#define LAUNCH_ADJ(CAPV, FULLV, GRID, REDO, NREDO, REDO_OUT)                                                                 \
+  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(GRID), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,            \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
-                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p)
+                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
-  if (c->n_off <= 1024) { if (full) LAUNCH_ADJ(1024, true); else LAUNCH_ADJ(1024, false); }
-  else if (c->n_off <= 8192) { if (full) LAUNCH_ADJ(8192, true); else LAUNCH_ADJ(8192, false); }
+  if (c->n_off <= 1024) {
+    if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);
+  } else if (c->n_off <= 8192) {
+    // A list for every lattice offset (72 KB of LDS) leaves two wavefronts per CU; surfaces fill a fraction of the ball,
+    // so the first pass runs with 2048 slots (18 KB) and hands rows that overflow to a second pass over a device-side list
+    VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
+    unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
+    VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
+    if (full) LAUNCH_ADJ(2048, true, vgs_xcd_grid(U), nullptr, d_nredo, c->work_ids.p); else LAUNCH_ADJ(2048, false, vgs_xcd_grid(U), nullptr, d_nredo, c->work_ids.p);
+    const unsigned int g2 = (unsigned int)U;   // upper bound; workgroups beyond the list leave at once
+    if (full) LAUNCH_ADJ(8192, true, g2, c->work_ids.p, d_nredo, nullptr); else LAUNCH_ADJ(8192, false, g2, c->work_ids.p, d_nredo, nullptr);
+  }
   else { c->err = "neighbour ball larger than 8192 lattice offsets (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
 #undef LAUNCH_ADJ
   VGS_HIP_TRY(c, hipGetLastError());
