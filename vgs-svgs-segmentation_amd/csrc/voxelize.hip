@@ -117,6 +117,19 @@ __global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, i
   if ((threadIdx.x & 63) == 0 && best < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, best);
 }
 
+// after a scan: publish the index found together with that point's coordinates (one host read per growth step) and
+// re-arm the search word for the next scan
+__global__ void k_fetch_violation(const float* __restrict__ xyz, int stride_f, unsigned long long* __restrict__ result,
+                                  unsigned long long* __restrict__ out_idx, float* __restrict__ out_pt) {
+  const unsigned long long idx = *result;
+  *out_idx = idx;
+  if (idx != ~0ull) {
+    const float* p = xyz + (int64_t)idx * stride_f;
+    out_pt[0] = p[0]; out_pt[1] = p[1]; out_pt[2] = p[2];
+  }
+  *result = ~0ull;
+}
+
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
 __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const EpochTable* __restrict__ ep,
                              double res, int code_bits, uint64_t* __restrict__ code, uint32_t* __restrict__ perm) {
@@ -190,12 +203,12 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
     }
   }
   VGS_HIP_TRY(c, c->counters.ensure(64));
-  unsigned long long* d_res = (unsigned long long*)c->counters.p;
+  unsigned long long* d_res = (unsigned long long*)c->counters.p;         // search word (smallest violating index so far)
+  unsigned long long* d_out = (unsigned long long*)c->counters.p + 1;     // published: index, then the point (3 floats)
   int64_t start = 0;
-  float pt[3];
+  struct { unsigned long long idx; float pt[4]; } found;
+  VGS_HIP_TRY(c, hipMemsetAsync(d_res, 0xff, sizeof(unsigned long long), c->stream));
   for (int iter = 0; iter < 4096; ++iter) {
-    unsigned long long none = ~0ull;
-    VGS_HIP_TRY(c, hipMemcpyAsync(d_res, &none, sizeof(none), hipMemcpyHostToDevice, c->stream));
     BoxD b;
     for (int a = 0; a < 3; ++a) { b.min[a] = box.min[a]; b.max[a] = box.max[a]; }
     b.defined = box.defined ? 1 : 0;
@@ -205,12 +218,13 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
       if (!b.defined) blocks = std::min(blocks, 8);  // every finite point violates an undefined box: the first one is near `start`
       hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, start, c->N, b, d_res);
     }
-    unsigned long long idx = ~0ull;
-    VGS_HIP_TRY(c, hipMemcpyAsync(&idx, d_res, sizeof(idx), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(k_fetch_violation, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_res, d_out, (float*)(d_out + 1));
+    VGS_HIP_TRY(c, hipMemcpyAsync(&found, d_out, 8 + 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned long long idx = found.idx;
+    const float* pt = found.pt;
     if (idx == ~0ull) break;
     if (c->grid_pinned && record_epochs) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
-    VGS_HIP_TRY(c, hipMemcpy(pt, c->xyz + (int64_t)idx * c->stride_f, 3 * sizeof(float), hipMemcpyDeviceToHost));
     box.adopt(pt);
     if (record_epochs) {
       Epoch e; e.first = (int64_t)idx;
