@@ -104,6 +104,7 @@ struct vgs_ctx {
   DevBuf<uint64_t> code_a, code_b;
   DevBuf<uint32_t> perm_a, perm_b;
   DevBuf<uint8_t> sort_tmp;
+  DevBuf<uint64_t> grow_state;         // GrowState of the box growth (voxelize.hip)
   DevBuf<uint32_t> head_flag, pt_vox;  // per sorted position
   DevBuf<uint64_t> vox_code;
   DevBuf<uint32_t> vox_start;

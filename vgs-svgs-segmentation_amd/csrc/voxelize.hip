@@ -67,21 +67,39 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
          (vm_bits(z) & 0x7f800000u) != 0x7f800000u;
 }
 
-struct BoxD { double min[3], max[3]; int defined; };
+// The growth of the octree box runs on the device: a scan finds the smallest index of a finite point outside the box,
+// one thread replays PCL's growth rule (OctreeBox::adopt, same double arithmetic) for that point and records the
+// epoch, the next scan starts behind it.  The host queues a batch of (scan, adopt) pairs and reads the state once;
+// pairs queued after the last growth return at once.
+struct GrowState {
+  double min[3], max[3], res;
+  unsigned long long shift[3];
+  unsigned long long found;      // search word of the running scan (smallest violating index, ~0 = none)
+  long long start;               // next scan starts here
+  int depth, defined, done, n_epochs, record, overflow;
+  Epoch epochs[VGS_MAX_EPOCHS];
+};
 
-// smallest index >= start of a finite point outside the box (or any finite point if the box is undefined)
-// Packed xyz (12-byte points) is read as three 16-byte loads per four points; the running answer is polled once per trip.
-__device__ __forceinline__ bool fv_outside(float x, float y, float z, const BoxD& box) {
+struct BoxD { double min[3], max[3]; int defined; };
+__device__ __forceinline__ bool fv_outside(float x, float y, float z, const BoxD& g) {
   if (!finite3(x, y, z)) return false;
-  return !box.defined || (double)x < box.min[0] || (double)x >= box.max[0] || (double)y < box.min[1] ||
-         (double)y >= box.max[1] || (double)z < box.min[2] || (double)z >= box.max[2];
+  return !g.defined || (double)x < g.min[0] || (double)x >= g.max[0] || (double)y < g.min[1] ||
+         (double)y >= g.max[1] || (double)z < g.min[2] || (double)z >= g.max[2];
 }
 
-__global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t start, int64_t n, BoxD box,
-                                  unsigned long long* __restrict__ result) {
+// Packed xyz (12-byte points) is read as three 16-byte loads per four points; the running answer is polled once per trip.
+__global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t n, GrowState* __restrict__ gs) {
+  if (gs->done) return;
+  BoxD box;   // a private copy: the search word below lives in the same structure
+  for (int a = 0; a < 3; ++a) { box.min[a] = gs->min[a]; box.max[a] = gs->max[a]; }
+  box.defined = gs->defined;
+  unsigned long long* result = &gs->found;
+  const int64_t start = gs->start;
   unsigned long long best = ~0ull;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  // an undefined box is violated by every finite point: the first one is near `start`, a few workgroups are enough
+  const int64_t nthreads = box.defined ? (int64_t)gridDim.x * blockDim.x : (int64_t)8 * blockDim.x;
+  if (tid >= nthreads) return;
   if (stride_f == 3 && (((uintptr_t)xyz) & 15u) == 0) {
     // groups of four points = 48 bytes = three float4; group g holds points 4g .. 4g+3
     const float4* q = (const float4*)xyz;
@@ -117,17 +135,52 @@ __global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, i
   if ((threadIdx.x & 63) == 0 && best < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, best);
 }
 
-// after a scan: publish the index found together with that point's coordinates (one host read per growth step) and
-// re-arm the search word for the next scan
-__global__ void k_fetch_violation(const float* __restrict__ xyz, int stride_f, unsigned long long* __restrict__ result,
-                                  unsigned long long* __restrict__ out_idx, float* __restrict__ out_pt) {
-  const unsigned long long idx = *result;
-  *out_idx = idx;
-  if (idx != ~0ull) {
-    const float* p = xyz + (int64_t)idx * stride_f;
-    out_pt[0] = p[0]; out_pt[1] = p[1]; out_pt[2] = p[2];
+// one thread: OctreeBox::adopt for the point the scan found (the same statements in the same order, double arithmetic)
+__global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned) {
+  if (g->done) return;
+  const unsigned long long idx = g->found;
+  g->found = ~0ull;
+  if (idx == ~0ull) { g->done = 1; return; }
+  if (pinned) { g->done = 2; return; }   // a point outside a pinned grid: the host reports it
+  const float* pp = xyz + (int64_t)idx * stride_f;
+  const float p[3] = {pp[0], pp[1], pp[2]};
+  const double eps = 1.1920928955078125e-07;   // std::numeric_limits<float>::epsilon()
+  const double res = g->res;
+  while (true) {
+    if (!g->defined) {
+      // first point: box of one voxel around it; (max - min) / res is 1 (or 0 after rounding), so getKeyBitSize gives depth 1
+      for (int a = 0; a < 3; ++a) { g->min[a] = (double)p[a] - res / 2; g->max[a] = (double)p[a] + res / 2; }
+      g->depth = 1;
+      const double side = (double)(1u << g->depth) * res - eps;
+      for (int a = 0; a < 3; ++a) {
+        const double over = (side - (g->max[a] - g->min[a])) / 2.0;
+        g->min[a] -= over;
+        g->max[a] += over;
+      }
+      g->defined = 1;
+      continue;
+    }
+    bool hi[3], any = false;
+    for (int a = 0; a < 3; ++a) {
+      hi[a] = (double)p[a] >= g->max[a];
+      any = any || hi[a] || ((double)p[a] < g->min[a]);
+    }
+    if (!any) break;
+    double side = (double)(1u << g->depth) * res;
+    for (int a = 0; a < 3; ++a)
+      if (!hi[a]) { g->min[a] -= side; g->shift[a] += (1ull << g->depth); }  // old root becomes the upper child
+    g->depth++;
+    side = (double)(1u << g->depth) * res - eps;
+    for (int a = 0; a < 3; ++a) g->max[a] = g->min[a] + side;
+    if (g->depth > 30) break;   // far beyond the supported depth of 21: the host reports it
   }
-  *result = ~0ull;
+  if (g->record) {
+    if (g->n_epochs >= VGS_MAX_EPOCHS) { g->overflow = 1; g->done = 1; return; }
+    Epoch& e = g->epochs[g->n_epochs++];
+    e.first = (int64_t)idx;
+    for (int a = 0; a < 3; ++a) { e.min[a] = g->min[a]; e.shift[a] = g->shift[a]; }
+  }
+  g->start = (long long)idx + 1;
 }
 
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
@@ -194,46 +247,38 @@ __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 // Sequential semantics, parallel execution: only points that fall outside the current box change it, so the
 // device finds the next such point and the host replays PCL's growth rule for it.
 vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
-  if (record_epochs) {
-    c->epochs.clear();
-    if (box.defined) {
-      Epoch e; e.first = 0;
-      for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
-      c->epochs.push_back(e);
-    }
-  }
+  static_assert(sizeof(GrowState) % 8 == 0, "GrowState is copied as 64-bit words");
   VGS_HIP_TRY(c, c->counters.ensure(64));
-  unsigned long long* d_res = (unsigned long long*)c->counters.p;         // search word (smallest violating index so far)
-  unsigned long long* d_out = (unsigned long long*)c->counters.p + 1;     // published: index, then the point (3 floats)
-  int64_t start = 0;
-  struct { unsigned long long idx; float pt[4]; } found;
-  VGS_HIP_TRY(c, hipMemsetAsync(d_res, 0xff, sizeof(unsigned long long), c->stream));
-  for (int iter = 0; iter < 4096; ++iter) {
-    BoxD b;
-    for (int a = 0; a < 3; ++a) { b.min[a] = box.min[a]; b.max[a] = box.max[a]; }
-    b.defined = box.defined ? 1 : 0;
-    if (start < c->N) {
-      int64_t work = c->N - start;
-      int blocks = (int)std::min<int64_t>((work / 4 + 255) / 256 + 1, 4096);
-      if (!b.defined) blocks = std::min(blocks, 8);  // every finite point violates an undefined box: the first one is near `start`
-      hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, start, c->N, b, d_res);
-    }
-    hipLaunchKernelGGL(k_fetch_violation, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_res, d_out, (float*)(d_out + 1));
-    VGS_HIP_TRY(c, hipMemcpyAsync(&found, d_out, 8 + 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const unsigned long long idx = found.idx;
-    const float* pt = found.pt;
-    if (idx == ~0ull) break;
-    if (c->grid_pinned && record_epochs) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
-    box.adopt(pt);
-    if (record_epochs) {
-      Epoch e; e.first = (int64_t)idx;
-      for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
-      c->epochs.push_back(e);
-      if ((int)c->epochs.size() >= VGS_MAX_EPOCHS) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
-    }
-    start = (int64_t)idx + 1;
+  VGS_HIP_TRY(c, c->grow_state.ensure(sizeof(GrowState) / 8));
+  GrowState* d_g = (GrowState*)c->grow_state.p;
+  static thread_local GrowState h;   // 7 KB: not on the stack
+  std::memset(&h, 0, sizeof(h));
+  for (int a = 0; a < 3; ++a) { h.min[a] = box.min[a]; h.max[a] = box.max[a]; h.shift[a] = box.shift[a]; }
+  h.res = box.res; h.depth = box.depth; h.defined = box.defined ? 1 : 0;
+  h.found = ~0ull; h.start = 0; h.record = record_epochs ? 1 : 0;
+  if (record_epochs && box.defined) {
+    Epoch& e = h.epochs[h.n_epochs++];
+    e.first = 0;
+    for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
   }
+  VGS_HIP_TRY(c, hipMemcpyAsync(d_g, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  const int pinned = (c->grid_pinned && record_epochs) ? 1 : 0;
+  const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, 4096));
+  for (int batch = 0; batch < 64; ++batch) {
+    // a scene grows its box about log2(extent / voxel) times; pairs queued after the last growth return at once
+    for (int k = 0; k < 8; ++k) {
+      hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g);
+      hipLaunchKernelGGL(k_adopt, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_g, pinned);
+    }
+    VGS_HIP_TRY(c, hipMemcpyAsync(&h, d_g, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h.done) break;
+  }
+  if (h.done == 2) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
+  if (h.overflow || !h.done) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
+  for (int a = 0; a < 3; ++a) { box.min[a] = h.min[a]; box.max[a] = h.max[a]; box.shift[a] = h.shift[a]; }
+  box.depth = h.depth; box.defined = h.defined != 0;
+  if (record_epochs) c->epochs.assign(h.epochs, h.epochs + h.n_epochs);
   return VGS_OK;
 }
 
