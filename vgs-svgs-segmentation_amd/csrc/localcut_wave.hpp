@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   __shared__ float cx[MAXM], cy[MAXM], cz[MAXM];  // centroids; cx = NaN when the position is unusable (VS:1829)
   __shared__ float thr[MAXM];
   __shared__ uint32_t claim[MAXM];                // merge: first undecided edge of the step touching a segment (all ones between uses)
-  __shared__ uint32_t gid[MAXM];                  // global voxel ids: the few pairs that get a full evaluation read their records through L2
+  constexpr bool GID_LDS = MAXM <= 128;           // wide classes read the id from the adjacency row instead: 2-4 KB less, one more workgroup per CU
+  __shared__ uint32_t gid[GID_LDS ? MAXM : 1];    // global voxel ids: the few pairs that get a full evaluation read their records through L2
   __shared__ pid_t lp[LCAP];
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
   __shared__ idx_t alist[MAXM];  // vertices whose segment can still merge (ascending)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
 #endif
 
   // ---- the neighbourhood in adjacency order (the adjacency stage already dropped inert unused voxels) ----
-  auto R = [&](int v) -> const NodeRec& { return node[gid[v]]; };
+  auto R = [&](int v) -> const NodeRec& { return node[GID_LDS ? gid[v] : (uint32_t)row[v]]; };
   const int m = n;
   if (m > MAXM || (P.dbg_max_m > 0 && m > P.dbg_max_m)) {  // beyond this kernel's arrays: hand over to the general kernel
     if (threadIdx.x == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);  // cut / size, looked up across lanes
   for (int c = (int)threadIdx.x; c < m; c += 64 * NW) {
     const uint32_t t = (uint32_t)row[c];
-    gid[c] = t;
+    if (GID_LDS) gid[c] = t;
     seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c; claim[c] = 0xffffffffu;
     const NodeRec& rc = node[t];
     cx[c] = (rc.flags & VGS_F_POS) ? rc.c[0] : vm_nan();
