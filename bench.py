@@ -185,7 +185,7 @@ def main():
             "config": {"workload": workload, "points_per_gpu": n_per, "voxels": V, "used_voxels": c["used"], "adjacency_entries": E,
                        "segments": c["kept"], "pair_evaluations": c["pairs"],
                        "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles, shared grid, one all-gather of boundary labels"},
-            "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,384> (local affinity graph + threshold-merge cut, bulk class)",
+            "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,448,1> (local affinity graph + threshold-merge cut, bulk class)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
                          "valu_issue_frac": valu_frac,

@@ -68,7 +68,7 @@ enum {
 enum {
   VGS_T_VOXELIZE = 0, VGS_T_FEATURES = 1, VGS_T_ADJACENCY = 2, VGS_T_LOCALCUT = 3, VGS_T_MERGE = 4,
   VGS_T_LABELS = 5, VGS_T_TOTAL = 6, VGS_T_LOCALCUT_KERNEL = 7, VGS_T_SUPERVOXEL = 8,
-  VGS_T_LOCALCUT_BULK = 9, /* the one launch of the bulk-class local-cut kernel (k_localcut_wave<96,384>), HIP events on its stream */
+  VGS_T_LOCALCUT_BULK = 9, /* the one launch of the bulk-class local-cut kernel (k_localcut_wave<96,448,1>), HIP events on its stream */
   VGS_T_COUNT = 12
 };
 

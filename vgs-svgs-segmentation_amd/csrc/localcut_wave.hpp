@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   __shared__ float cx[MAXM], cy[MAXM], cz[MAXM];  // centroids; cx = NaN when the position is unusable (VS:1829)
   __shared__ float thr[MAXM];
   __shared__ uint32_t claim[MAXM];                // merge: first undecided edge of the step touching a segment (all ones between uses)
-  constexpr bool GID_LDS = MAXM <= 128;           // wide classes read the id from the adjacency row instead: 2-4 KB less, one more workgroup per CU
+  constexpr bool GID_LDS = false;  // ids are read from the adjacency row (L2) when a record is needed: the LDS copy bought nothing and costs list slots
   __shared__ uint32_t gid[GID_LDS ? MAXM : 1];    // global voxel ids: the few pairs that get a full evaluation read their records through L2
   __shared__ pid_t lp[LCAP];
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
