@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -96,7 +97,10 @@ inline bool parse_pcd_header(std::istream& f, PcdHeader& h, std::string& err) {
   for (size_t k = 0; k < names.size(); ++k) {
     PcdField fd; fd.name = names[k]; fd.size = sizes[k]; fd.type = types[k]; fd.count = counts[k]; fd.offset = off;
     if (fd.size != 1 && fd.size != 2 && fd.size != 4 && fd.size != 8) { err = "PCD header: unsupported SIZE"; return false; }
+    // COUNT < 1 would give a negative or zero field offset (reads before the point), a huge COUNT an overflowed point size
+    if (fd.count < 1 || fd.count > (1 << 16)) { err = "PCD header: COUNT must be in [1, 65536]"; return false; }
     off += fd.size * fd.count;
+    if (off > (1 << 16)) { err = "PCD header: a point takes more than 65536 bytes"; return false; }
     h.fields.push_back(fd);
   }
   h.point_size = off;
@@ -125,15 +129,19 @@ inline int read_pcd_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
   }
   if (fx < 0 || fy < 0 || fz < 0) { err = "PCD file has no x / y / z fields"; return -1; }
   const size_t n = (size_t)h.points;
+  uint64_t left = 0;   // bytes of the file behind the header
   {
     // a corrupt header must not turn into a huge allocation: every point takes at least two bytes of the file
     const std::streampos here = f.tellg();
     f.seekg(0, std::ios::end);
-    const uint64_t left = (uint64_t)(f.tellg() - here);
+    left = (uint64_t)(f.tellg() - here);
     f.seekg(here);
     if (h.data != "binary_compressed" && (uint64_t)n > left) { err = "PCD header announces more points than the file can hold"; return -1; }
-    if (h.data == "binary_compressed" && (uint64_t)n > 64u * left + 64u) { err = "PCD header announces more points than the file can hold"; return -1; }
+    if (h.data == "binary" && (uint64_t)n * (uint64_t)h.point_size > left) { err = "PCD binary body is truncated"; return -1; }
+    // LZF expands a byte at most 264 / 3 times (a three-byte back reference of the maximum length)
+    if (h.data == "binary_compressed" && (uint64_t)n * (uint64_t)h.point_size > 88u * left + 64u) { err = "PCD header announces more points than the file can hold"; return -1; }
   }
+  try {
   pts.assign(n, pcl::PointXYZ());
   if (h.data == "ascii") {
     std::string line;
@@ -168,6 +176,7 @@ inline int read_pcd_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
     uint32_t csize = 0, usize = 0;
     f.read((char*)&csize, 4); f.read((char*)&usize, 4);
     if (!f || (size_t)usize != n * (size_t)h.point_size) { err = "PCD binary_compressed: bad size words"; return -1; }
+    if ((uint64_t)csize + 8u > left) { err = "PCD binary_compressed body is truncated"; return -1; }
     std::vector<unsigned char> in(csize), out(usize);
     f.read((char*)in.data(), csize);
     if ((size_t)f.gcount() != (size_t)csize) { err = "PCD binary_compressed body is truncated"; return -1; }
@@ -181,6 +190,10 @@ inline int read_pcd_xyz(const std::string& name, std::vector<pcl::PointXYZ>& pts
     }
   } else {
     err = "unsupported PCD DATA '" + h.data + "'";
+    return -1;
+  }
+  } catch (const std::bad_alloc&) {
+    err = "PCD file is too large for this host's memory";
     return -1;
   }
   if (width) *width = (uint32_t)h.width;

@@ -150,9 +150,10 @@ vgs_status vgs_set_grid(vgs_ctx* ctx, const vgs_grid_state* g);
  * their own connections are not trusted).  Components are then built from the connections that have an owned
  * endpoint, cluster sizes count owned voxels, and point labels wait for vgs_apply_root_labels. */
 vgs_status vgs_set_owned_region(vgs_ctx* ctx, const double* lo_xy, const double* hi_xy);
-/* after vgs_segment: one record (global voxel code, local component root) for both endpoints of every final
- * connection that crosses the ownership border.  Records of all ranks that share a code name the same segment.
- * Two-call protocol: code == NULL returns the count. */
+/* after vgs_segment: (global voxel code, local component root) records of the boundary voxels -- both endpoints of
+ * every connection that crosses the ownership border, and every owned voxel with a halo voxel in its neighbourhood
+ * (a possible closestCheck target of the neighbouring rank); duplicates possible.  Records of all ranks that share
+ * a code name the same segment.  Two-call protocol: code == NULL returns the count. */
 vgs_status vgs_get_boundary(vgs_ctx* ctx, int64_t* n_records, uint64_t* code, int32_t* root);
 /* local component roots that contain owned voxels, with the number of owned voxels (two-call protocol) */
 vgs_status vgs_get_owned_roots(vgs_ctx* ctx, int64_t* n_roots, int32_t* root, int32_t* owned_voxels);

@@ -256,15 +256,13 @@ class SuperVoxelBasedSegmentation {
   // the supervoxel labelling pcl::SupervoxelClustering would produce may also be supplied by the caller
   void setSupervoxelLabels(const std::vector<int32_t>& labels, int max_label) {
     chk(svgs_set_supervoxel_labels(ctx(), labels.data(), max_label), "svgs_set_supervoxel_labels");
-    have_labels_ = true;
   }
   void segmentSupervoxelCloudWithGraphModel(float sig_a, float sig_b, float sig_l, float cut_thred, float sig_p, float sig_n,
                                             float sig_o, float sig_e, float sig_c, float sig_w) {  // SS:362
     p_.color_impt = sig_a; p_.spatial_impt = sig_b; p_.normal_impt = sig_l; p_.cut_thred = cut_thred;
     p_.sig_p = sig_p; p_.sig_n = sig_n; p_.sig_o = sig_o; p_.sig_e = sig_e; p_.sig_c = sig_c; p_.sig_w = sig_w;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
-    if (!have_labels_) chk(svgs_supervoxels(ctx()), "svgs_supervoxels");
-    chk(svgs_segment(ctx()), "svgs_segment");
+    chk(vgs_run(ctx()), "vgs_run");  // createSupervoxels (unless the caller's labelling of THIS cloud is in place), then the graph stages
   }
   std::vector<int32_t> drawColorMapofPointsinClusters() {                                // SS:613
     std::vector<int32_t> lab((size_t)count(VGS_N_POINTS) + 1);
@@ -287,7 +285,6 @@ class SuperVoxelBasedSegmentation {
   vgs_params p_;
   std::unique_ptr<vgs_ctx, vgs_detail::CtxDeleter> ctx_;
   PCXYZPtr cloud_;
-  bool have_labels_ = false;
 };
 
 }  // namespace pcl

@@ -91,3 +91,57 @@ def test_class_mirror(run, gpu):
     np.testing.assert_array_equal(sv.drawColorMapofPointsinClusters(), run["eng"].point_labels())
     assert sv.getClusterNum() == run["eng"].counts()["clusters"]
     assert len(sv.getClusterIdx()) == run["eng"].counts()["kept"]
+
+
+def test_labels_do_not_outlive_their_cloud(gpu):
+    """a supervoxel labelling belongs to the cloud (and, when it came from svgs_supervoxels, to the VCCS
+    parameters) it was made for.  A new cloud or new voxel/seed sizes must trigger a new clustering, never a run over
+    stale labels (with a larger cloud that was an out-of-bounds read)."""
+    from vgs_svgs_segmentation_amd._lib import VgsError
+    small = gpu.scenes.urban_scene(40_000)
+    big = gpu.scenes.urban_scene(90_000, seed=77)
+    p = gpu.default_params(3)
+
+    def fresh(xyz, params):
+        e = gpu.Engine(params)
+        e.set_points(xyz)
+        e.run()
+        return e.point_labels(), e.supervoxel_labels()
+
+    eng = gpu.Engine(p)
+    eng.set_points(small)
+    eng.run()
+    eng.set_points(big)                       # larger cloud: the old labels must be gone
+    with pytest.raises(VgsError):
+        eng.svgs_segment()
+    with pytest.raises(VgsError):
+        eng.supervoxel_labels()
+    eng.run()
+    lab, (sv, mx) = fresh(big, p)
+    np.testing.assert_array_equal(eng.point_labels(), lab)
+    np.testing.assert_array_equal(eng.supervoxel_labels()[0], sv)
+    # new seed size: labels from svgs_supervoxels are recomputed ...
+    q = gpu.default_params(3, seed_size=0.4)
+    eng.set_params(q)
+    eng.run()
+    lab2, (sv2, mx2) = fresh(big, q)
+    assert mx2 != mx
+    np.testing.assert_array_equal(eng.supervoxel_labels()[0], sv2)
+    np.testing.assert_array_equal(eng.point_labels(), lab2)
+    # ... while a caller's own labelling survives parameter changes but not a new cloud
+    labels, max_label = grid_supervoxels(big, 0.25)
+    eng.set_supervoxel_labels(labels, max_label)
+    eng.set_params(p)
+    eng.run()
+    np.testing.assert_array_equal(eng.supervoxel_labels()[0], labels)
+    eng.set_points(small)
+    with pytest.raises(VgsError):
+        eng.svgs_segment()
+
+    # the class mirror asks the context, it keeps no flag of its own
+    sv_cls = gpu.SuperVoxelBasedSegmentation(0.05)
+    for cloud in (small, big):
+        sv_cls.setInputCloud(cloud)
+        sv_cls.addPointsFromInputCloud()
+        sv_cls.segmentSupervoxelCloudWithGraphModel(0.0, 0.25, 0.75, 0.5, 0.2, 0.2, 0.2, 0.2, 0.2, 1.0)
+        np.testing.assert_array_equal(sv_cls.drawColorMapofPointsinClusters(), fresh(cloud, p)[0])

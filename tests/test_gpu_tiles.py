@@ -51,28 +51,19 @@ class FakeDist:
         t.copy_(m)
 
 
-def test_two_tiles_match_single_engine(gpu):
+def _run_tiled(gpu, parts, params_kw, pitch, world=2):
+    """parts[r] = points loaded by rank r; returns per-rank (labels of its own points, kept, counts)."""
     import torch
     from vgs_svgs_segmentation_amd.dist import TiledSegmenter
-    world, n_per = 2, 150_000
-    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
-    tiles = [gpu.scenes.tiled_urban_scene(n_per * world, tiles=(world, 1), tile_index=r) for r in range(world)]
-    p = gpu.default_params(2, voxel_size=0.1)
-    whole = np.concatenate(tiles)
-    eng = gpu.Engine(p)
-    eng.set_points(whole)
-    eng.run()
-    ref = eng.point_labels()
-
     fd = FakeDist(world)
     out, errs = [None] * world, []
 
     def work(r):
         try:
             fd.tls.rank = r
-            d = torch.from_numpy(tiles[r]).to("cuda:0")
-            seg = TiledSegmenter(gpu.default_params(2, voxel_size=0.1), fd, tiles=(world, 1), rank=r, world=world, pitch=pitch)
-            seg.set_points_device(d, tiles[r])
+            d = torch.from_numpy(parts[r]).to("cuda:0")
+            seg = TiledSegmenter(gpu.default_params(2, **params_kw), fd, tiles=(world, 1), rank=r, world=world, pitch=pitch)
+            seg.set_points_device(d, parts[r])
             seg.run()
             out[r] = (seg.point_labels(), seg.kept, seg.engine.counts())
         except Exception as e:  # noqa: BLE001
@@ -85,8 +76,28 @@ def test_two_tiles_match_single_engine(gpu):
     for t in th:
         t.join()
     assert not errs, errs
+    return out
+
+
+def _single(gpu, whole, params_kw):
+    eng = gpu.Engine(gpu.default_params(2, **params_kw))
+    eng.set_points(whole)
+    eng.run()
+    return eng
+
+
+def test_two_tiles_match_single_engine(gpu):
+    world, n_per = 2, 150_000
+    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
+    tiles = [gpu.scenes.tiled_urban_scene(n_per * world, tiles=(world, 1), tile_index=r) for r in range(world)]
+    kw = dict(voxel_size=0.1)
+    whole = np.concatenate(tiles)
+    eng = _single(gpu, whole, kw)
+    ref = eng.point_labels()
+    out = _run_tiled(gpu, tiles, kw, pitch)
     tiled = np.concatenate([out[r][0] for r in range(world)])
     assert out[0][1] == out[1][1]
+    # the tolerance covers closestCheck only (its eligibility test looks one neighbourhood further than the halo)
     agree = partition_agreement(tiled, ref)
     assert agree >= 0.999, agree
     kept_ref = eng.counts()["kept"]
@@ -95,3 +106,97 @@ def test_two_tiles_match_single_engine(gpu):
     left = set(tiled[: n_per][tiled[: n_per] >= 0].tolist())
     right = set(tiled[n_per:][tiled[n_per:] >= 0].tolist())
     assert left & right
+
+    # exact part: everything except closestCheck's candidates (voxels whose list is {self} after crossValidation; a
+    # re-attachment only ever moves the candidate itself) and segments so small that one re-attached voxel decides
+    # whether they pass the `> voxels_min` filter -- labels identical up to renaming, dropped points included
+    off, _ = eng.lists("connect_cross")
+    used = eng.attributes()["used"] != 0
+    cand = used & (np.diff(off) == 1)
+    pv = eng.point_voxel()
+    root, _ = eng.node_labels()
+    seg_size = np.bincount(root, minlength=root.size)[root]          # voxels of the single-engine segment of every voxel
+    ok_vox = (~cand) & ((seg_size >= 8) | (seg_size <= 1))
+    m = (pv >= 0) & ok_vox[np.maximum(pv, 0)]
+    assert m.mean() > 0.85
+    from helpers import canonical_labels
+    a, b = canonical_labels(tiled[m]), canonical_labels(ref[m])
+    assert np.array_equal(a, b), f"{int((a != b).sum())} of {int(m.sum())} points differ outside closestCheck"
+
+
+def _plate_scene(seed=7):
+    """Two ground halves with a gap on the x > 0 side and a small upright plate over the gap, just right of x = 0:
+    the plate's voxel is isolated by the local cut and closestCheck re-attaches it to the ground LEFT of x = 0
+    (designed with the oracle; the test re-checks these preconditions on the single engine's own lists)."""
+    rng = np.random.default_rng(seed)
+    def rect(o, a, b, n):
+        o, a, b = (np.asarray(v, dtype=np.float64) for v in (o, a, b))
+        nrm = np.cross(a, b); nrm /= np.linalg.norm(nrm)
+        return o + rng.random(n)[:, None] * a + rng.random(n)[:, None] * b + (rng.standard_normal(n) * 0.003)[:, None] * nrm
+    dens = 2500.0   # points per m^2 = 25 per voxel face
+    left = rect((-3.0, -2.0, 0.0), (3.0, 0, 0), (0, 4.0, 0), int(12 * dens))
+    right = rect((0.42, -2.0, 0.0), (2.58, 0, 0), (0, 4.0, 0), int(2.58 * 4 * dens))
+    plate = rect((0.06, -0.08, 0.21), (0.0, 0.07, 0), (0.01, 0, 0.08), 40)     # 7 cm x 8 cm, nearly vertical: one voxel
+    pts = np.concatenate([left, right, plate]).astype(np.float32)
+    tag = np.concatenate([np.zeros(len(left), np.int8), np.ones(len(right), np.int8), np.full(len(plate), 2, np.int8)])
+    perm = rng.permutation(len(pts))
+    return pts[perm], tag[perm]
+
+
+def test_reattachment_across_the_border(gpu):
+    """an isolated voxel owned by one rank whose closestCheck target is owned by the other must end up in the
+    target's segment, exactly as in a single engine (the target's owner publishes it although it sees no crossing
+    connection of its own)."""
+    from helpers import canonical_labels
+    pts, tag = _plate_scene()
+    order = np.argsort(pts[:, 0] >= 0.0, kind="stable")   # rank 0's points first: the chained grid then equals the single engine's
+    pts, tag = pts[order], tag[order]
+    kw = dict(voxel_size=0.1)
+    eng = _single(gpu, pts, kw)
+    ref = eng.point_labels()
+    # preconditions of the scene, read from the single engine: some plate voxel is re-attached to a voxel left of x = 0
+    off_c, idx_c = eng.lists("connect_cross")
+    off_f, idx_f = eng.lists("connect_final")
+    cen = eng.voxel_centers()
+    pv = eng.point_voxel()
+    plate_vox = np.unique(pv[(tag == 2) & (pv >= 0)])
+    crossing = []
+    for v in plate_vox:
+        if off_c[v + 1] - off_c[v] == 1 and off_f[v + 1] - off_f[v] > 1:           # {self} before, re-attached after
+            t = int(idx_f[off_f[v] + 1])
+            if cen[v, 0] >= 0.0 and cen[t, 0] < 0.0:
+                crossing.append((int(v), t))
+    assert crossing, "scene precondition: no plate voxel is re-attached across x = 0"
+    own = pts[:, 0] < 0.0
+    parts = [pts[own], pts[~own]]
+    out = _run_tiled(gpu, parts, kw, pitch=3.0)
+    tiled = np.concatenate([out[0][0], out[1][0]])
+    for v, t in crossing:
+        lv, lt = tiled[pv == v], tiled[pv == t]
+        assert lv.min() == lv.max() == lt.min() == lt.max() and lv[0] >= 0, (v, t, lv[:3], lt[:3])
+    assert out[0][1] == out[1][1] == eng.counts()["kept"]
+    a, b = canonical_labels(tiled), canonical_labels(ref)
+    assert np.array_equal(a, b), f"{int((a != b).sum())} of {a.size} point labels differ from the single engine"
+
+
+def test_points_in_voxels_that_straddle_the_border(gpu):
+    """A voxel whose cube reaches over the border holds points loaded by both ranks; the rank that does not own the
+    voxel must still label its points (it learns the label through the owner's boundary record)."""
+    from helpers import canonical_labels
+    rng = np.random.default_rng(11)
+    n = 120_000
+    pts = np.stack([rng.random(n) * 8.0 - 4.0 + 0.037, rng.random(n) * 6.0 - 3.0, rng.standard_normal(n) * 0.003 + 0.5], axis=1).astype(np.float32)
+    pts = pts[np.argsort(pts[:, 0] >= 0.0, kind="stable")]   # rank 0's points first: same lattice as the chained grid
+    kw = dict(voxel_size=0.1)
+    eng = _single(gpu, pts, kw)
+    ref = eng.point_labels()
+    own = pts[:, 0] < 0.0
+    out = _run_tiled(gpu, [pts[own], pts[~own]], kw, pitch=4.0)
+    tiled = np.concatenate([out[0][0], out[1][0]])
+    cen = eng.voxel_centers()
+    pv = eng.point_voxel()
+    foreign = (pv >= 0) & ((cen[np.maximum(pv, 0), 0] < 0.0) != own)    # points loaded by the rank that does not own their voxel
+    assert (foreign & (ref >= 0)).sum() > 100, "scene precondition: the border cuts through used voxels"
+    np.testing.assert_array_equal(tiled[foreign] >= 0, ref[foreign] >= 0)
+    a, b = canonical_labels(tiled), canonical_labels(ref)
+    assert np.array_equal(a, b), f"{int((a != b).sum())} of {a.size} point labels differ from the single engine"

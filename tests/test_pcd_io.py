@@ -102,6 +102,38 @@ def test_reader_rejects_bad_files(tool, pcd, tmp_path):
     assert subprocess.call([tool, "convert", str(comp), str(tmp_path / "o.pcd")], stderr=subprocess.DEVNULL) in (0, 1)   # must not crash
 
 
+@pytest.mark.parametrize("data", ["binary", "binary_compressed", "ascii"])
+@pytest.mark.parametrize("count", ["-1 1 1 1", "0 1 1 1", "1000000000 1 1 1", "70000 1 1 1"])
+def test_reader_rejects_hostile_count(tool, tmp_path, data, count):
+    """COUNT < 1 (negative field offsets) or huge COUNT (overflowed point size) must be a clean error, never a crash."""
+    import struct
+    bad = tmp_path / "count.pcd"
+    head = f"FIELDS pad x y z\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT {count}\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA {data}\n".encode()
+    body = struct.pack("<8f", *range(8)) if data != "ascii" else b"0 1 2 3\n4 5 6 7\n"
+    if data == "binary_compressed":
+        body = struct.pack("<II", 32, 32) + body
+    bad.write_bytes(head + body)
+    assert subprocess.call([tool, "convert", str(bad), str(tmp_path / "o.pcd")], stderr=subprocess.DEVNULL) == 1
+
+
+def test_reader_rejects_oversized_compressed_size_word(tool, pcd, tmp_path):
+    """binary_compressed: a compressed-size word beyond the end of the file must not become a 4 GB allocation."""
+    import struct
+    xyz = _cloud(100, 3)
+    comp = tmp_path / "comp.pcd"
+    pcd.write_pcd(comp, xyz, mode="binary_compressed")
+    blob = bytearray(comp.read_bytes())
+    at = blob.index(b"DATA binary_compressed\n") + len(b"DATA binary_compressed\n")
+    blob[at:at + 4] = struct.pack("<I", 0xFFFFFFF0)
+    comp.write_bytes(bytes(blob))
+    assert subprocess.call([tool, "convert", str(comp), str(tmp_path / "o.pcd")], stderr=subprocess.DEVNULL) == 1
+    # a POINTS value far beyond the file
+    big = tmp_path / "big.pcd"
+    big.write_bytes(b"FIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 4000000000\nHEIGHT 1\nPOINTS 4000000000\nDATA binary_compressed\n"
+                    + struct.pack("<II", 8, 0) + b"\0" * 8)
+    assert subprocess.call([tool, "convert", str(big), str(tmp_path / "o.pcd")], stderr=subprocess.DEVNULL) == 1
+
+
 def test_coloured_cluster_export(tool, pcd, tmp_path):
     xyz = _cloud(500, 5)
     src = tmp_path / "in.pcd"

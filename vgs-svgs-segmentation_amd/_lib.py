@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvgs_hip.so")
+# VGS_LIB names another build of the same library next to this file (the -DVGS_PROF diagnostics build, `make prof`)
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("VGS_LIB", "libvgs_hip.so")))
 CSRC = os.path.join(_HERE, "csrc")
 
 VGS_OK, VGS_E_ARG, VGS_E_STATE, VGS_E_HIP, VGS_E_NOMEM, VGS_E_UNSUPPORTED, VGS_E_IO = range(7)

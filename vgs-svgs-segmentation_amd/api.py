@@ -288,7 +288,6 @@ class SuperVoxelBasedSegmentation:
         self._p = default_params(3, voxel_size=float(input_resolution), device=device)
         self._eng = Engine(self._p)
         self._cloud = None
-        self._have_labels = False
 
     def setInputCloud(self, cloud):
         self._cloud = np.ascontiguousarray(cloud, dtype=np.float32)
@@ -324,7 +323,6 @@ class SuperVoxelBasedSegmentation:
     def setSupervoxelLabels(self, labels, max_label):
         """What pcl::SupervoxelClustering::getLabeledCloud / getMaxLabel return (SS:283-284), supplied by the caller."""
         self._eng.set_supervoxel_labels(labels, max_label)
-        self._have_labels = True
 
     def getVoxelNum(self):                                                            # SS:111
         return self._eng.counts()["voxels"]
@@ -338,9 +336,7 @@ class SuperVoxelBasedSegmentation:
         q.cut_thred, q.sig_p, q.sig_n, q.sig_o, q.sig_e, q.sig_c, q.sig_w = (float(v) for v in (
             cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w))
         self._eng.set_params(q)
-        if not self._have_labels:
-            self._eng.supervoxels()
-        self._eng.svgs_segment()
+        self._eng.run()   # createSupervoxels unless the caller's labelling of THIS cloud is in place, then the graph stages
 
     def drawColorMapofPointsinClusters(self, output_cloud=None):                      # SS:613
         return self._eng.point_labels()

@@ -142,7 +142,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
-  c->owned.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
+  c->owned.release(); c->straddle.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -169,6 +169,8 @@ vgs_status vgs_set_params(vgs_ctx* c, const vgs_params* p) {
       p->spatial_impt != o.spatial_impt || p->normal_impt != o.normal_impt)
     keep = ST_POINTS;
   if (c->stage > keep) c->stage = keep;
+  // labels from svgs_supervoxels depend on voxel_size / seed_size / the three importances; a caller's own labelling does not
+  if (keep == ST_POINTS && c->P.method == 3 && !c->sv_labels_external) { c->sv_have_labels = false; c->sv_max_label = 0; c->sv_label_n = -1; }
   c->P = *p;
   return VGS_OK;
 }
@@ -183,6 +185,8 @@ static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes)
   c->stage = ST_POINTS;
   c->counts[VGS_N_POINTS] = n;
   for (int i = 0; i < VGS_T_COUNT; ++i) c->times[i] = 0;
+  // a supervoxel labelling belongs to the cloud it was made for (SS:279-331 rebuilds it per createSupervoxels call)
+  c->sv_have_labels = false; c->sv_labels_external = false; c->sv_max_label = 0; c->sv_label_n = -1;
   return VGS_OK;
 }
 
@@ -273,7 +277,7 @@ vgs_status svgs_set_supervoxel_labels(vgs_ctx* c, const int32_t* labels_host, in
   VGS_HIP_TRY(c, c->sv_label.ensure(c->N > 0 ? c->N : 1));
   if (c->N > 0) VGS_HIP_TRY(c, hipMemcpy(c->sv_label.p, labels_host, (size_t)c->N * 4, hipMemcpyHostToDevice));
   c->sv_max_label = max_label;
-  c->sv_have_labels = true;
+  c->sv_have_labels = true; c->sv_labels_external = true; c->sv_label_n = c->N;
   if (c->stage > ST_POINTS) c->stage = ST_POINTS;
   return VGS_OK;
 }
@@ -283,14 +287,15 @@ vgs_status svgs_supervoxels(vgs_ctx* c) {
   if (c->P.method != 3) { c->err = "svgs_supervoxels: context was created for method 2 (VGS)"; return VGS_E_STATE; }
   if (c->stage < ST_POINTS) { c->err = "svgs_supervoxels: set the input cloud first"; return VGS_E_STATE; }
   if (!(c->P.seed_size > c->P.voxel_size)) { c->err = "svgs_supervoxels: seed_size must exceed voxel_size"; return VGS_E_ARG; }
+  c->sv_have_labels = false; c->sv_labels_external = false; c->sv_label_n = -1;
   vgs_status s = timed(c, VGS_T_SUPERVOXEL, [&] { return vgs_stage_vccs(c); });
-  if (s == VGS_OK) c->stage = ST_POINTS;
+  if (s == VGS_OK) { c->stage = ST_POINTS; c->sv_label_n = c->N; }
   return s;
 }
 
 vgs_status svgs_get_supervoxel_labels(vgs_ctx* c, int32_t* labels, int32_t* max_label) {
   if (!c || !labels || !max_label) return VGS_E_ARG;
-  if (!c->sv_have_labels) { c->err = "svgs_get_supervoxel_labels: no supervoxel labelling yet"; return VGS_E_STATE; }
+  if (!c->sv_have_labels || c->sv_label_n != c->N) { c->err = "svgs_get_supervoxel_labels: no supervoxel labelling of this cloud yet"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   if (c->N > 0) VGS_HIP_TRY(c, hipMemcpy(labels, c->sv_label.p, (size_t)c->N * 4, hipMemcpyDeviceToHost));
   *max_label = c->sv_max_label;
@@ -301,6 +306,7 @@ vgs_status svgs_segment(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
   if (c->P.method != 3) { c->err = "svgs_segment: context was created for method 2 (VGS)"; return VGS_E_STATE; }
   if (c->stage < ST_POINTS || !c->sv_have_labels) { c->err = "svgs_segment: needs the input cloud and supervoxel labels (createSupervoxels)"; return VGS_E_STATE; }
+  if (c->sv_label_n != c->N) { c->err = "svgs_segment: the supervoxel labels were made for a different cloud"; return VGS_E_STATE; }
   vgs_status s;
   if ((s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_svgs_group(c); })) != VGS_OK) return s;       // SS:279-331
   if ((s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); })) != VGS_OK) return s;         // SS:1238-1303

@@ -1,8 +1,8 @@
 // multigpu.hip -- tile support: shared grid chaining, ownership, boundary records, final labels.
 // The reference is single-process; scenes shard by spatial tile, one context per GPU.  Everything per voxel is
 // local to a ball of radius graph_size, only the connected components are global: each rank segments its tile
-// plus a halo, trusts the connections that have an owned endpoint, and publishes one (voxel code, local root)
-// record per endpoint of every connection that crosses the ownership border.  One all-gather of these records
+// plus a halo, trusts the mutual connections that have an owned endpoint and the re-attachments of its owned voxels,
+// and publishes one (voxel code, local root) record per boundary voxel (k_boundary).  One all-gather of these records
 // (RCCL, done by the host driver) lets every rank run the same small union-find over (rank, root) pairs.
 #include <algorithm>
 #include <cstring>
@@ -13,7 +13,7 @@
 #include "vgs_context.hpp"
 
 __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float res_f, float min_x, float min_y, double lo_x, double lo_y,
-                        double hi_x, double hi_y, uint8_t* __restrict__ owned) {
+                        double hi_x, double hi_y, uint8_t* __restrict__ owned, uint8_t* __restrict__ straddle) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t code = vox_code[v];
@@ -21,25 +21,39 @@ __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float 
   const double cx = (double)vm_voxel_center(vm_compact21(code >> 2), res_f, min_x);
   const double cy = (double)vm_voxel_center(vm_compact21(code >> 1), res_f, min_y);
   owned[v] = (cx >= lo_x && cx < hi_x && cy >= lo_y && cy < hi_y) ? 1 : 0;
+  // the voxel's cube reaches over a border of the region: points on both sides (loaded by different ranks) fall into it
+  const double h = 0.5001 * (double)res_f;
+  straddle[v] = (fabs(cx - lo_x) < h || fabs(cx - hi_x) < h || fabs(cy - lo_y) < h || fabs(cy - hi_y) < h) ? 1 : 0;
 }
 
 vgs_status vgs_compute_owned(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->owned.ensure(c->V > 0 ? c->V : 1));
+  VGS_HIP_TRY(c, c->straddle.ensure(c->V > 0 ? c->V : 1));
   if (c->V == 0) return VGS_OK;
   hipLaunchKernelGGL(k_owned, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, c->V, c->P.voxel_size,
-                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p);
+                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p, c->straddle.p);
   VGS_HIP_TRY(c, hipGetLastError());
   return VGS_OK;
 }
 
-// both endpoints of every final connection (mutual or re-attachment) that crosses the ownership border
+// Boundary voxels of a tile: every voxel through which a local component can continue on another rank.
+//   * a voxel (owned or halo) with a mutual connection to a voxel of the other ownership: both ranks see that
+//     connection exactly (halo = 2*graph_size + voxel_size), both publish both endpoints, each from its own row;
+//   * an owned voxel with a halo voxel in its neighbourhood: it may be the closestCheck target of an isolated voxel
+//     of the neighbouring rank (VS:2293).  Only the owner of the isolated voxel decides that re-attachment, so the
+//     owner of the target cannot know about it and must publish the target unconditionally -- else the other
+//     rank's (target code, root) record finds no partner and the re-attached voxel becomes a one-voxel segment;
+//   * both ends of a re-attachment of an owned voxel to a halo voxel;
+//   * every voxel, used or not, whose cube reaches over the border (k_boundary_straddle): the ranks on both sides hold
+//     points of it, and the rank that does not own it learns its label through the record of the rank that does.
+// At most two records per voxel (duplicates are removed by the sort that follows).
 __global__ __launch_bounds__(64) void k_boundary(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                  const uint32_t* __restrict__ adj_cnt, int adj_stride, const uint8_t* __restrict__ mutual,
                                                  const int32_t* __restrict__ attach, const uint8_t* __restrict__ owned,
                                                  const uint32_t* __restrict__ parent, const uint64_t* __restrict__ vox_code,
                                                  unsigned long long cap, unsigned long long* __restrict__ n_out,
                                                  uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root) {
-  const int64_t u = blockIdx.x;
+  const int64_t u = vgs_xcd_item(blockIdx.x, U);
   if (u >= U) return;
   const int lane = threadIdx.x;
   const uint32_t i = used_ids[u];
@@ -47,38 +61,40 @@ __global__ __launch_bounds__(64) void k_boundary(const uint32_t* __restrict__ us
   const uint64_t* row = adj_key + u * adj_stride;
   const uint8_t* mrow = mutual + u * adj_stride;
   const bool oi = owned[i] != 0;
-  for (int base = 0; base < n + 1; base += 64) {
-    const int k = base + lane;
-    bool cross = false;
-    uint32_t t = 0;
-    if (k < n) {
-      t = (uint32_t)row[k];
-      cross = mrow[k] && t > i && ((owned[t] != 0) != oi);
-    } else if (k == n) {
-      const int32_t a = attach[i];
-      if (a >= 0) { t = (uint32_t)a; cross = oi && !owned[t]; }
-    }
-    const unsigned long long mk = __ballot(cross);
-    if (mk == 0ull) continue;
-    unsigned long long basepos = 0;
-    const int l0 = __ffsll((long long)mk) - 1;
-    if (lane == l0) basepos = atomicAdd(n_out, 2ull * (unsigned long long)__popcll(mk));
-    basepos = __shfl((long long)basepos, l0, 64);
-    if (cross) {
-      const unsigned long long p = basepos + 2ull * (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
-      if (p + 1 < cap) {
-        out_code[p] = vox_code[i]; out_root[p] = (int32_t)parent[i];
-        out_code[p + 1] = vox_code[t]; out_root[p + 1] = (int32_t)parent[t];
-      }
-    }
+  bool pub = false;
+  for (int k = lane; k < n; k += 64) {
+    const uint32_t t = (uint32_t)row[k];
+    const bool ot = owned[t] != 0;
+    pub = pub || (oi ? !ot : (ot && mrow[k] != 0));
   }
+  pub = __ballot(pub) != 0ull;
+  if (lane != 0) return;
+  const int32_t a = attach[i];
+  const bool att = a >= 0 && oi && !owned[a];   // the count-as-index target (Q7) need not be a neighbour
+  const unsigned int cnt = (pub || att ? 1u : 0u) + (att ? 1u : 0u);
+  if (cnt == 0) return;
+  const unsigned long long p = atomicAdd(n_out, (unsigned long long)cnt);
+  if (p + cnt > cap) return;
+  out_code[p] = vox_code[i]; out_root[p] = (int32_t)parent[i];
+  if (att) { out_code[p + 1] = vox_code[a]; out_root[p + 1] = (int32_t)parent[a]; }
 }
 
-__global__ void k_apply_root_labels(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ owned, const int32_t* __restrict__ root_label,
-                                    int64_t V, int32_t* __restrict__ vox_label) {
+__global__ void k_boundary_straddle(const uint8_t* __restrict__ straddle, int64_t V, const uint32_t* __restrict__ parent,
+                                    const uint64_t* __restrict__ vox_code, unsigned long long cap, unsigned long long* __restrict__ n_out,
+                                    uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V || !straddle[v]) return;
+  const unsigned long long p = atomicAdd(n_out, 1ull);
+  if (p < cap) { out_code[p] = vox_code[v]; out_root[p] = (int32_t)parent[v]; }
+}
+
+// halo voxels take the label of their local component too: a voxel that reaches over the border holds points of this
+// rank although another rank owns it (its root is then a boundary root and carries the owner's label)
+__global__ void k_apply_root_labels(const uint32_t* __restrict__ parent, const int32_t* __restrict__ root_label, int64_t V,
+                                    int32_t* __restrict__ vox_label) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  vox_label[v] = (!owned || owned[v]) ? root_label[parent[v]] : -1;
+  vox_label[v] = root_label[parent[v]];
 }
 
 __global__ void k_point_labels2(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, const int32_t* __restrict__ vox_label,
@@ -193,7 +209,7 @@ vgs_status vgs_get_boundary(vgs_ctx* c, int64_t* n_records, uint64_t* code, int3
   if (!c || !n_records) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED || !c->have_region) { c->err = "vgs_get_boundary: segment a context with an owned region first"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
-  if (c->U == 0) { *n_records = 0; return VGS_OK; }
+  if (c->V == 0) { *n_records = 0; return VGS_OK; }
   unsigned long long cap = c->bnd_code.cap;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (cap < 1024) cap = 1u << 20;
@@ -202,8 +218,11 @@ vgs_status vgs_get_boundary(vgs_ctx* c, int64_t* n_records, uint64_t* code, int3
     unsigned long long* d_n = (unsigned long long*)c->counters.p + 32;
     VGS_HIP_TRY(c, hipMemsetAsync(d_n, 0, 8, c->stream));
     const uint8_t* mutual = c->conn.p + (size_t)c->U * c->adj_stride;
-    hipLaunchKernelGGL(k_boundary, dim3((unsigned)c->U), dim3(64), 0, c->stream, c->used_ids.p, c->U, c->adj_key.p, c->adj_cnt.p,
+    if (c->U > 0)
+      hipLaunchKernelGGL(k_boundary, dim3(vgs_xcd_grid(c->U)), dim3(64), 0, c->stream, c->used_ids.p, c->U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->owned.p, c->parent.p, c->vox_code.p, cap, d_n, c->bnd_code.p, c->bnd_root.p);
+    hipLaunchKernelGGL(k_boundary_straddle, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->straddle.p, c->V, c->parent.p,
+                       c->vox_code.p, cap, d_n, c->bnd_code.p, c->bnd_root.p);
     unsigned long long n = 0;
     VGS_HIP_TRY(c, hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -308,8 +327,8 @@ vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* 
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (bad) { c->err = "vgs_apply_tile_labels: root out of range"; return VGS_E_ARG; }
   }
-  hipLaunchKernelGGL(k_apply_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p,
-                     c->have_region ? c->owned.p : nullptr, c->root_label.p, V, c->vox_label.p);
+  hipLaunchKernelGGL(k_apply_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p, c->root_label.p, V,
+                     c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
   VGS_HIP_TRY(c, hipGetLastError());
@@ -352,8 +371,8 @@ vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t* root, const int32_t*
   VGS_HIP_TRY(c, c->root_label.ensure(V));
   VGS_HIP_TRY(c, hipMemcpy(c->root_label.p, map.data(), (size_t)V * 4, hipMemcpyHostToDevice));
   const int TB = 256;
-  hipLaunchKernelGGL(k_apply_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p,
-                     c->have_region ? c->owned.p : nullptr, c->root_label.p, V, c->vox_label.p);
+  hipLaunchKernelGGL(k_apply_root_labels, dim3((unsigned)((V + TB - 1) / TB)), dim3(TB), 0, c->stream, c->parent.p, c->root_label.p, V,
+                     c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
   VGS_HIP_TRY(c, hipGetLastError());

@@ -158,6 +158,8 @@ struct vgs_ctx {
   DevBuf<int32_t> sv_label;     // per point: supervoxel label (0 = unassigned), what getLabeledCloud returns (SS:283)
   int32_t sv_max_label = 0;
   bool sv_have_labels = false;
+  bool sv_labels_external = false;  // supplied through svgs_set_supervoxel_labels (independent of the VCCS parameters)
+  int64_t sv_label_n = -1;          // number of points the labelling was made for
   DevBuf<uint32_t> sv_key_a, sv_key_b;
   DevBuf<uint64_t> cell_code_a, cell_code_b;
   DevBuf<uint32_t> cell_id_a, cell_id_b, cell_start;
@@ -172,6 +174,7 @@ struct vgs_ctx {
   bool have_region = false;
   double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
   DevBuf<uint8_t> owned;        // per voxel: 1 = centre inside this rank's region
+  DevBuf<uint8_t> straddle;     // per voxel: 1 = its cube crosses the border of the region (it may hold points of two ranks)
   DevBuf<uint64_t> bnd_code;    // boundary records
   DevBuf<int32_t> bnd_root;
   DevBuf<int32_t> root_label;   // per voxel id: label of the component rooted there

@@ -2,9 +2,12 @@
 
 The reference is single-process.  Everything per voxel (binning, PCA, adjacency, local cut, mutual filter) is
 local to a ball of radius graph_size; only the connected components are global.  Each rank therefore segments
-its tile plus a halo of raw points (2*graph_size + voxel_size wide) on ONE shared grid, trusts the connections
-that have an owned endpoint, and publishes one (voxel code, local root) record per endpoint of every connection
-crossing the ownership border.  After one all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) every rank
+its tile plus a halo of raw points (2*graph_size + voxel_size wide) on ONE shared grid, trusts the mutual
+connections that have an owned endpoint and the re-attachments (closestCheck) of its own voxels, and publishes one
+(voxel code, local root) record per boundary voxel: the endpoints of every connection crossing the ownership
+border, every owned voxel with a halo voxel in its neighbourhood (the neighbouring rank may re-attach one of its
+isolated voxels to it), and every voxel whose cube reaches over the border (both ranks hold points of it; the rank
+that does not own it learns its label from the owner's record).  After one all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests) every rank
 runs the same small union-find over (rank, root) pairs and labels its own points.  Payloads are O(boundary
 voxels): the exchange is latency-bound, so it is a single collective with no tuning.
 
