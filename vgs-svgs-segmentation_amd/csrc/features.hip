@@ -19,8 +19,8 @@
 
 __global__ __launch_bounds__(FEAT_TB) void k_features(const float* __restrict__ xs, const float* __restrict__ ys,
                                                       const float* __restrict__ zs, const uint32_t* __restrict__ vox_start,
-                                                      int64_t V, int points_min, int svgs, NodeRec* __restrict__ node,
-                                                      uint32_t* __restrict__ used_flag) {
+                                                      int64_t V, int points_min, int svgs, const uint64_t* __restrict__ vox_code,
+                                                      NodeRec* __restrict__ node, uint32_t* __restrict__ used_flag) {
   __shared__ float lx[FEAT_TILE], ly[FEAT_TILE], lz[FEAT_TILE];
   const int64_t v0 = (int64_t)blockIdx.x * FEAT_TB;
   const int64_t v = v0 + threadIdx.x;
@@ -75,7 +75,14 @@ __global__ __launch_bounds__(FEAT_TB) void k_features(const float* __restrict__ 
   NodeRec r;
   for (int i = 0; i < 3; ++i) { r.c[i] = 0.f; r.n[i] = 0.f; }
   for (int i = 0; i < 8; ++i) r.f[i] = 0.f;
-  r.flags = 0; r.pad = 0;
+  r.flags = 0;
+  // VGS: the low 10 bits of the voxel's lattice coordinates ride along in the record's spare word, so that whoever gathers
+  // two records also knows their lattice offset (near-pair lists of the local cut); supervoxels are not on a lattice
+  r.pad = 0;
+  if (!svgs) {
+    const uint64_t code = vox_code[v];
+    r.pad = (vm_compact21(code >> 2) & 1023u) | ((vm_compact21(code >> 1) & 1023u) << 10) | ((vm_compact21(code) & 1023u) << 20);
+  }
   if (used) {
     C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
     if (svgs) for (int i = 0; i < 9; ++i) C[i] = C[i] / cnt;  // SS:1425
@@ -116,7 +123,7 @@ vgs_status vgs_stage_features(vgs_ctx* c) {
   const unsigned nb = (unsigned)((V + FEAT_TB - 1) / FEAT_TB);
   hipLaunchKernelGGL(k_features, dim3(nb), dim3(FEAT_TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V,
                      c->P.method == 3 ? -1 : c->P.points_min,  // every supervoxel is used (SS:1288)
-                     c->P.method == 3 ? 1 : 0, c->node.p, used_flag);
+                     c->P.method == 3 ? 1 : 0, c->vox_code.p, c->node.p, used_flag);
   size_t bytes = 0;
   VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, bytes, used_flag, excl, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
   VGS_HIP_TRY(c, c->sort_tmp.ensure(bytes));

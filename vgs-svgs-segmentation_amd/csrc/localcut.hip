@@ -414,35 +414,42 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 #include "localcut_wave.hpp"
 
-// split the used voxels into four classes by the number of neighbours; order inside a class follows the voxel order.
+// split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.
+// Class A (the bulk) is split once more: voxels with few heavy near pairs of their own (short near-pair list) are the
+// ones the lazy schedule works on for long or gives up on, so they form class A1, the part of the bulk launch that is
+// dealt out first.  (Any voxel may go to any class: the split only schedules.)
 // One global atomic per class and 1024 voxels (same-address atomics serialise).
+#define LC_NCLASS 5   // A, B, C, D, A1
 __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
-                                                   int max_a, int max_b, int max_c, uint32_t* __restrict__ ids_a, uint32_t* __restrict__ ids_b,
-                                                   uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d, unsigned int* __restrict__ n_abc) {
-  __shared__ unsigned int s_cnt[16][4];   // per wavefront and class: count, then base
-  __shared__ unsigned int s_base[4];
+                                                   int max_a, int max_b, int max_c, const uint32_t* __restrict__ used_ids,
+                                                   const uint8_t* __restrict__ nl_cnt, int a1_max, uint32_t* __restrict__ ids_a,
+                                                   uint32_t* __restrict__ ids_b, uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d,
+                                                   uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc) {
+  __shared__ unsigned int s_cnt[16][LC_NCLASS];   // per wavefront and class: count, then base
+  __shared__ unsigned int s_base[LC_NCLASS];
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int cls = -1;
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
     cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3));
+    if (cls == 0 && nl_cnt && (int)nl_cnt[used_ids[u]] <= a1_max) cls = 4;   // NL_NONE (255) stays in A
   }
-  unsigned long long mk[4];
-  for (int k = 0; k < 4; ++k) {
+  unsigned long long mk[LC_NCLASS];
+  for (int k = 0; k < LC_NCLASS; ++k) {
     mk[k] = __ballot(cls == k);
     if (lane == 0) s_cnt[wave][k] = (unsigned int)__popcll(mk[k]);
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < LC_NCLASS) {
     const int k = threadIdx.x;
     unsigned int tot = 0;
     for (int w = 0; w < 16; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
     s_base[k] = tot ? atomicAdd(&n_abc[k], tot) : 0u;
   }
   __syncthreads();
-  uint32_t* const outs[4] = {ids_a, ids_b, ids_c, ids_d};
-  for (int k = 0; k < 4; ++k)
+  uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1};
+  for (int k = 0; k < LC_NCLASS; ++k)
     if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }
 
@@ -474,7 +481,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.prune_unused = 0;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure(6 * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure(7 * (size_t)U + 16));
   VGS_HIP_TRY(c, c->csize.ensure((size_t)(c->V > U ? c->V : U)));  // used here as per-voxel evaluation counters (index u)
   VGS_HIP_TRY(c, c->counters.ensure(64));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
@@ -484,9 +491,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   uint32_t* ids_d = c->work_ids.p + 3 * U;    // the rest: one workgroup per voxel (k_localcut)
   uint32_t* ids_f = c->work_ids.p + 4 * U;    // handed over by the A/B wave kernels (m <= WAVE_B)
   uint32_t* ids_g = c->work_ids.p + 5 * U;    // handed over by the C wave kernel
-  unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 4 class counters (2 words)
-  unsigned int* d_nf = (unsigned int*)(c->counters.p + 10);
+  uint32_t* ids_a1 = c->work_ids.p + 6 * U;   // class A voxels with a short near-pair list of their own: they run first
+  unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 5 class counters (words 8-10)
+  unsigned int* d_nf = (unsigned int*)(c->counters.p + 11);
   unsigned int* d_ng = d_nf + 1;
+
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
   constexpr int LCAP_A = 448, LCAP_B = 312, LCAP_C = 2048;
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
@@ -494,14 +503,22 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
   constexpr int SMALL_M = 128, SMALL_CAP = 4096;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
+  {
+    // near-pair lists for the shells of the one-wavefront classes closest to the voxel (nearlist.hip); built on the main
+    // stream before the classes are formed (the split of class A reads the list lengths) and before the side streams fork
+    vgs_status sn = vgs_stage_nearlists(c);
+    if (sn != VGS_OK) return sn;
+  }
+  const int a1_max = getenv("VGS_A1MAX") ? atoi(getenv("VGS_A1MAX")) : 4;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
-                     0, WAVE_A, WAVE_B, WAVE_C, ids_a, ids_b, ids_c, ids_d, d_nabc);
-  unsigned int nabc[4] = {0, 0, 0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, 16, hipMemcpyDeviceToHost, c->stream));
+                     0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, a1_max, ids_a, ids_b, ids_c,
+                     ids_d, ids_a1, d_nabc);
+  unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, sizeof(nabc), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
 #ifdef VGS_PROF
   if (const char* oc = getenv("VGS_ONLY_CLASS")) {  // diagnostics: run a single class (results are incomplete)
-    for (int k = 0; k < 4; ++k) if (k != atoi(oc)) nabc[k] = 0;
+    for (int k = 0; k < LC_NCLASS; ++k) if (k != atoi(oc)) nabc[k] = 0;
   }
 #endif
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
@@ -520,6 +537,14 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
   WP.dbg_max_m = getenv("VGS_DBG_MAXM") ? atoi(getenv("VGS_DBG_MAXM")) : 0;
+  {
+    // Shells up to (NL_REACH voxels)^2 are complete in the near-pair lists; the margin covers centroids that float
+    // rounding puts a hair outside their voxel's cube.
+    const float reach = (float)NL_REACH * c->P.voxel_size;
+    WP.near.cnt = c->nl_cnt.p; WP.near.slot = c->nl_slot.p; WP.near.dw = c->nl_dw.p;
+    WP.near.d2max = reach * reach * 0.999f;
+    WP.near.enabled = c->nl_enabled ? 1 : 0;
+  }
   // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the
   // device (fixed grid of nw workgroups starting at list position `offset`); otherwise nw is the length.
   auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid, const unsigned int* n_dev = nullptr, unsigned int offset = 0) -> vgs_status {
@@ -590,8 +615,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                        ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
-  if (nabc[0] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, (const uint32_t*)nullptr, 0,
+  // class A1 (the voxels the lazy schedule is likely to work on for long, or give up on) is the launch's first list: the
+  // long-running wavefronts start first, the light ones fill the tail.  (Running A1 as a launch of its own with its
+  // hand-overs on a side stream was measured: the 34 KB workgroups of the hand-over kernel starve beside the bulk.)
+  if (nabc[0] + nabc[4] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
                        ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
@@ -599,7 +627,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // trip before the launch); the host checks the length afterwards.
   // (A second pass through the wave kernel with a 1024-edge list and 16 rounds was measured: it costs as much as the
   // workgroup kernel and still hands half of them over.)
-  const unsigned int nab = nabc[0] + nabc[1];
+  const unsigned int nab = nabc[0] + nabc[1] + nabc[4];
   // about 1.4 % of the A/B voxels are handed over on the urban scenes; idle workgroups of this kernel are not free
   const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
   {
@@ -619,7 +647,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (st != VGS_OK) return st;
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->counts[13] = nabc[0]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];
+  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -646,6 +674,19 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     double sm = 0, se = 0, sp = 0; uint32_t mn = ~0u, mx = 0;
     for (uint32_t u : idf) { sm += ac[u]; se += ev[u]; sp += 0.5 * ac[u] * (ac[u] - 1.0); mn = ac[u] < mn ? ac[u] : mn; mx = ac[u] > mx ? ac[u] : mx; }
     fprintf(stderr, "[vgs] handed-over voxels: %u, m avg %.1f min %u max %u, evaluations avg %.0f of %.0f pairs, slow-path %llu\n", nfg[0], sm / nfg[0], mn, mx, se / nfg[0], sp / nfg[0], h[7]);
+    if (c->nl_enabled) {
+      // how well does a voxel's own near-list length predict a hand-over?
+      std::vector<uint8_t> nc((size_t)c->V);
+      std::vector<uint32_t> uid((size_t)U);
+      VGS_HIP_TRY(c, hipMemcpy(nc.data(), c->nl_cnt.p, nc.size(), hipMemcpyDeviceToHost));
+      VGS_HIP_TRY(c, hipMemcpy(uid.data(), c->used_ids.p, uid.size() * 4, hipMemcpyDeviceToHost));
+      long long hall[34] = {0}, hho[34] = {0};
+      for (size_t u2 = 0; u2 < (size_t)U; ++u2) { int k = nc[uid[u2]]; hall[k > 32 ? 33 : k]++; }
+      for (uint32_t u2 : idf) { int k = nc[uid[u2]]; hho[k > 32 ? 33 : k]++; }
+      fprintf(stderr, "[vgs] own near-list length: all / handed over:");
+      for (int k = 0; k < 34; ++k) if (hall[k]) fprintf(stderr, " %d:%lld/%lld", k, hall[k], hho[k]);
+      fprintf(stderr, "\n");
+    }
   }
   if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
 #ifdef VGS_PROF

@@ -27,6 +27,8 @@
 
 #include <type_traits>
 
+#include "nearlist.hpp"
+
 // VGS_PROF=1 builds accumulate per-phase shader cycles (s_memtime) into counters[16..31] (diagnostics only)
 #ifdef VGS_PROF
 #define LW_T0() long long _t0 = clock64()
@@ -58,6 +60,7 @@ struct LwParams {
   int dbg_stop;     // diagnostics: leave the first round after step N (0 = run normally)
   int max_rounds;   // shells a wavefront works through before it hands the voxel over (classes A/B)
   int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
+  NearLists near;   // per-voxel lists of the heavy pairs within two lattice steps (nearlist.hpp): the first shell walks them
 };
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
@@ -91,7 +94,20 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   constexpr uint32_t PCOMP = SMALL ? 0xffffu : 0xffffffffu;  // stored complemented: descending (w, ~pid) = w desc, pid asc
   // edge list: lw = weight bits, lp = PCOMP - pid; a dropped entry is (0, 0), below every real edge (real lp >= 1)
   __shared__ uint32_t lw[LCAP];
-  __shared__ float cx[MAXM], cy[MAXM], cz[MAXM];  // centroids; cx = NaN when the position is unusable (VS:1829)
+  // centroids (cx = NaN when the position is unusable, VS:1829) -- or, while the first shell is read from the near-pair
+  // lists, the lattice offset of every vertex from the voxel and the vertex sitting at every offset of the 11^3 ball
+  // (0xff = none).  The two never live at the same time: the general enumeration stages the centroids when it first runs.
+  constexpr bool NEAR = SMALL && NW == 1;
+  constexpr int NMAP_DIM = 2 * NL_BALL + 1;
+  constexpr int NMAP_BYTES = (NMAP_DIM * NMAP_DIM * NMAP_DIM + 3) / 4 * 4;
+  constexpr int CBUF_BYTES = (NEAR && NMAP_BYTES + 2 * MAXM > 12 * MAXM) ? NMAP_BYTES + 2 * MAXM : 12 * MAXM;
+  __shared__ __attribute__((aligned(16))) unsigned char cbuf[CBUF_BYTES];
+  float* const cx = (float*)cbuf;
+  float* const cy = cx + MAXM;
+  float* const cz = cy + MAXM;
+  uint32_t* const nmap4 = (uint32_t*)cbuf;
+  uint8_t* const nmap = cbuf;
+  uint16_t* const nlat = (uint16_t*)(cbuf + NMAP_BYTES);   // (dx+5) | (dy+5) << 4 | (dz+5) << 8
   __shared__ float thr[MAXM];
   __shared__ uint32_t claim[MAXM];                // merge: first undecided edge of the step touching a segment (all ones between uses)
   constexpr bool GID_LDS = false;  // ids are read from the adjacency row (L2) when a record is needed: the LDS copy bought nothing and costs list slots
@@ -145,15 +161,53 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
   const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);  // cut / size, looked up across lanes
+  bool near_ok = false;   // wave-uniform: the first shell can be read from the near-pair lists
+  bool cen_ready = true;  // centroids are staged
+  uint32_t pad0 = 0;
+  if constexpr (NEAR) {
+    near_ok = P.near.enabled != 0;
+    if (near_ok) {
+      for (int k = lane; k < NMAP_BYTES / 4; k += 64) nmap4[k] = 0xffffffffu;
+      pad0 = node[(uint32_t)row[0]].pad;   // vertex 0 is the voxel itself
+      wave_sync();
+    }
+  }
+  auto stage_centroids = [&]() {
+    for (int c = (int)threadIdx.x; c < m; c += 64 * NW) {
+      const NodeRec& rc = node[(uint32_t)row[c]];
+      cx[c] = (rc.flags & VGS_F_POS) ? rc.c[0] : vm_nan();
+      cy[c] = rc.c[1];
+      cz[c] = rc.c[2];
+    }
+  };
+  bool near_bad = false;
+  uint32_t tid_reg0 = 0u, tid_reg1 = 0u;   // one-wavefront classes: global ids of vertices lane and lane + 64 (MAXM <= 128)
   for (int c = (int)threadIdx.x; c < m; c += 64 * NW) {
     const uint32_t t = (uint32_t)row[c];
+    if constexpr (NEAR) { if (c < 64) tid_reg0 = t; else tid_reg1 = t; }
     if (GID_LDS) gid[c] = t;
     seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c; claim[c] = 0xffffffffu;
-    const NodeRec& rc = node[t];
-    cx[c] = (rc.flags & VGS_F_POS) ? rc.c[0] : vm_nan();
-    cy[c] = rc.c[1];
-    cz[c] = rc.c[2];
+    if constexpr (NEAR) {
+      if (near_ok) {
+        const uint32_t pd = node[t].pad;
+        const int ox = nl_diff10(pd & 1023u, pad0 & 1023u) + NL_BALL, oy = nl_diff10((pd >> 10) & 1023u, (pad0 >> 10) & 1023u) + NL_BALL,
+                  oz = nl_diff10((pd >> 20) & 1023u, (pad0 >> 20) & 1023u) + NL_BALL;
+        const bool inb = (unsigned)ox < (unsigned)NMAP_DIM && (unsigned)oy < (unsigned)NMAP_DIM && (unsigned)oz < (unsigned)NMAP_DIM;
+        if (inb) {
+          nlat[c] = (uint16_t)(ox | (oy << 4) | (oz << 8));
+          nmap[(oz * NMAP_DIM + oy) * NMAP_DIM + ox] = (uint8_t)c;
+        }
+        near_bad = near_bad || !inb || P.near.cnt[t] == NL_NONE;
+      }
+    }
   }
+  if constexpr (NEAR) {
+    if (near_ok) {
+      near_ok = __ballot(near_bad) == 0ull;
+      cen_ready = false;
+    }
+  }
+  if (!near_ok) { if (!cen_ready) wave_sync(); stage_centroids(); cen_ready = true; }
   blk_sync();
 
   LW_ACC(0);  // gather
@@ -310,6 +364,79 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     return dropped;
   };
 
+  // Shells inside the reach of the near-pair lists: every pair (va < vb) of the neighbourhood with squared centroid
+  // distance in [cut_lo, cut_hi) (cut_hi <= the lists' reach) and a weight above the singleton threshold, straight into the
+  // edge list with its stored weight -- what enum_section + eval_section produce for that shell, without the n^2/2 distance
+  // tests and without a single weight evaluation.  After the first shell only pairs of two still-active vertices
+  // (threshold of their segment below the level the scan has reached: fact F) in different segments count.  Vertex va contributes the entries of ITS list that point at a later vertex: the stored
+  // weight has the list's owner as first argument, which is the orientation the cut wants.
+  // Four vertices per step, sixteen lanes each (lists are sorted by distance: on a surface the shell ends before entry 16);
+  // a vertex whose sixteenth entry is still inside the shell gets a step of its own for the rest.
+  auto near_enum = [&](int n_list, float cut_lo, float cut_hi, bool merged, float act_level) -> int {
+    int count = 0;
+    auto vertex_id = [&](int va) -> uint32_t {   // global id of vertex va from the registers of lane va & 63
+      const uint32_t lo = (uint32_t)__shfl((int)tid_reg0, va & 63, 64), hi = (uint32_t)__shfl((int)tid_reg1, va & 63, 64);
+      return va < 64 ? lo : hi;
+    };
+    // entry e = (d2, w), s = packed offset of vertex va's list; all lanes call
+    auto take = [&](int va, bool act, float2 e, uint32_t sl) -> bool {
+      bool inr = false;
+      uint32_t pid = 0;
+      const bool inside = act && e.x < cut_hi;
+      if (inside && e.x >= cut_lo) {
+        // nibble-wise (a + 5) + (s + 2): the partner's offset from the voxel, + 7
+        const uint32_t q = (uint32_t)nlat[va] + sl;
+        const int bx = (int)(q & 15u) - NL_REACH, by = (int)((q >> 4) & 15u) - NL_REACH, bz = (int)((q >> 8) & 15u) - NL_REACH;
+        if ((unsigned)bx < (unsigned)NMAP_DIM && (unsigned)by < (unsigned)NMAP_DIM && (unsigned)bz < (unsigned)NMAP_DIM) {
+          const int vb = nmap[(bz * NMAP_DIM + by) * NMAP_DIM + bx];
+          if (vb != 0xff && va < vb) {
+            inr = true;
+            if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+            pid = ((uint32_t)va << PSH) | (uint32_t)vb;
+          }
+        }
+      }
+      const unsigned long long mk = __ballot(inr);
+      if (inr) {
+        const int pos = n_list + count + __popcll(mk & lt_mask);
+        if (pos < LCAP) { lw[pos] = vm_bits(e.y); lp[pos] = (pid_t)(PCOMP - pid); }
+      }
+      count += __popcll(mk);
+      return inside;
+    };
+    const int j = lane & 15;
+    // two groups of four vertices per trip: their list entries are requested together (the ids come out of registers,
+    // so the only memory round trip of a trip is the entries themselves)
+    for (int base = 0; base < m; base += 8) {
+      const int va0 = base + (lane >> 4), va1 = va0 + 4;
+      const bool a0 = va0 < m, a1 = va1 < m;
+      const size_t o0 = (size_t)vertex_id(va0) * NL_S + (size_t)j, o1 = (size_t)vertex_id(va1) * NL_S + (size_t)j;
+      float2 e0 = make_float2(0.f, 0.f), e1 = make_float2(0.f, 0.f);
+      uint32_t s0 = 0, s1 = 0;
+      if (a0) { e0 = P.near.dw[o0]; s0 = P.near.slot[o0]; }
+      if (a1) { e1 = P.near.dw[o1]; s1 = P.near.slot[o1]; }
+      const bool in0 = take(va0, a0, e0, s0);
+      const bool in1 = take(va1, a1, e1, s1);
+      // the shell may go on behind entry 15 of a vertex: the rest of that list gets a step of its own
+      const unsigned long long more0 = __ballot(in0 && j == 15), more1 = __ballot(in1 && j == 15);
+      for (int g = 0; g < 2; ++g) {
+        unsigned long long more = g ? more1 : more0;
+        while (more) {
+          const int l0 = __ffsll((long long)more) - 1;
+          more &= more - 1ull;
+          const int va = base + (l0 >> 4) + 4 * g;
+          const bool act = lane < NL_S - 16;
+          const size_t o = (size_t)vertex_id(va) * NL_S + 16 + (size_t)(lane & 15);
+          float2 e = make_float2(0.f, 0.f);
+          uint32_t sl = 0;
+          if (act) { e = P.near.dw[o]; sl = P.near.slot[o]; }
+          take(va, act, e, sl);
+        }
+      }
+    }
+    return count;
+  };
+
   // ---- wavefronts 1 .. NW-1: serve the sections until wavefront 0 is done ----
   if constexpr (NW > 1) {
     if (wave != 0) {
@@ -460,6 +587,22 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     }
     return __ballot(any) == 0ull;
   };
+  // In-place compaction of the candidates [from, from + count) that `live` keeps; returns the number kept.
+  auto close_gaps = [&](int from, int count, bool by_weight) -> int {
+    int kept = from;
+    for (int base = from; base < from + count; base += 64) {
+      const int e = base + lane;
+      uint32_t kw = 0, kp = 0;
+      if (e < from + count) { kw = lw[e]; kp = lp[e]; }
+      const bool live = kp != 0u;   // a dropped entry has lp == 0; a real one has lp >= 1
+      const unsigned long long mk = __ballot(live);
+      wave_sync();
+      if (live) { const int d = kept + __popcll(mk & lt_mask); if (by_weight) lw[d] = kw; lp[d] = (pid_t)kp; }
+      kept += __popcll(mk);
+      wave_sync();
+    }
+    return kept;
+  };
   if (m >= 2) {
     // =========================== phase A: edges heavier than a singleton's threshold ===========================
     int n_list = 0;      // edges carried in the list (sorted, all lighter than the previous level, heavier than thr0)
@@ -472,13 +615,17 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     {
       const float cap = 2.0f * (P.cap_frac * (float)LCAP) * P.r2_graph / ((float)m * (float)m);
       cut_hi = cut_hi < cap ? cut_hi : cap;
+      if (near_ok) cut_hi = cut_hi < P.near.d2max ? cut_hi : P.near.d2max;   // the lists reach this far
     }
     int shrink = 0;
     bool phase_a_complete = false;
     int rounds = 0;
+    float act_level = __builtin_huge_valf();   // vertices whose segment's threshold is below this are still active
     while (true) {
       // a neighbourhood that keeps hundreds of edges waiting above thr0 makes slow progress here: after a few
       // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
+      // (examining all remaining pairs in this kernel and keeping the survivors only was tried: the neighbourhoods that
+      // get here hold more edges above thr0 than the list, or overflow it in phase B, and are handed over anyway)
       if (++rounds > (MAXM > 128 ? 14 : P.max_rounds)) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
@@ -486,7 +633,18 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int Pact = use_minor ? n_min * n_act : n_act * (n_act - 1) / 2;   // (upper bound of) candidate pairs
       // once every pair between the still-active vertices fits in the list there is no point in further shells
       const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
-      const int count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
+      const bool near_round = NEAR && near_ok && !final_round && !(cut_hi > P.near.d2max);   // a shell inside the lists' reach
+      int count;
+      if constexpr (NEAR) {
+        if (near_round) {
+          count = near_enum(n_list, cut_lo, cut_hi, merges > 0, act_level);
+        } else {
+          if (!cen_ready) { stage_centroids(); cen_ready = true; wave_sync(); }   // the offset map is not needed any more
+          count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
+        }
+      } else {
+        count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
+      }
       LW_ACC(1);  // enumerate
       if (P.dbg_stop == 1) return;
       LW_CNT(8, 1);  // rounds
@@ -501,25 +659,14 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       shrink = 0;
       wave_sync();
       // ---- 2. full weight of the shell's pairs; NaN (Q3) and weights <= thr0 (fact S) are not stored ----
-      const int dropped = run_eval(n_list, count);
+      const int dropped = near_round ? 0 : run_eval(n_list, count);   // the lists hold weights above thr0 only
       n_evals += (unsigned int)count;
       auto sort_len = [](int c) { int np = 64; while (np < c) np <<= 1; return np; };
       if (dropped > 0 && sort_len(n_list + count - dropped) < sort_len(n_list + count)) {
         // close the gaps before sorting when that halves the sort network (its length is the next power of two):
         // ascending and in place, a write never passes the read position
         wave_sync();
-        int kept = n_list;
-        for (int base = n_list; base < n_list + count; base += 64) {
-          const int e = base + lane;
-          uint32_t kw = 0, kp = 0;
-          if (e < n_list + count) { kw = lw[e]; kp = lp[e]; }
-          const bool live = kp != 0u;   // a dropped entry is (0, 0); a real one has lp >= 1
-          const unsigned long long mk = __ballot(live);
-          wave_sync();
-          if (live) { const int d = kept + __popcll(mk & lt_mask); lw[d] = kw; lp[d] = (pid_t)kp; }
-          kept += __popcll(mk);
-          wave_sync();
-        }
+        const int kept = close_gaps(n_list, count, true);
         n_list = kept;
         sort_list(n_list);
       } else {
@@ -602,8 +749,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       }
       n_list = kept;
       LW_ACC(5);  // freeze + carry
+      act_level = level;
       cut_lo = cut_hi;
       cut_hi = cut_hi * P.grow;
+      if (near_ok && cut_lo < P.near.d2max && cut_hi > P.near.d2max) cut_hi = P.near.d2max;   // one more shell from the lists
     }
     // =========================== phase B: edges at or below a singleton's threshold ===========================
     if (phase_a_complete && !bail && merges < m - 1) {

@@ -234,11 +234,17 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + u * adj_stride;
   const uint8_t* mrow = mutual + u * adj_stride;
+  // after the first hook and the pointer jumping most neighbours already hang under the same node: equal parents mean
+  // one tree, whatever other wavefronts do meanwhile (links are only ever added), and cost one load instead of two finds
+  const uint32_t pi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int k = threadIdx.x; k < n; k += 64) {
     if (!mrow[k]) continue;
     const uint32_t t = (uint32_t)row[k];
     // tiled runs: a connection is trusted only if one endpoint is owned (both neighbourhoods are then complete)
-    if (t > i && (!owned || owned[i] || owned[t])) uf_union(parent, i, t);  // each mutual edge appears in both rows: union once
+    if (t > i && (!owned || owned[i] || owned[t])) {  // each mutual edge appears in both rows: union once
+      if (__hip_atomic_load(&parent[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pi) continue;
+      uf_union(parent, i, t);
+    }
   }
   if (threadIdx.x == 0) {
     const int32_t t = attach[i];

@@ -1,0 +1,39 @@
+// nearlist.hpp -- near-pair lists shared by nearlist.hip (builder) and the local cut (consumer).
+//
+// The local cut of voxel i (localcut_wave.hpp) examines, in its first shell, every pair (a, b) of i's neighbours whose
+// centroids are closer than about 1.5 voxels -- the same few pairs for every i that has both in its neighbourhood, about
+// 70 times each on a surface.  Voxels sit on a lattice, so these pairs are known per VOXEL: for every used voxel a the
+// builder lists its used neighbours b at most NL_REACH lattice steps away (Chebyshev) with
+//     centroid distance^2  d2(a, b) < (NL_REACH * voxel_size)^2   and   w(a, b) > 1 - cut  (not NaN),
+// sorted by d2, as (d2, w, packed lattice offset).  w(a, b) is vm_pair_weight with a as its FIRST argument (the
+// weight is symmetric only up to an ulp; the cut needs w(first, second) in the order of i's adjacency row, so both
+// orientations exist, one in each voxel's list).  The cut then walks the lists of its vertices instead of testing all
+// n^2/2 pairs, and takes the stored weight instead of evaluating it.
+// Exactness: centroids lie inside their voxel's cube, so a pair more than NL_REACH lattice steps apart on some axis is
+// farther apart than NL_REACH voxel sizes: every pair with d2 < near_d2max is in the lists.  Pairs at or below the
+// singleton threshold 1 - cut are never stored by phase A of the cut either (fact S).
+#ifndef NEARLIST_HPP_
+#define NEARLIST_HPP_
+
+#include <stdint.h>
+
+#define NL_S 32       // entries per voxel; a voxel with more heavy near pairs is marked NL_NONE and its neighbourhoods take the general path
+#define NL_REACH 2    // Chebyshev reach of the lists in lattice steps
+#define NL_NONE 0xffu
+#define NL_BALL 5     // largest lattice offset of a neighbour the consumer's offset map can hold ((2*5+1)^3 bytes of LDS)
+
+struct NearLists {
+  const uint8_t* cnt;    // [V]        number of entries, NL_NONE = no list
+  const uint16_t* slot;  // [V * NL_S] lattice offset of b from a: (dx+2) | (dy+2) << 4 | (dz+2) << 8
+  const float2* dw;      // [V * NL_S] (squared centroid distance, vm_pair_weight(a, b)), ascending distance; unused entries
+                         //            hold (+inf, 0), so a reader needs no count: "d2 < shell radius" ends the list
+  float d2max;           // lists are complete for shells up to this squared centroid distance
+  int enabled;
+};
+
+// signed difference of two 10-bit lattice coordinates (exact for |difference| < 512)
+#if defined(__HIPCC__)
+__device__ __forceinline__ int nl_diff10(uint32_t a, uint32_t b) { return (int)(((a - b + 512u) & 1023u)) - 512; }
+#endif
+
+#endif

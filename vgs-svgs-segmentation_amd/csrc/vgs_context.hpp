@@ -138,6 +138,12 @@ struct vgs_ctx {
   bool adj_pruned = false;              // rows hold used neighbours only
   float adj_r2 = 0.f;
 
+  // near-pair lists (nearlist.hip): per voxel id, the heavy pairs with a used voxel at most two lattice steps away
+  DevBuf<uint8_t> nl_cnt;
+  DevBuf<uint16_t> nl_slot;
+  DevBuf<float2> nl_dw;
+  bool nl_enabled = false;
+
   // local cut / merge
   DevBuf<uint8_t> conn;
   DevBuf<uint32_t> csize;      // per voxel: list length after crossValidation (0 for unused)
@@ -199,6 +205,7 @@ vgs_status vgs_stage_features(vgs_ctx* c);
 vgs_status vgs_stage_adjacency(vgs_ctx* c);
 vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2);
 bool vgs_unused_are_inert(const vgs_params& p);
+vgs_status vgs_stage_nearlists(vgs_ctx* c);   // part of the local-cut stage
 vgs_status vgs_stage_localcut(vgs_ctx* c);
 vgs_status vgs_stage_merge(vgs_ctx* c);
 vgs_status vgs_stage_vccs(vgs_ctx* c);
