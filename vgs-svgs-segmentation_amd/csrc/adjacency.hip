@@ -14,6 +14,7 @@
 // the full neighbour count (closestCheck needs it: VS:2201, VS:2243).  The full lists of the reference's
 // getOneVoxelAdjacency are produced on demand by the FULL instantiation (vgs_get_lists).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "vgs_context.hpp"
@@ -145,6 +146,188 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }  // stored entries, all neighbours
 }
 
+// ---- hot path for small balls: candidates from brick occupancy masks --------------------------------------------
+// On a surface about a sixth of the ball's lattice cells are occupied, yet the kernel above probes the brick table for
+// every one of them.  Here a lane fetches one BRICK of the (at most 5 x 5 x 5) bricks the ball touches, ANDs its occupancy
+// with the precomputed mask of ball cells inside that brick (one mask per position of the voxel in its own brick), and the
+// set bits of all lanes are expanded into a dense candidate list: the per-cell work (float predicate, key, group) is done
+// for occupied cells only.  Candidates arrive brick by brick, so the survivors are put in order of integer offset length
+// with a counting sort (histogram in LDS); inside a length group the final slot is found as above.  Rows that do not fit,
+// or whose float distances leave the band of their integer lengths, go to the redo list of the general kernel.
+#define ADJM_BRICKS 128
+#define ADJM_TRIPS 5   // candidates per lane kept in registers (CAPC = 64 * ADJM_TRIPS)
+template <int CAP, int NB>
+__global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids, int64_t U,
+                                                        const Brick* __restrict__ bricks, uint32_t hbits, const uint64_t* __restrict__ masks,
+                                                        int R, float res_f, float min_x, float min_y, float min_z, float r2,
+                                                        int adj_stride, uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
+                                                        uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
+                                                        const int32_t* __restrict__ nvals, unsigned int* __restrict__ n_redo,
+                                                        uint32_t* __restrict__ redo_out) {
+  constexpr int NB3 = NB * NB * NB, Bh = NB / 2, CAPC = 64 * ADJM_TRIPS;
+  static_assert(NB3 <= ADJM_BRICKS, "two bricks per lane");
+  __shared__ uint64_t s_occ[ADJM_BRICKS];
+  __shared__ uint32_t s_first[ADJM_BRICKS];
+  __shared__ uint16_t s_cand[CAPC];     // used << 13 | brick slot << 6 | bit
+  __shared__ uint64_t lst[CAP];
+  __shared__ uint8_t gl[CAP];
+  __shared__ uint32_t s_hist[128], s_cur[128];   // two 16-bit counters per word: integer length l lives in word l >> 1
+  __shared__ float ctab[3][32];
+  const int lane = threadIdx.x;
+  const int64_t u = vgs_xcd_item(blockIdx.x, U);
+  if (u >= U) return;
+  const uint32_t i = used_ids[u];
+  const uint64_t code = vox_code[i];
+  const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
+  const float cx = vm_voxel_center(kx, res_f, min_x), cy = vm_voxel_center(ky, res_f, min_y), cz = vm_voxel_center(kz, res_f, min_z);
+  if (lane < 2 * R + 1) {
+    ctab[0][lane] = vm_voxel_center(kx + (uint32_t)(lane - R), res_f, min_x);
+    ctab[1][lane] = vm_voxel_center(ky + (uint32_t)(lane - R), res_f, min_y);
+    ctab[2][lane] = vm_voxel_center(kz + (uint32_t)(lane - R), res_f, min_z);
+  }
+  for (int k = lane; k < 128; k += 64) s_hist[k] = 0;
+  const int px = (int)(kx & 3u), py = (int)(ky & 3u), pz = (int)(kz & 3u);
+  const uint64_t* mrow = masks + (size_t)((pz * 4 + py) * 4 + px) * (size_t)NB3;
+  // ---- one brick per lane (two trips: NB3 <= 128): the whole 32-byte table entry comes in one round trip ----
+  uint64_t cand[2] = {0ull, 0ull}, cusd[2] = {0ull, 0ull};
+#pragma unroll
+  for (int trip = 0; trip < 2; ++trip) {
+    const int sidx = trip * 64 + lane;
+    uint64_t occ = 0ull;
+    uint32_t first = 0u;
+    if (sidx < NB3) {
+      const uint64_t bm = mrow[sidx];
+      const int bi = sidx % NB - Bh, bj = (sidx / NB) % NB - Bh, bk = sidx / (NB * NB) - Bh;
+      const int nbx = (int)(kx >> 2) + bi, nby = (int)(ky >> 2) + bj, nbz = (int)(kz >> 2) + bk;
+      if (bm != 0ull && nbx >= 0 && nby >= 0 && nbz >= 0) {
+        const unsigned long long key = (((unsigned long long)nbz << 42) | ((unsigned long long)nby << 21) | (unsigned long long)nbx) + 1ull;
+        const uint32_t mask = (1u << hbits) - 1u;
+        uint32_t sl = hash_slot(key, hbits);
+        while (true) {
+          const ulonglong2 k01 = *(const ulonglong2*)&bricks[sl];          // key, occ
+          if (k01.x == key) {
+            const ulonglong2 k23 = *((const ulonglong2*)&bricks[sl] + 1);  // used, (first, pad)
+            occ = k01.y; first = (uint32_t)k23.y;
+            cand[trip] = occ & bm; cusd[trip] = k23.x;
+            break;
+          }
+          if (k01.x == 0ull) break;
+          sl = (sl + 1) & mask;
+        }
+      }
+      s_occ[sidx] = occ; s_first[sidx] = first;
+    }
+  }
+  // ---- expand the set bits of all lanes into one candidate list ----
+  const int mine = __popcll(cand[0]) + __popcll(cand[1]);
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  const int ntot = __shfl(incl, 63, 64);
+  auto to_redo = [&]() { if (lane == 0) redo_out[atomicAdd(n_redo, 1u)] = (uint32_t)u; };
+  if (ntot > CAPC) { to_redo(); return; }
+  {
+    int pos = incl - mine;
+#pragma unroll
+    for (int trip = 0; trip < 2; ++trip) {
+      uint64_t mm = cand[trip];
+      const int sidx = trip * 64 + lane;
+      while (mm) {
+        const int bit = __ffsll((long long)mm) - 1;
+        mm &= mm - 1ull;
+        s_cand[pos++] = (uint16_t)(((int)((cusd[trip] >> bit) & 1ull) << 13) | (sidx << 6) | bit);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per candidate: float predicate, key, integer length; survivors stay in registers until their slots are known ----
+  const float res2 = res_f * res_f;
+  int nstore = 0, mused = 0;
+  bool in_band = true;
+  uint64_t rkey[ADJM_TRIPS];
+  int rnorm[ADJM_TRIPS];   // -1 = nothing to store
+#pragma unroll
+  for (int tr = 0; tr < ADJM_TRIPS; ++tr) {
+    rnorm[tr] = -1; rkey[tr] = 0;
+    const int q = tr * 64 + lane;
+    if (tr * 64 < ntot) {   // wave-uniform
+      bool keep = false, is_used = false;
+      if (q < ntot) {
+        const int cb = s_cand[q];
+        const int sidx = (cb >> 6) & 127, bit = cb & 63;
+        is_used = (cb >> 13) != 0;
+        const int bi = sidx % NB - Bh, bj = (sidx / NB) % NB - Bh, bk = sidx / (NB * NB) - Bh;
+        // bit = z0 y0 x0 z1 y1 x1 (brick_local)
+        const int lx = ((bit >> 2) & 1) | (((bit >> 5) & 1) << 1), ly = ((bit >> 1) & 1) | (((bit >> 4) & 1) << 1), lz = (bit & 1) | (((bit >> 3) & 1) << 1);
+        const int dx = 4 * bi + lx - px, dy = 4 * bj + ly - py, dz = 4 * bk + lz - pz;
+        const uint64_t occ = s_occ[sidx];
+        const uint64_t above = (bit == 63) ? 0ull : (occ >> (bit + 1));
+        const uint32_t t = s_first[sidx] + (uint32_t)__popcll(above);
+        const float tx = cx - ctab[0][dx + R];
+        const float ty = cy - ctab[1][dy + R];
+        const float tz = cz - ctab[2][dz + R];
+        const float d2 = (tx * tx + ty * ty) + tz * tz;
+        if (d2 < r2) {
+          keep = true;
+          const int norm = dx * dx + dy * dy + dz * dz;
+          in_band = in_band && (fabsf(d2 - (float)norm * res2) < 0.49f * res2) && (norm < 256);
+          if (is_used) {
+            rkey[tr] = ((uint64_t)vm_bits(d2) << 32) | t;
+            rnorm[tr] = norm & 255;
+            atomicAdd(&s_hist[(norm & 255) >> 1], 1u << (16 * (norm & 1)));
+          }
+        }
+      }
+      nstore += __popcll(__ballot(keep && is_used));
+      mused += __popcll(__ballot(keep));
+    }
+  }
+  if (nstore > CAP || __ballot(!in_band) != 0ull) { to_redo(); return; }
+  __syncthreads();
+  // ---- counting sort by integer length: start of every length's group (four lengths per lane) ----
+  {
+    const uint32_t w0 = s_hist[2 * lane], w1 = s_hist[2 * lane + 1];
+    const uint32_t h[4] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+    const uint32_t sum = h[0] + h[1] + h[2] + h[3];
+    uint32_t inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += v; }
+    const uint32_t s0 = inc - sum, s1 = s0 + h[0], s2 = s1 + h[1], s3 = s2 + h[2];
+    const uint32_t p0 = s0 | (s1 << 16), p1 = s2 | (s3 << 16);
+    s_hist[2 * lane] = p0; s_hist[2 * lane + 1] = p1;   // starts
+    s_cur[2 * lane] = p0; s_cur[2 * lane + 1] = p1;     // cursors
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tr = 0; tr < ADJM_TRIPS; ++tr) {
+    if (rnorm[tr] >= 0) {
+      const int g = rnorm[tr];
+      const uint32_t old = atomicAdd(&s_cur[g >> 1], 1u << (16 * (g & 1)));
+      const uint32_t pos = (old >> (16 * (g & 1))) & 0xffffu;
+      lst[pos] = rkey[tr]; gl[pos] = (uint8_t)g;
+    }
+  }
+  __syncthreads();
+  // ---- final slot inside the group (the order inside a group is open: equal lengths, keys differ in rounding and id) ----
+  uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  const int cnt = nstore;
+  for (int p = lane; p < cnt; p += 64) {
+    const uint64_t key = lst[p];
+    const int g = gl[p];
+    const int first = (int)((s_hist[g >> 1] >> (16 * (g & 1))) & 0xffffu);
+    const int last = (int)((s_cur[g >> 1] >> (16 * (g & 1))) & 0xffffu);   // one past the group
+    int rank = 0;
+    for (int q = first; q < last; ++q) rank += lst[q] < key ? 1 : 0;
+    row[first + rank] = key;
+  }
+  if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
+  if (gtab) {
+    uint16_t* gt = gtab + (int64_t)u * gstride;
+    for (int r = lane; r <= ngroups; r += 64) {
+      const int g = r < ngroups ? (nvals[r] & 255) : 0;
+      gt[r] = (uint16_t)(r < ngroups ? ((s_hist[g >> 1] >> (16 * (g & 1))) & 0xffffu) : (uint32_t)cnt);
+    }
+  }
+}
+
 // an edge that touches an unused voxel carries the constant weight of five distances of 100 (VS:1602-1606);
 // if that cannot beat a singleton's threshold 1 - cut the unused voxels can never merge: they are inert (exact)
 bool vgs_unused_are_inert(const vgs_params& p) {
@@ -178,6 +361,36 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   std::sort(offs.begin(), offs.end());
   c->n_off = (int)offs.size();
   c->adj_R = R;
+  {
+    // ball masks for k_adjacency_masks: for every position p of a voxel inside its 4x4x4 brick and every brick offset b,
+    // the cells of that brick that belong to the ball (bit = brick_local of the cell)
+    int Rm = 0;
+    for (const auto& o : offs) {
+      const int32_t pk = o.second;
+      const int d[3] = {(int)(int8_t)(pk & 0xff), (int)(int8_t)((pk >> 8) & 0xff), (int)(int8_t)((pk >> 16) & 0xff)};
+      for (int a = 0; a < 3; ++a) Rm = std::max(Rm, std::abs(d[a]));
+    }
+    const int Bh = (Rm + 3) / 4, NB = 2 * Bh + 1, NB3 = NB * NB * NB;
+    c->adj_mask_nb = 0;
+    if (NB == 3 || NB == 5) {
+      std::vector<uint64_t> masks((size_t)64 * NB3, 0ull);
+      for (int p = 0; p < 64; ++p) {
+        const int px = p & 3, py = (p >> 2) & 3, pz = p >> 4;
+        for (const auto& o : offs) {
+          const int32_t pk = o.second;
+          const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
+          const int ax = px + dx, ay = py + dy, az = pz + dz;   // cell relative to the origin of the voxel's brick
+          const int bi = (ax >= 0 ? ax / 4 : -((3 - ax) / 4)), bj = (ay >= 0 ? ay / 4 : -((3 - ay) / 4)), bk = (az >= 0 ? az / 4 : -((3 - az) / 4));
+          const int lx = ax - 4 * bi, ly = ay - 4 * bj, lz = az - 4 * bk;
+          const int local = (lz & 1) | ((ly & 1) << 1) | ((lx & 1) << 2) | ((lz & 2) << 2) | ((ly & 2) << 3) | ((lx & 2) << 4);
+          masks[(size_t)p * NB3 + (size_t)(((bk + Bh) * NB + (bj + Bh)) * NB + (bi + Bh))] |= 1ull << local;
+        }
+      }
+      VGS_HIP_TRY(c, c->adj_masks.ensure(masks.size()));
+      VGS_HIP_TRY(c, hipMemcpy(c->adj_masks.p, masks.data(), masks.size() * 8, hipMemcpyHostToDevice));
+      c->adj_mask_nb = NB;
+    }
+  }
   std::vector<int32_t> packed(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
@@ -215,7 +428,22 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
-  if (c->n_off <= 1024) {
+  if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !getenv("VGS_NO_ADJMASKS")) {
+    // hot path: candidates from the brick occupancy masks; rows it cannot take go through the general kernel
+    VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
+    unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
+    VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
+#define LAUNCH_ADJM(NBV)                                                                                                          \
+    hipLaunchKernelGGL((k_adjacency_masks<240, NBV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,  \
+                       (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
+                       out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p)
+    if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
+#undef LAUNCH_ADJM
+    unsigned int n_redo = 0;
+    VGS_HIP_TRY(c, hipMemcpyAsync(&n_redo, d_nredo, 4, hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_redo > 0) LAUNCH_ADJ(1024, false, n_redo, c->work_ids.p, d_nredo, nullptr);
+  } else if (c->n_off <= 1024) {
     if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);
   } else if (c->n_off <= 8192) {
     // A list for every lattice offset (72 KB of LDS) leaves two wavefronts per CU; surfaces fill a fraction of the ball,
