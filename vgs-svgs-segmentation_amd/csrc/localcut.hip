@@ -238,24 +238,54 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
       fast_done = true;  // the voxel stays alone
     } else {
       {
+        // Two passes, so that the expensive full weight runs on full wavefronts: (1) every pair gets the cheap proximity +
+        // angle bound, the survivors are queued (pair ids in the upper half of the list array: CAP 32-bit slots);
+        // (2) the queue is evaluated densely, edges heavier than thr0 go to the list.  In clutter -- where this kernel
+        // is used -- four of five pairs leave in pass 1; evaluated in place they would idle beside a lane that stays.
+        uint32_t* queue = (uint32_t*)(list + CAP / 2);
+        int* q_n = &s_rdone;   // free until the histogram rounds (restored below)
+        if (tid == 0) *q_n = 0;
+        __syncthreads();
         int a = 0, qq = tid;
         while (true) {
           while (a < m - 1 && qq >= m - 1 - a) { qq -= (m - 1 - a); ++a; }
-          if (a >= m - 1) break;
-          const int b = a + 1 + qq;
-          const NodeRec& A = nd(a);
-          const NodeRec& B = nd(b);
-          const float ub = vm_weight_bound_da(A, B, P.W);
-          ++my_pairs;
-          if (!(ub <= thr0)) {
-            const float w = vm_pair_weight(A, B, P.W);
-            if (w > thr0) {
-              const int pos = atomicAdd(&s_nlist, 1);
-              if (pos < CAP) list[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - (((uint32_t)a << 16) | (uint32_t)b));
-            }
+          const bool live = a < m - 1;
+          bool keep = false;
+          int b = 0;
+          if (live) {
+            b = a + 1 + qq;
+            ++my_pairs;
+            keep = !(vm_weight_bound_da(nd(a), nd(b), P.W) <= thr0);
           }
+          const unsigned long long mk = __ballot(keep);
+          if (mk != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(q_n, __popcll(mk));
+            base = __shfl(base, 0, 64);
+            if (keep) { const int pos = base + __popcll(mk & ((1ull << lane) - 1ull)); if (pos < CAP) queue[pos] = ((uint32_t)a << 16) | (uint32_t)b; }
+          }
+          if (__ballot(live) == 0ull) break;
           qq += LC_TB;
         }
+        __syncthreads();
+        const int nq = *q_n;
+        if (nq > CAP) {
+          if (tid == 0) s_nlist = CAP + 1;   // queue overflow: take the general rounds
+        } else {
+          for (int e = tid; e < nq; e += LC_TB) {
+            const uint32_t pid = queue[e];
+            const int pa = (int)(pid >> 16), pb = (int)(pid & 0xffffu);
+            const float w = vm_pair_weight(nd(pa), nd(pb), P.W);
+            if (w > thr0) {
+              const int pos = atomicAdd(&s_nlist, 1);
+              // the list grows from the bottom while the queue sits in the upper half: more than CAP / 2 edges count as overflow
+              if (pos < CAP / 2) list[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffffffu - pid);
+              else s_nlist = CAP + 1;
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0) s_rdone = LC_NBIN * LC_NBIN;
       }
       __syncthreads();
       const int nlA = s_nlist;

@@ -7,78 +7,122 @@
 
 #include "nearlist.hpp"
 
+// NLB_G voxels per wavefront: the candidates of all of them that pass the cheap tests (lattice reach, centroid distance)
+// are queued in LDS, so that the expensive part -- the weight -- runs on full wavefronts (a voxel alone fills a third of one).
+#define NLB_G 8
+#define NLB_QCAP 512
 __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                    const uint32_t* __restrict__ adj_cnt, int adj_stride, const NodeRec* __restrict__ node,
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
                                                    float lat_d2_lim, float d2max,
                                                    uint8_t* __restrict__ out_cnt, uint16_t* __restrict__ out_slot, float2* __restrict__ out_dw) {
-  __shared__ float s_d2[NL_S], s_w[NL_S];
-  __shared__ uint16_t s_slot[NL_S];
-  const int64_t u = vgs_xcd_item(blockIdx.x, U);
-  if (u >= U) return;
+  __shared__ uint32_t q_t[NLB_QCAP];      // partner voxel id
+  __shared__ float q_d2[NLB_QCAP], q_w[NLB_QCAP];   // centroid distance^2; weight, NaN = not kept
+  __shared__ uint16_t q_slot[NLB_QCAP];
+  __shared__ uint8_t q_g[NLB_QCAP];       // which voxel of the group
+  __shared__ uint32_t s_vid[NLB_G];
+  __shared__ int s_start[NLB_G + 1], s_kept[NLB_G];
   const int lane = threadIdx.x;
-  const uint32_t i = used_ids[u];
-  const int n = (int)adj_cnt[u];
-  const uint64_t* row = adj_key + u * adj_stride;
-  // a row whose centre distances are not within half a lattice step^2 of their offsets' integer lengths (coordinates so
-  // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
-  if (gtab[u * gstride] == 0xffffu) { if (lane == 0) out_cnt[i] = NL_NONE; return; }
-  const NodeRec me = node[i];
-  const float ax = (me.flags & VGS_F_POS) ? me.c[0] : vm_nan();   // as the cut stages centroids: an unusable position is a NaN x
-  int total = 0;
-  for (int base = 1; base < n; base += 64) {   // entry 0 is the voxel itself
-    const int k = base + lane;
-    bool cand = false;
-    uint32_t t = 0;
-    if (k < n) {
-      const uint64_t kk = row[k];
-      cand = vm_from_bits((uint32_t)(kk >> 32)) <= lat_d2_lim;   // centre distance: beyond sqrt(12) lattice steps no offset fits the reach
-      t = (uint32_t)kk;
-    }
-    if (__ballot(cand) == 0ull) break;   // the row is sorted by centre distance
-    bool valid = false;
-    float d2 = 0.f, w = 0.f;
-    uint32_t slot = 0;
-    if (cand) {
-      const NodeRec nb = node[t];
-      const int dx = nl_diff10(nb.pad & 1023u, me.pad & 1023u), dy = nl_diff10((nb.pad >> 10) & 1023u, (me.pad >> 10) & 1023u),
-                dz = nl_diff10((nb.pad >> 20) & 1023u, (me.pad >> 20) & 1023u);
-      if (dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
-        const float bx = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
-        const float ex = ax - bx, ey = me.c[1] - nb.c[1], ez = me.c[2] - nb.c[2];   // the cut's own expression (order-free: squares)
-        d2 = (ex * ex + ey * ey) + ez * ez;
-        d2 = (d2 == d2) ? d2 : 1.0e4f;
-        if (d2 < d2max) {
-          w = vm_pair_weight(me, nb, W);
-          valid = w > thr0;   // NaN compares false
-          slot = (uint32_t)(dx + NL_REACH) | ((uint32_t)(dy + NL_REACH) << 4) | ((uint32_t)(dz + NL_REACH) << 8);
+  const int64_t ngroups = (U + NLB_G - 1) / NLB_G;
+  const int64_t grp = vgs_xcd_item(blockIdx.x, ngroups);
+  if (grp >= ngroups) return;
+  const int64_t u0 = grp * NLB_G;
+  const int ng = (int)((U - u0 < NLB_G) ? (U - u0) : NLB_G);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int g = 0;
+  while (g < ng) {
+    // ---- 1. queue the candidates of as many voxels of the group as fit ----
+    const int g_first = g;
+    int nq = 0;
+    for (; g < ng; ++g) {
+      // (2 * NL_REACH + 1)^3 - 1 cells can qualify at most
+      if (nq + ((2 * NL_REACH + 1) * (2 * NL_REACH + 1) * (2 * NL_REACH + 1) - 1) > NLB_QCAP) break;
+      const int64_t u = u0 + g;
+      const uint32_t i = used_ids[u];
+      if (lane == 0) { s_vid[g] = i; s_start[g] = nq; }
+      // a row whose centre distances are not within half a lattice step^2 of their offsets' integer lengths (coordinates so
+      // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
+      if (gtab[u * gstride] == 0xffffu) { if (lane == 0) s_kept[g] = -1; continue; }
+      if (lane == 0) s_kept[g] = 0;
+      const int n = (int)adj_cnt[u];
+      const uint64_t* row = adj_key + u * adj_stride;
+      const NodeRec& me = node[i];
+      const uint32_t mpad = me.pad;
+      const float ax = (me.flags & VGS_F_POS) ? me.c[0] : vm_nan();   // as the cut stages centroids: an unusable position is a NaN x
+      const float ay = me.c[1], az = me.c[2];
+      for (int base = 1; base < n; base += 64) {   // entry 0 is the voxel itself
+        const int k = base + lane;
+        bool cand = false;
+        uint32_t t = 0;
+        if (k < n) {
+          const uint64_t kk = row[k];
+          cand = vm_from_bits((uint32_t)(kk >> 32)) <= lat_d2_lim;   // centre distance: beyond sqrt(12) lattice steps no offset fits the reach
+          t = (uint32_t)kk;
         }
+        if (__ballot(cand) == 0ull) break;   // the row is sorted by centre distance
+        bool ok = false;
+        float d2 = 0.f;
+        uint32_t slot = 0;
+        if (cand) {
+          const NodeRec& nb = node[t];
+          const uint32_t npad = nb.pad;
+          const int dx = nl_diff10(npad & 1023u, mpad & 1023u), dy = nl_diff10((npad >> 10) & 1023u, (mpad >> 10) & 1023u),
+                    dz = nl_diff10((npad >> 20) & 1023u, (mpad >> 20) & 1023u);
+          if (dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
+            const float bx = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
+            const float ex = ax - bx, ey = ay - nb.c[1], ez = az - nb.c[2];   // the cut's own expression (order-free: squares)
+            d2 = (ex * ex + ey * ey) + ez * ez;
+            d2 = (d2 == d2) ? d2 : 1.0e4f;
+            ok = d2 < d2max;
+            slot = (uint32_t)(dx + NL_REACH) | ((uint32_t)(dy + NL_REACH) << 4) | ((uint32_t)(dz + NL_REACH) << 8);
+          }
+        }
+        const unsigned long long mk = __ballot(ok);
+        if (ok) {
+          const int pos = nq + __popcll(mk & lt);   // < NLB_QCAP: checked before the voxel was started
+          q_t[pos] = t; q_d2[pos] = d2; q_slot[pos] = (uint16_t)slot; q_g[pos] = (uint8_t)g;
+        }
+        nq += __popcll(mk);
       }
     }
-    const unsigned long long mk = __ballot(valid);
-    if (valid) {
-      const int pos = total + __popcll(mk & ((1ull << lane) - 1ull));
-      if (pos < NL_S) { s_d2[pos] = d2; s_w[pos] = w; s_slot[pos] = (uint16_t)slot; }
+    if (lane == 0) s_start[g] = nq;
+    __syncthreads();
+    // ---- 2. weights, on full wavefronts ----
+    for (int e = lane; e < nq; e += 64) {
+      const float w = vm_pair_weight(node[s_vid[q_g[e]]], node[q_t[e]], W);   // the list's owner is the FIRST argument
+      q_w[e] = (w > thr0) ? w : vm_nan();   // NaN compares false
     }
-    total += __popcll(mk);
-  }
-  if (total > NL_S) { if (lane == 0) out_cnt[i] = NL_NONE; return; }
-  __syncthreads();
-  if (lane < total) {
-    // ascending (d2, slot): every entry counts the smaller ones
-    const float md = s_d2[lane];
-    const uint32_t ms = s_slot[lane];
-    int r = 0;
-    for (int q = 0; q < total; ++q) {
-      const float qd = s_d2[q];
-      r += (qd < md || (qd == md && (uint32_t)s_slot[q] < ms)) ? 1 : 0;
+    __syncthreads();
+    // ---- 3. every kept entry finds its place in its voxel's list: ascending (d2, slot) among the kept ones ----
+    for (int e = lane; e < nq; e += 64) {
+      const float mw = q_w[e];
+      if (mw == mw) {
+        const int gg = q_g[e];
+        const int s0 = s_start[gg], s1 = s_start[gg + 1];
+        const float md = q_d2[e];
+        const uint32_t ms = q_slot[e];
+        int r = 0;
+        for (int q = s0; q < s1; ++q) {
+          const float qw = q_w[q], qd = q_d2[q];
+          r += (qw == qw && (qd < md || (qd == md && (uint32_t)q_slot[q] < ms))) ? 1 : 0;
+        }
+        if (r < NL_S) {
+          const size_t o = (size_t)s_vid[gg] * NL_S + (size_t)r;
+          out_dw[o] = make_float2(md, mw); out_slot[o] = (uint16_t)ms;
+        }
+        if (s_kept[gg] >= 0) atomicAdd(&s_kept[gg], 1);
+      }
     }
-    const size_t o = (size_t)i * NL_S + (size_t)r;
-    out_dw[o] = make_float2(md, s_w[lane]); out_slot[o] = (uint16_t)ms;
-  } else if (lane < NL_S) {
-    out_dw[(size_t)i * NL_S + (size_t)lane] = make_float2(__builtin_huge_valf(), 0.0f);   // end of list for readers
+    __syncthreads();
+    // ---- 4. counts and end-of-list marks ----
+    for (int x = lane; x < (g - g_first) * NL_S; x += 64) {
+      const int gg = g_first + x / NL_S, j = x % NL_S;
+      const int kept = s_kept[gg];
+      if (kept >= 0 && kept <= NL_S && j >= kept) out_dw[(size_t)s_vid[gg] * NL_S + (size_t)j] = make_float2(__builtin_huge_valf(), 0.0f);
+      if (j == 0) out_cnt[s_vid[gg]] = (kept < 0 || kept > NL_S) ? (uint8_t)NL_NONE : (uint8_t)kept;
+    }
+    __syncthreads();
   }
-  if (lane == 0) out_cnt[i] = (uint8_t)total;
 }
 
 // the lists exist when voxels are on a lattice (VGS), unused voxels are out of the rows (they would need entries too),
@@ -101,7 +145,7 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   const float reach = (float)NL_REACH * res;
   // a pair inside the reach has a lattice offset of at most 3 * NL_REACH^2 squared steps; half a step^2 of slack for the float centres
   const float lat_lim = ((float)(3 * NL_REACH * NL_REACH) + 0.5f) * res * res;
-  hipLaunchKernelGGL(k_near_lists, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+  hipLaunchKernelGGL(k_near_lists, dim3(vgs_xcd_grid((U + NLB_G - 1) / NLB_G)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                      c->node.p, c->adj_gtab.p, c->adj_gstride, W, thr0, lat_lim, reach * reach, c->nl_cnt.p, c->nl_slot.p, c->nl_dw.p);
   VGS_HIP_TRY(c, hipGetLastError());
   c->nl_enabled = true;
