@@ -57,18 +57,20 @@ def cpu_baseline(v, xyz_full, params, target_points=150_000):
 
 
 def profiled_traffic(n_points):
-    """HBM bytes (and VALU wave instructions) per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json,
+    """HBM bytes (and VALU wave instructions) per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r02_traffic.json,
     written by tools/collect_profiles.sh from FETCH_SIZE + WRITE_SIZE of the same bench command); None if the profile
     is missing or was taken on another workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if int(t.get("points", -1)) != int(n_points):
-            return None
-        return float(t["hbm_bytes_per_launch"]), t.get("valu_wave_instructions_per_launch")
-    except (OSError, ValueError, KeyError):
-        return None, None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for tag in ("r02", "r01"):   # the newest round's profile that exists
+        try:
+            with open(os.path.join(prof, f"{tag}_traffic.json")) as f:
+                t = json.load(f)
+            if int(t.get("points", -1)) != int(n_points):
+                continue
+            return float(t["hbm_bytes_per_launch"]), t.get("valu_wave_instructions_per_launch")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def main():

@@ -5,7 +5,7 @@
 #   3. --pmc SQ instruction mix           -> per-kernel averages per launch
 # and <tag>_traffic.json = HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE, both reported in KB).
 # Output: gpurun_out/profiles/ (copy into profiles/ to commit).  usage: tools/collect_profiles.sh r01
-tag=${1:-r01}
+tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profiles
 mkdir -p $out

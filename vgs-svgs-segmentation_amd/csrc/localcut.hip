@@ -512,7 +512,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
   VGS_HIP_TRY(c, c->work_ids.ensure(7 * (size_t)U + 16));
-  VGS_HIP_TRY(c, c->csize.ensure((size_t)(c->V > U ? c->V : U)));  // used here as per-voxel evaluation counters (index u)
+  VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
   VGS_HIP_TRY(c, c->counters.ensure(64));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
   uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, records in LDS, small footprint
@@ -531,7 +531,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
   constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
-  constexpr int SMALL_M = 128, SMALL_CAP = 4096;
+  #ifndef LC_SMALL_CAP
+#define LC_SMALL_CAP 4096
+#endif
+  constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   {
     // near-pair lists for the shells of the one-wavefront classes closest to the voxel (nearlist.hip); built on the main
@@ -586,13 +589,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt, c->csize.p);
+                         c->node.p, LP, c->conn.p, cnt, c->evals.p);
     } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt, c->csize.p);
+                         c->node.p, LP, c->conn.p, cnt, c->evals.p);
     }
     return VGS_OK;
   };
@@ -622,7 +625,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev[2], 0));
       hipLaunchKernelGGL((k_localcut_wave<WAVE_D, LCAP_D, NW_D>), dim3(((nabc[3] + 7) / 8) * 8), dim3(64 * NW_D), 0, c->stream4, (const uint32_t*)nullptr, 0,
                          ids_d, (int)nabc[3], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
-                         ids_g, d_ng, c->csize.p, dbg_buf);
+                         ids_g, d_ng, c->evals.p, dbg_buf);
       VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows both C and D
     }
@@ -630,7 +633,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
-                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->csize.p, dbg_buf);
+                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf);
     // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
     vgs_status st = VGS_OK;
     const unsigned int ncd = nabc[2] + nabc[3];
@@ -642,7 +645,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // classes A and B have the same LDS footprint, so their workgroups interleave freely; B (heavier) goes first
   if (nabc[1] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
-                       ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+                       ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
   // class A1 (the voxels the lazy schedule is likely to work on for long, or give up on) is the launch's first list: the
@@ -650,7 +653,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // hand-overs on a side stream was measured: the 34 KB workgroups of the hand-over kernel starve beside the bulk.)
   if (nabc[0] + nabc[4] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
-                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->csize.p, dbg_buf);
+                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
@@ -665,41 +668,37 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
-  unsigned int nfg[2] = {0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(nfg, d_nf, 8, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+  // one read-back for the stage: the kernels' flags (words 0-7) and the lengths of the hand-over lists (word 11)
+  unsigned long long hc[12] = {0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const unsigned long long* h = hc;
+  const unsigned int nfg[2] = {(unsigned int)(hc[11] & 0xffffffffull), (unsigned int)(hc[11] >> 32)};
   const unsigned int nf = nfg[0] + nfg[1];
-  {
+  if (nfg[0] > grid_f || nfg[1] > GRID_G) {
     // lists longer than their fixed grids (not seen on the benchmark scenes): finish the rest
     vgs_status st = VGS_OK;
     if (nfg[0] > grid_f) st = launch_block(ids_f + grid_f, nfg[0] - grid_f, true);
     if (st == VGS_OK && nfg[1] > GRID_G) st = launch_block(ids_g + GRID_G, nfg[1] - GRID_G, false);
     if (st != VGS_OK) return st;
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+    VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
   c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
-  VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
-  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[10], c->ev[11]));
   c->times[VGS_T_LOCALCUT_BULK] = kms;
-  c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts live in csize until the merge stage reuses it; summed below
-  {
-    std::vector<uint32_t> ev((size_t)U);
-    VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->csize.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-    long long tot = 0;
-    for (uint32_t x : ev) tot += x;
-    c->counts[VGS_N_PAIRS] = tot;
-  }
+  c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
   if (getenv("VGS_DEBUG") && nfg[0] > 0) {
     std::vector<uint32_t> idf(nfg[0]), ev((size_t)U), ac((size_t)U);
     VGS_HIP_TRY(c, hipMemcpy(idf.data(), ids_f, idf.size() * 4, hipMemcpyDeviceToHost));
-    VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->csize.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->evals.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     VGS_HIP_TRY(c, hipMemcpy(ac.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     double sm = 0, se = 0, sp = 0; uint32_t mn = ~0u, mx = 0;
     for (uint32_t u : idf) { sm += ac[u]; se += ev[u]; sp += 0.5 * ac[u] * (ac[u] - 1.0); mn = ac[u] < mn ? ac[u] : mn; mx = ac[u] > mx ? ac[u] : mx; }

@@ -40,10 +40,11 @@
 #define LW_CNT(slot, v) do {} while (0)
 #endif
 
-// wavefronts per SIMD the compiler must leave room for (register budget 512 / LW_WAVES).  7 and 8 run equally fast on
-// URB10M; 8 spills 37 registers to scratch (+0.3 GB of HBM writes per launch), 7 spills one.
+// wavefronts per SIMD the compiler must leave room for (register budget 512 / LW_WAVES).  6 and 7 run equally fast on
+// URB10M; at 7 (72 registers) the kernel spills 48 bytes per lane to scratch (+1.1 GB of HBM writes per launch, measured
+// with WRITE_SIZE), at 6 (80 registers) two registers, once.
 #ifndef LW_WAVES
-#define LW_WAVES 7
+#define LW_WAVES 6
 #endif
 // pairs per lane and trip of the pair enumeration (their LDS reads are issued together); 4 spills 6 registers at 72
 #ifndef LW_TRIP

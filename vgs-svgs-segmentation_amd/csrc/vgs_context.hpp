@@ -148,6 +148,7 @@ struct vgs_ctx {
 
   // local cut / merge
   DevBuf<uint8_t> conn;
+  DevBuf<uint32_t> evals;      // per used voxel: pair evaluations of its local cut (diagnostics, summed on request)
   DevBuf<uint32_t> csize;      // per voxel: list length after crossValidation (0 for unused)
   DevBuf<int32_t> attach;      // per voxel: closestCheck target or -1
   DevBuf<uint8_t> cc_flags;    // per voxel: bit0 candidate, bit1 success

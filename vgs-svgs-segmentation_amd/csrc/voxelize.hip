@@ -5,6 +5,7 @@
 // HBM-bound integer work: one 12/16-byte read per point for the code, one stable LSD radix sort
 // of (code, index) pairs, one run-length pass, one gather of the points into leaf order (SoA) so that
 // the PCA stage reads each voxel's points as one contiguous, ascending-index run.
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 
@@ -263,7 +264,9 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   }
   VGS_HIP_TRY(c, hipMemcpyAsync(d_g, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
   const int pinned = (c->grid_pinned && record_epochs) ? 1 : 0;
-  const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, 4096));
+  // few enough threads that the scan moves through the cloud front to back (a growth step is found within the first
+  // trip or two: the points come in random order), enough to keep the HBM pipes full on the one scan that reads everything
+  const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, getenv("VGS_FV_BLOCKS") ? atoi(getenv("VGS_FV_BLOCKS")) : 512));
   for (int batch = 0; batch < 64; ++batch) {
     // a scene grows its box about log2(extent / voxel) times; pairs queued after the last growth return at once
     for (int k = 0; k < 8; ++k) {
