@@ -89,12 +89,13 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
                                                       uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out) {
   constexpr bool SMALL = MAXM <= 255;  // indices and segment sizes fit a byte
   typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;   // vertex / segment index, segment size
-  typedef typename std::conditional<SMALL, uint16_t, uint32_t>::type pid_t;  // pair id (a << PSH) | b with a < b
+  // pair id = (a << PSH) | b with a < b
   constexpr int PSH = SMALL ? 8 : 16;
   constexpr uint32_t PMASK = (1u << PSH) - 1u;
   constexpr uint32_t PCOMP = SMALL ? 0xffffu : 0xffffffffu;  // stored complemented: descending (w, ~pid) = w desc, pid asc
-  // edge list: lw = weight bits, lp = PCOMP - pid; a dropped entry is (0, 0), below every real edge (real lp >= 1)
-  __shared__ uint32_t lw[LCAP];
+  // edge list: 64-bit keys, weight bits above the complemented pair id -- one compare orders (w desc, pid asc), one LDS
+  // access moves an edge.  A dropped entry is 0, below every real edge; a candidate that has no weight yet is its plain pid.
+  __shared__ uint64_t lk[LCAP];
   // centroids (cx = NaN when the position is unusable, VS:1829) -- or, while the first shell is read from the near-pair
   // lists, the lattice offset of every vertex from the voxel and the vertex sitting at every offset of the 11^3 ball
   // (0xff = none).  The two never live at the same time: the general enumeration stages the centroids when it first runs.
@@ -113,7 +114,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   __shared__ uint32_t claim[MAXM];                // merge: first undecided edge of the step touching a segment (all ones between uses)
   constexpr bool GID_LDS = false;  // ids are read from the adjacency row (L2) when a record is needed: the LDS copy bought nothing and costs list slots
   __shared__ uint32_t gid[GID_LDS ? MAXM : 1];    // global voxel ids: the few pairs that get a full evaluation read their records through L2
-  __shared__ pid_t lp[LCAP];
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM];
   __shared__ idx_t alist[MAXM];  // vertices whose segment can still merge (ascending)
   __shared__ idx_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
@@ -225,9 +225,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {
       if (hi >= cnt) return;
-      const uint32_t xw = lw[lo], yw = lw[hi];
-      const uint32_t xp = lp[lo], yp = lp[hi];
-      if ((xw < yw) || (xw == yw && xp < yp)) { lw[lo] = yw; lw[hi] = xw; lp[lo] = (pid_t)yp; lp[hi] = (pid_t)xp; }
+      const uint64_t x = lk[lo], y = lk[hi];
+      if (x < y) { lk[lo] = y; lk[hi] = x; }
     };
     blk_sync();
     for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       }
       if (inr) {
         const int pos = n_list + base + __popcll(mk & lt_mask);
-        if (pos < LCAP) lp[pos] = (pid_t)pid;
+        if (pos < LCAP) lk[pos] = (uint64_t)pid;
       }
     };
     if (use_minor) {
@@ -348,14 +347,13 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int e = base + lane;
       bool drop = false;
       if (e < n_list + count) {
-        const uint32_t pid = (uint32_t)lp[e];
+        const uint32_t pid = (uint32_t)lk[e];
         const NodeRec& A = R(pid >> PSH);
         const NodeRec& B = R(pid & PMASK);
         float w = 0.0f;
         if (!screen || !(vm_weight_bound_da(A, B, W) <= thr0)) w = vm_pair_weight(A, B, W);
         drop = !(w > thr0);
-        lw[e] = drop ? 0u : vm_bits(w);
-        lp[e] = drop ? (pid_t)0 : (pid_t)(PCOMP - pid);
+        lk[e] = drop ? 0ull : (((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid));
       }
       const int nd = __popcll(__ballot(drop));
       dropped += nd;
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const unsigned long long mk = __ballot(inr);
       if (inr) {
         const int pos = n_list + count + __popcll(mk & lt_mask);
-        if (pos < LCAP) { lw[pos] = vm_bits(e.y); lp[pos] = (pid_t)(PCOMP - pid); }
+        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(e.y) << 32) | (uint64_t)(PCOMP - pid);
       }
       count += __popcll(mk);
       return inside;
@@ -521,9 +519,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       int sa = 0, sb = 0;
       bool alive = false;
       if (e < cnt) {
-        w = vm_from_bits(lw[e]);
+        const uint64_t key = lk[e];
+        w = vm_from_bits((uint32_t)(key >> 32));
         alive = w > level;
-        const uint32_t pid = PCOMP - (uint32_t)lp[e];
+        const uint32_t pid = PCOMP - (uint32_t)key;
         sa = seg[pid >> PSH];
         sb = seg[pid & PMASK];
       }
@@ -589,16 +588,16 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     return __ballot(any) == 0ull;
   };
   // In-place compaction of the candidates [from, from + count) that `live` keeps; returns the number kept.
-  auto close_gaps = [&](int from, int count, bool by_weight) -> int {
+  auto close_gaps = [&](int from, int count) -> int {
     int kept = from;
     for (int base = from; base < from + count; base += 64) {
       const int e = base + lane;
-      uint32_t kw = 0, kp = 0;
-      if (e < from + count) { kw = lw[e]; kp = lp[e]; }
-      const bool live = kp != 0u;   // a dropped entry has lp == 0; a real one has lp >= 1
+      uint64_t kk = 0;
+      if (e < from + count) kk = lk[e];
+      const bool live = kk != 0ull;   // a dropped entry is 0
       const unsigned long long mk = __ballot(live);
       wave_sync();
-      if (live) { const int d = kept + __popcll(mk & lt_mask); if (by_weight) lw[d] = kw; lp[d] = (pid_t)kp; }
+      if (live) { const int d = kept + __popcll(mk & lt_mask); lk[d] = kk; }
       kept += __popcll(mk);
       wave_sync();
     }
@@ -667,7 +666,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         // close the gaps before sorting when that halves the sort network (its length is the next power of two):
         // ascending and in place, a write never passes the read position
         wave_sync();
-        const int kept = close_gaps(n_list, count, true);
+        const int kept = close_gaps(n_list, count);
         n_list = kept;
         sort_list(n_list);
       } else {
@@ -735,16 +734,16 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       for (int base = pos; base < n_list; base += 64) {
         const int e = base + lane;
         bool keep_e = false;
-        uint32_t kw = 0, kp = 0;
+        uint64_t kk = 0;
         if (e < n_list) {
-          kw = lw[e]; kp = lp[e];
-          const uint32_t pid = PCOMP - kp;
+          kk = lk[e];
+          const uint32_t pid = PCOMP - (uint32_t)kk;
           const int sa = seg[pid >> PSH], sb = seg[pid & PMASK];
           keep_e = (sa != sb) && (thr[sa] < level) && (thr[sb] < level);
         }
         const unsigned long long mk = __ballot(keep_e);
         wave_sync();  // all lanes have read their entry before anyone overwrites the front of the list
-        if (keep_e) { const int d = kept + __popcll(mk & lt_mask); lw[d] = kw; lp[d] = (pid_t)kp; }
+        if (keep_e) { const int d = kept + __popcll(mk & lt_mask); lk[d] = kk; }
         kept += __popcll(mk);
         wave_sync();
       }
@@ -789,22 +788,21 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         for (int base = 0; base < Pb; base += 64) {
           while (ia < nb - 1 && qq >= nb - 1 - ia) { qq -= (nb - 1 - ia); ++ia; }
           bool inr = false, evaluated = false;
-          uint32_t kw = 0, kp = 0;
+          uint64_t kk = 0;
           if (ia < nb - 1) {
             const int a = alist[ia], b = alist[ia + 1 + qq];
             if (seg[a] != seg[b]) {
               const float w = vm_pair_weight(R(a), R(b), W);
               evaluated = true;
               inr = (w <= thr0);  // heavier edges were examined in phase A; NaN compares false
-              kw = vm_bits(w);
-              kp = PCOMP - (((uint32_t)a << PSH) | (uint32_t)b);
+              kk = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - (((uint32_t)a << PSH) | (uint32_t)b));
             }
           }
           n_evals += (unsigned int)__popcll(__ballot(evaluated));
           const unsigned long long mk = __ballot(inr);
           if (inr) {
             const int pos = count + __popcll(mk & lt_mask);
-            if (pos < LCAP) { lw[pos] = kw; lp[pos] = (pid_t)kp; }
+            if (pos < LCAP) lk[pos] = kk;
           }
           count += __popcll(mk);
           qq += 64;
