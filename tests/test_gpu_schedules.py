@@ -1,0 +1,99 @@
+"""The round-2 schedules of the local cut and the adjacency search must not show in any result: near-pair lists
+(nearlist.hip: shells inside two lattice steps read stored weights), the split of the bulk class, and the brick-mask
+candidate search (k_adjacency_masks) are compared with the oracle (DevMath, lean: bit-exact bar) on inputs chosen to reach
+their corners -- lists that overflow (NL_NONE), balls wider than the lists' offset map, list ends behind entry 16,
+rows handed to the general adjacency kernel -- and against the same engine with each schedule switched off."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import canonical_labels, oracle_params, ragged_lists, ragged_sets
+
+pytestmark = pytest.mark.gpu
+
+
+def _slab_scene(n, seed, thickness=0.35):
+    """A thick slab with a gentle ripple: voxels filled in three dimensions with consistent normals -- every voxel has far more
+    than 32 neighbours within two lattice steps (near-pair lists overflow when the cut keeps them all) and adjacency rows
+    longer than the mask kernel's list."""
+    rng = np.random.default_rng(seed)
+    side = np.sqrt(n / (2500.0 * (thickness / 0.1)))
+    x = rng.random(n) * side - side / 2 + 0.013
+    y = rng.random(n) * side - side / 2 + 0.027
+    z = rng.random(n) * thickness + 0.02 * np.sin(3.0 * x) + 1.0
+    return np.stack([x, y, z], axis=1).astype(np.float32)
+
+
+CASES = [
+    # name, scene, n, params
+    ("urban_loose_cut", "urban", 90_000, dict(voxel_size=0.1, cut_thred=0.6)),          # thr0 = 0.4: long lists, entries behind 16
+    ("urban_tight_cut", "urban", 90_000, dict(voxel_size=0.1, cut_thred=0.1)),          # thr0 = 0.9: short lists, many rounds
+    ("urban_sig_w1", "urban", 90_000, dict(voxel_size=0.1, sig_w=1.0)),
+    ("town_r3", "town", 70_000, dict()),                                                # voxel 0.15: ball of 3 voxels, 3x3x3 bricks
+    ("urban_r6", "urban", 90_000, dict(voxel_size=0.08)),                               # ball of 6.25 voxels: beyond the offset map, lists off
+    ("slab_overflow", "slab", 70_000, dict(voxel_size=0.1, cut_thred=0.9)),             # thr0 = 0.1: > 32 heavy near pairs -> no list
+    ("slab_default", "slab", 70_000, dict(voxel_size=0.1)),
+]
+
+
+def _scene(gpu, kind, n):
+    if kind == "slab":
+        return _slab_scene(n, 5)
+    return {"urban": gpu.scenes.urban_scene, "town": gpu.scenes.town_scene}[kind](n)
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def case(request, gpu, oracle):
+    name, kind, n, kw = request.param
+    xyz = _scene(gpu, kind, n)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    return dict(name=name, xyz=xyz, p=p, eng=eng, ref=ref)
+
+
+def test_adjacency_exact_order(case):
+    eng, ref = case["eng"], case["ref"]
+    used = np.nonzero(ref.nodes()["used"])[0]
+    gl, rl = ragged_lists(*eng.lists("adjacency")), ragged_lists(*ref.lists("adjacency"))
+    bad = [int(v) for v in used if gl[v] != rl[v]]
+    assert not bad, f"{len(bad)} adjacency rows differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("which", ["connect_cut", "connect_cross", "connect_final"])
+def test_connect_lists_exact(case, which):
+    gs, rs = ragged_sets(*case["eng"].lists(which)), ragged_sets(*case["ref"].lists(which))
+    bad = [v for v in range(len(rs)) if gs[v] != rs[v]]
+    assert not bad, f"{which}: {len(bad)} of {len(rs)} voxels differ, first {bad[:5]}"
+
+
+def test_labels_identical(case):
+    eng, ref = case["eng"], case["ref"]
+    pl_ref, nc_ref = ref.labels()
+    root, _ = eng.node_labels()
+    np.testing.assert_array_equal(canonical_labels(root), canonical_labels(nc_ref))
+    np.testing.assert_array_equal(eng.point_labels(), pl_ref)
+
+
+@pytest.mark.parametrize("knob", ["VGS_NO_NEAR", "VGS_NO_ADJMASKS", "VGS_A1MAX"])
+def test_same_result_with_the_schedule_off(case, gpu, knob):
+    """The knobs only schedule: rows, connect lists and labels are identical bit for bit (pair-evaluation counts may differ)."""
+    old = os.environ.get(knob)
+    os.environ[knob] = "-1" if knob == "VGS_A1MAX" else "1"
+    try:
+        e2 = gpu.Engine(case["p"])
+        e2.set_points(case["xyz"])
+        e2.run()
+        for which in ("adjacency", "connect_cut", "connect_final"):
+            a, b = e2.lists(which), case["eng"].lists(which)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(e2.point_labels(), case["eng"].point_labels())
+    finally:
+        if old is None:
+            del os.environ[knob]
+        else:
+            os.environ[knob] = old
