@@ -31,14 +31,30 @@ __device__ __forceinline__ int brick_local(uint32_t nx, uint32_t ny, uint32_t nz
   return (int)((nz & 1u) | ((ny & 1u) << 1) | ((nx & 1u) << 2) | ((nz & 2u) << 2) | ((ny & 2u) << 3) | ((nx & 2u) << 4));
 }
 
-// every voxel finds (or creates) its brick's slot and ORs its bits in; the brick's first voxel is the smallest id
+// Every brick gets a slot with the OR of its voxels' bits; the brick's first voxel is the smallest id.  Voxels are
+// sorted by Morton code, so the voxels of a brick are neighbours in the array: a wavefront first ORs the bits of each run
+// of equal brick keys among its lanes (segmented scan, six shuffle steps) and only the last lane of a run goes to the
+// table -- about nine times fewer probes and atomics than one insert per voxel.
 static __global__ void k_brick_insert(const uint64_t* __restrict__ vox_code, const NodeRec* __restrict__ node, int64_t V,
                                Brick* __restrict__ table, uint32_t hbits) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  const uint64_t code = vox_code[v];
-  const unsigned long long key = brick_key(vm_compact21(code >> 2), vm_compact21(code >> 1), vm_compact21(code));  // 0 = empty
-  const unsigned long long bit = 1ull << (code & 63ull);  // == brick_local of the same coordinates
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  unsigned long long key = 0ull, occ = 0ull, usd = 0ull;   // key 0 = no voxel in this lane
+  uint32_t first = 0xffffffffu;
+  if (v < V) {
+    const uint64_t code = vox_code[v];
+    key = brick_key(vm_compact21(code >> 2), vm_compact21(code >> 1), vm_compact21(code));
+    occ = 1ull << (code & 63ull);  // == brick_local of the same coordinates
+    if (node && (node[v].flags & VGS_F_EIG)) usd = occ;
+    first = (uint32_t)v;
+  }
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long ko = __shfl_up(key, o, 64), oo = __shfl_up(occ, o, 64), uo = __shfl_up(usd, o, 64);
+    const uint32_t fo = (uint32_t)__shfl_up((int)first, o, 64);
+    if (lane >= o && ko == key) { occ |= oo; usd |= uo; first = fo < first ? fo : first; }   // runs are contiguous: equal keys o lanes apart span one run
+  }
+  const unsigned long long knext = __shfl_down(key, 1, 64);
+  if (key == 0ull || (lane < 63 && knext == key)) return;   // not the last lane of its run
   const uint32_t mask = (1u << hbits) - 1u;
   uint32_t s = hash_slot(key, hbits);
   while (true) {
@@ -46,9 +62,9 @@ static __global__ void k_brick_insert(const uint64_t* __restrict__ vox_code, con
     if (prev == 0ull || prev == key) break;
     s = (s + 1) & mask;
   }
-  atomicOr(&table[s].occ, bit);
-  if (node && (node[v].flags & VGS_F_EIG)) atomicOr(&table[s].used, bit);
-  atomicMin(&table[s].first, (uint32_t)v);
+  atomicOr(&table[s].occ, occ);
+  if (usd) atomicOr(&table[s].used, usd);
+  atomicMin(&table[s].first, first);
 }
 
 // voxel id in lattice cell (nx, ny, nz), -1 if empty; *is_used tells whether that voxel has > points_min points

@@ -608,7 +608,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   dbg_buf = s_dbg.p;
 #endif
   VGS_HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->conn.p, 0, (size_t)U * c->adj_stride, c->stream));  // connect flags start at 0
+  // every kernel writes the whole row of its voxel (0.2 GB that need no memset); only the diagnostic early exits leave rows behind
+  if (WP.dbg_stop != 0 || WP.shell0 < 0.0f) VGS_HIP_TRY(c, hipMemsetAsync(c->conn.p, 0, (size_t)U * c->adj_stride, c->stream));
   // The heavy classes (few, long-running wavefronts with a large LDS footprint) run on two side streams and are
   // launched BEFORE the bulk class: once the bulk class has filled every CU's LDS with its small workgroups a 35 KB
   // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).

@@ -826,8 +826,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // ---- result: the segment of vertex 0 (the voxel itself) ----
   {
     const int s0 = seg[0];
-    for (int c = lane; c < m; c += 64)
-      if ((int)seg[c] == s0) crow[c] = 1;
+    for (int c = lane; c < m; c += 64) crow[c] = ((int)seg[c] == s0) ? 1 : 0;   // the whole row: nobody zeroes the table first
   }
   if (lane == 0) evals_out[u] = n_evals;  // summed on the host on request: no same-address atomics on the hot path
 #ifdef VGS_PROF

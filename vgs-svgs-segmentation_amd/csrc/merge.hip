@@ -193,9 +193,11 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
   }
 }
 
-__global__ void k_iota(uint32_t* p, int64_t n) {
+// one pass instead of five fills: parent = identity, the per-voxel tables of the stage at their start values
+__global__ void k_merge_init(uint32_t* __restrict__ parent, uint32_t* __restrict__ csize, int32_t* __restrict__ attach,
+                             uint8_t* __restrict__ cc_flags, uint32_t* __restrict__ csz, int64_t n) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) p[v] = (uint32_t)v;
+  if (v < n) { parent[v] = (uint32_t)v; csize[v] = 0u; attach[v] = -1; cc_flags[v] = 0; csz[v] = 0u; }
 }
 
 // first hook (ECL-CC style): every used voxel points at its smallest trusted neighbour with a smaller id.  Ids only
@@ -343,16 +345,12 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->vox_label.ensure(V));
   VGS_HIP_TRY(c, c->counters.ensure(16));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint64_t), c->stream));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->csize.p, 0, V * sizeof(uint32_t), c->stream));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->attach.p, 0xff, V * sizeof(int32_t), c->stream));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->cc_flags.p, 0, V * sizeof(uint8_t), c->stream));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->csz.p, 0, V * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_merge_init, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, c->csize.p, c->attach.p, c->cc_flags.p, c->csz.p, V);
   uint8_t* mutual = nullptr;
   unsigned int n_cand = 0, n_succ = 0;
   if (U > 0) {
     if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
-    hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, c->have_region ? nullptr : c->parent.p,
                        (c->P.method == 2 && c->adj_have_gtab) ? c->adj_gtab.p : nullptr, c->adj_gstride, c->adj_nrank.p,
@@ -384,7 +382,6 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   }
   // connected components
   if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
-  if (U == 0) hipLaunchKernelGGL(k_iota, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0 && c->have_region)
     hipLaunchKernelGGL(k_cc_init, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
