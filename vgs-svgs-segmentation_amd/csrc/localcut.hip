@@ -27,6 +27,9 @@
 #include "vgs_context.hpp"
 
 #define LC_TB 256
+#ifndef LC_SMALL_CAP
+#define LC_SMALL_CAP 4096   // edge list of the hand-over kernel for up to 128 neighbours
+#endif
 #define LC_NBIN 2048
 
 struct LcParams {
@@ -497,6 +500,10 @@ static size_t lc_smem_bytes() {
   return (size_t)CAP * 8 + (NODES_LDS ? (size_t)MAXM * sizeof(NodeRec) : 0) + (size_t)MAXM * (4 + 4 + 2 + 2 + 2) + 64;
 }
 
+#ifdef VGS_PROF
+static DevBuf<uint32_t> s_dbg;   // per-voxel cycle / round counters of the diagnostics build
+#endif
+
 vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const int64_t U = c->U;
   c->counts[VGS_N_PAIRS] = 0;
@@ -531,10 +538,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
   constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
-  #ifndef LC_SMALL_CAP
-#define LC_SMALL_CAP 4096
-#endif
-  constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
+    constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   {
     // near-pair lists for the shells of the one-wavefront classes closest to the voxel (nearlist.hip); built on the main
@@ -570,6 +574,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
   WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
   WP.dbg_max_m = getenv("VGS_DBG_MAXM") ? atoi(getenv("VGS_DBG_MAXM")) : 0;
+  VGS_HIP_TRY(c, c->lc_pending.ensure((size_t)U)); VGS_HIP_TRY(c, c->lc_defer.ensure((size_t)U));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
+  WP.pending = c->lc_pending.p;
   {
     // Shells up to (NL_REACH voxels)^2 are complete in the near-pair lists; the margin covers centroids that float
     // rounding puts a hair outside their voxel's cube.
@@ -602,7 +609,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   static_assert(WAVE_B <= SMALL_M, "wave-kernel hand-overs must fit the mid-size workgroup kernel");
   uint32_t* dbg_buf = nullptr;
 #ifdef VGS_PROF
-  static DevBuf<uint32_t> s_dbg;
   VGS_HIP_TRY(c, s_dbg.ensure(4 * (size_t)U));
   VGS_HIP_TRY(c, hipMemset(s_dbg.p, 0, 16 * (size_t)U));
   dbg_buf = s_dbg.p;
@@ -635,6 +641,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf);
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));   // class C done (its hand-overs follow)
     // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
     vgs_status st = VGS_OK;
     const unsigned int ncd = nabc[2] + nabc[3];
@@ -656,46 +663,99 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
                        ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
-  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
-  // trip before the launch); the host checks the length afterwards.
+  // trip before the launch); the host checks the length afterwards (vgs_localcut_finish).  The kernel runs on the side
+  // stream of class B, behind the bulk, and is NOT waited for here: the merge stage starts crossValidation on the rows that
+  // touch no handed-over voxel meanwhile (its small workgroups leave the LDS to the 34 KB workgroups of this kernel).
   // (A second pass through the wave kernel with a 1024-edge list and 16 rounds was measured: it costs as much as the
   // workgroup kernel and still hands half of them over.)
   const unsigned int nab = nabc[0] + nabc[1] + nabc[4];
   // about 1.4 % of the A/B voxels are handed over on the urban scenes; idle workgroups of this kernel are not free
   const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
   {
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->stream3;  // launch_block uses c->stream
     vgs_status st = launch_block(ids_f, grid_f, true, d_nf, 0);
+    c->stream = main_stream;
     if (st != VGS_OK) return st;
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[4], c->stream3));
   }
+  // the main stream goes on once every class has produced its rows or marked them pending
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
+  if (nabc[3] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[12], 0));
+  c->lc_tail.open = true; c->lc_tail.grid_f = grid_f; c->lc_tail.grid_g = GRID_G;
+  for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
+  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
+  c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
+  VGS_HIP_TRY(c, hipGetLastError());
+  return VGS_OK;
+}
+
+// Second half of the stage, called by the merge stage once it has nothing left to do beside the hand-over kernels: waits
+// for them, reads the stage's flags and list lengths back (one copy), finishes lists longer than their fixed grids, and
+// returns the number of rows crossValidation has put off.
+vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
+  if (n_deferred) *n_deferred = 0;
+  if (!c->lc_tail.open) return VGS_OK;
+  c->lc_tail.open = false;
+  const int64_t U = c->U;
+  unsigned long long* cnt = (unsigned long long*)c->counters.p;
+  const unsigned int grid_f = c->lc_tail.grid_f, GRID_G = c->lc_tail.grid_g;
+  uint32_t* ids_f = c->work_ids.p + 4 * U;
+  uint32_t* ids_g = c->work_ids.p + 5 * U;
+  LcParams LP;
+  LP.W = make_weight_params(c->P);
+  LP.cut = c->P.cut_thred;
+  LP.prune_unused = 0;
+  constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
+  constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
+  auto launch_rest = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
+    if (nw == 0) return VGS_OK;
+    if (mid) {
+      auto kern = k_localcut<SMALL_M, SMALL_CAP, false>;
+      const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
+      VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p);
+    } else {
+      auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
+      const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
+      VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p);
+    }
+    return VGS_OK;
+  };
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-  // one read-back for the stage: the kernels' flags (words 0-7) and the lengths of the hand-over lists (word 11)
-  unsigned long long hc[12] = {0};
+  // one read-back: the kernels' flags (words 0-7), the lengths of the hand-over lists (word 11), the rows put off (word 13)
+  unsigned long long hc[14] = {0};
   VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   const unsigned long long* h = hc;
   const unsigned int nfg[2] = {(unsigned int)(hc[11] & 0xffffffffull), (unsigned int)(hc[11] >> 32)};
   const unsigned int nf = nfg[0] + nfg[1];
+  if (n_deferred) *n_deferred = (unsigned int)(hc[13] & 0xffffffffull);
   if (nfg[0] > grid_f || nfg[1] > GRID_G) {
     // lists longer than their fixed grids (not seen on the benchmark scenes): finish the rest
     vgs_status st = VGS_OK;
-    if (nfg[0] > grid_f) st = launch_block(ids_f + grid_f, nfg[0] - grid_f, true);
-    if (st == VGS_OK && nfg[1] > GRID_G) st = launch_block(ids_g + GRID_G, nfg[1] - GRID_G, false);
+    if (nfg[0] > grid_f) st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true);
+    if (st == VGS_OK && nfg[1] > GRID_G) st = launch_rest(ids_g + GRID_G, nfg[1] - GRID_G, false);
     if (st != VGS_OK) return st;
     VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
     VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
   VGS_HIP_TRY(c, hipGetLastError());
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[10], c->ev[11]));
   c->times[VGS_T_LOCALCUT_BULK] = kms;
-  c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
   if (getenv("VGS_DEBUG") && nfg[0] > 0) {
     std::vector<uint32_t> idf(nfg[0]), ev((size_t)U), ac((size_t)U);
     VGS_HIP_TRY(c, hipMemcpy(idf.data(), ids_f, idf.size() * 4, hipMemcpyDeviceToHost));
@@ -722,7 +782,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 #ifdef VGS_PROF
   {
     std::vector<uint32_t> dbg(4 * (size_t)U);
-    VGS_HIP_TRY(c, hipMemcpy(dbg.data(), dbg_buf, dbg.size() * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(dbg.data(), s_dbg.p, dbg.size() * 4, hipMemcpyDeviceToHost));
     // histogram of per-voxel cost by m bucket
     double cyc[9] = {0}, cntb[9] = {0}, rnd[9] = {0}, evl[9] = {0}; double maxc = 0; size_t maxu = 0;
     for (size_t q = 0; q < (size_t)U; ++q) { uint32_t mm = dbg[4*q]; if (!mm) continue; int b = mm <= 32 ? 0 : mm <= 64 ? 1 : mm <= 96 ? 2 : mm <= 128 ? 3 : mm <= 160 ? 4 : mm <= 192 ? 5 : mm <= 224 ? 6 : 7; double cy = 16.0 * dbg[4*q+2]; cyc[b] += cy; cntb[b] += 1; rnd[b] += dbg[4*q+1]; evl[b] += dbg[4*q+3]; if (cy > maxc) { maxc = cy; maxu = q; } }

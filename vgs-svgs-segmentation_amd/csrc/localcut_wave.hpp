@@ -62,6 +62,7 @@ struct LwParams {
   int max_rounds;   // shells a wavefront works through before it hands the voxel over (classes A/B)
   int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
   NearLists near;   // per-voxel lists of the heavy pairs within two lattice steps (nearlist.hpp): the first shell walks them
+  uint8_t* pending; // per used voxel: set when the voxel is handed over (its connect row is final only after the hand-over kernel)
 };
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   auto R = [&](int v) -> const NodeRec& { return node[GID_LDS ? gid[v] : (uint32_t)row[v]]; };
   const int m = n;
   if (m > MAXM || (P.dbg_max_m > 0 && m > P.dbg_max_m)) {  // beyond this kernel's arrays: hand over to the general kernel
-    if (threadIdx.x == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
+    if (threadIdx.x == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; P.pending[u] = 1; }
     return;
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     }
   }
   if (bail) {
-    if (lane == 0) fallback[atomicAdd(n_fallback, 1u)] = u;
+    if (lane == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; P.pending[u] = 1; }
     return;
   }
   // ---- result: the segment of vertex 0 (the voxel itself) ----

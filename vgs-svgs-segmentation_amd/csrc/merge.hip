@@ -33,10 +33,18 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                               int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
                                               uint32_t* __restrict__ csize, uint32_t* __restrict__ parent,
-                                              const uint16_t* __restrict__ gtab, int gstride, const uint8_t* __restrict__ nrank, float inv_res2) {
-  const int64_t u = vgs_xcd_item(blockIdx.x, U);
-  if (u >= U) return;
+                                              const uint16_t* __restrict__ gtab, int gstride, const uint8_t* __restrict__ nrank, float inv_res2,
+                                              const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
+                                              unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work) {
+  // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
+  // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
+  // (work != null): the rows put off.
+  int64_t u;
+  if (work) { if ((int)blockIdx.x >= n_work) return; u = (int64_t)work[blockIdx.x]; }
+  else { u = vgs_xcd_item(blockIdx.x, U); if (u >= U) return; }
   const int lane = threadIdx.x;
+  if (pending && pending[u]) { if (lane == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; return; }
+  bool touches_pending = false;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + u * adj_stride;
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
       } else {
         const uint32_t ut = used_rank[t];
         if (ut != 0xffffffffu) {
+          if (pending && pending[ut]) touches_pending = true;
           const uint64_t want = (key & 0xffffffff00000000ull) | (uint64_t)i;
           const uint64_t* trow = adj_key + (int64_t)ut * adj_stride;
           int lo = 0, hi = -1, found = -1;
@@ -94,6 +103,10 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
     }
     mrow[k] = mflag;
     kept += mflag;
+  }
+  if (pending && __ballot(touches_pending) != 0ull) {   // what was written to the row is overwritten by the second pass
+    if (lane == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u;
+    return;
   }
   for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
   if (lane == 0) csize[i] = (uint32_t)kept;
@@ -343,22 +356,39 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->csize.ensure(V)); VGS_HIP_TRY(c, c->attach.ensure(V)); VGS_HIP_TRY(c, c->cc_flags.ensure(V));
   VGS_HIP_TRY(c, c->parent.ensure(V)); VGS_HIP_TRY(c, c->csz.ensure(V)); VGS_HIP_TRY(c, c->kept_rank.ensure(V + 1));
   VGS_HIP_TRY(c, c->vox_label.ensure(V));
-  VGS_HIP_TRY(c, c->counters.ensure(16));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(uint64_t), c->stream));
+  // this stage's counters live in words 48-55: words 0-13 still belong to the local cut, whose hand-over kernels may be running
+  VGS_HIP_TRY(c, c->counters.ensure(64));
+  uint64_t* mcnt = c->counters.p + 48;
+  VGS_HIP_TRY(c, hipMemsetAsync(mcnt, 0, 8 * sizeof(uint64_t), c->stream));
   hipLaunchKernelGGL(k_merge_init, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, c->csize.p, c->attach.p, c->cc_flags.p, c->csz.p, V);
   uint8_t* mutual = nullptr;
   unsigned int n_cand = 0, n_succ = 0;
   if (U > 0) {
     if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
+    const uint16_t* gt = (c->P.method == 2 && c->adj_have_gtab) ? c->adj_gtab.p : nullptr;
+    const float inv_res2 = 1.0f / (c->P.voxel_size * c->P.voxel_size);
+    uint32_t* cross_parent = c->have_region ? nullptr : c->parent.p;
+    unsigned int* d_ndefer = (unsigned int*)(c->counters.p + 13);   // zeroed with the local cut's counters
+    // crossValidation starts while the hand-over kernels of the local cut still run (vgs_stage_localcut): rows that touch a
+    // handed-over voxel are put off, ...
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, c->conn.p, mutual, c->csize.p, c->have_region ? nullptr : c->parent.p,
-                       (c->P.method == 2 && c->adj_have_gtab) ? c->adj_gtab.p : nullptr, c->adj_gstride, c->adj_nrank.p,
-                       1.0f / (c->P.voxel_size * c->P.voxel_size));
+                       c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
+                       c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0);
+    // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
+    unsigned int n_defer = 0;
+    {
+      vgs_status sf = vgs_localcut_finish(c, &n_defer);
+      if (sf != VGS_OK) return sf;
+    }
+    if (n_defer > 0)
+      hipLaunchKernelGGL(k_cross, dim3(n_defer), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
+                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer);
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
-    unsigned int* d_ncand = (unsigned int*)(c->counters.p + 0);
-    unsigned int* d_changed = (unsigned int*)(c->counters.p + 1);
+    unsigned int* d_ncand = (unsigned int*)(mcnt + 0);
+    unsigned int* d_changed = (unsigned int*)(mcnt + 1);
     hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_mused.p,
                        c->csize.p, MP.adjacency_min, c->cc_flags.p, c->work_ids.p, d_ncand);
     VGS_HIP_TRY(c, hipMemcpyAsync(&n_cand, d_ncand, 4, hipMemcpyDeviceToHost, c->stream));
@@ -394,7 +424,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   uint32_t* keep_flag = c->head_flag.p;  // >= N >= V entries, free after features
   VGS_HIP_TRY(c, c->head_flag.ensure(V + 1));
   keep_flag = c->head_flag.p;
-  unsigned int* d_nroots = (unsigned int*)(c->counters.p + 2);
+  unsigned int* d_nroots = (unsigned int*)(mcnt + 2);
   hipLaunchKernelGGL(k_root_flags, dim3((unsigned)((V + 1023) / 1024)), dim3(1024), 0, c->stream, c->parent.p, c->csz.p, V, c->P.method == 3 ? -1 : c->P.voxels_min,
                      keep_flag, d_nroots);
   size_t bytes = 0;
@@ -411,7 +441,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipMemcpyAsync(&last_rank, c->kept_rank.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipMemcpyAsync(&last_flag, keep_flag + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (U > 0 && n_cand > 0) VGS_HIP_TRY(c, hipMemcpy(&n_succ, (unsigned int*)(c->counters.p + 1), 4, hipMemcpyDeviceToHost));
+  if (U > 0 && n_cand > 0) VGS_HIP_TRY(c, hipMemcpy(&n_succ, (unsigned int*)(mcnt + 1), 4, hipMemcpyDeviceToHost));
   c->counts[VGS_N_REATTACHED] = n_succ;
   c->counts[VGS_N_CLUSTERS] = n_roots;
   c->counts[VGS_N_KEPT] = (int64_t)last_rank + last_flag;

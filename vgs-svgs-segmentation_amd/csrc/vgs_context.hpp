@@ -149,6 +149,11 @@ struct vgs_ctx {
   // local cut / merge
   DevBuf<uint8_t> conn;
   DevBuf<uint32_t> evals;      // per used voxel: pair evaluations of its local cut (diagnostics, summed on request)
+  // hand-overs of the local cut run on a side stream while the merge stage already cross-validates the rows they cannot
+  // touch: per used voxel "handed over, connect row not final yet", the rows put off, and what vgs_localcut_finish needs
+  DevBuf<uint8_t> lc_pending;
+  DevBuf<uint32_t> lc_defer;
+  struct { bool open = false; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; } lc_tail;
   DevBuf<uint32_t> csize;      // per voxel: list length after crossValidation (0 for unused)
   DevBuf<int32_t> attach;      // per voxel: closestCheck target or -1
   DevBuf<uint8_t> cc_flags;    // per voxel: bit0 candidate, bit1 success
@@ -209,7 +214,8 @@ vgs_status vgs_stage_adjacency(vgs_ctx* c);
 vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2);
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_nearlists(vgs_ctx* c);   // part of the local-cut stage
-vgs_status vgs_stage_localcut(vgs_ctx* c);
+vgs_status vgs_stage_localcut(vgs_ctx* c);   // launches everything; its hand-over kernels may still run when it returns
+vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred);  // waits for them, checks the stage's flags (called by the merge stage)
 vgs_status vgs_stage_merge(vgs_ctx* c);
 vgs_status vgs_stage_vccs(vgs_ctx* c);
 vgs_status vgs_stage_svgs_group(vgs_ctx* c);
