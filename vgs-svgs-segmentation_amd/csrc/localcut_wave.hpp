@@ -575,20 +575,20 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   };
 
   // ---- can the voxel itself ever merge?  While it is a singleton it needs an incident edge heavier than thr0.  On
-  // surfaces vertex 0 joins a segment in the first shell, so the test is only made when it has not (after shell one).
+  // surfaces vertex 0 joins a segment in the first shell, so the test is only made when it has not (after shell one):
+  // the cheap bound first, the full weight for the pairs it lets through -- at most m - 1 evaluations that save a voxel
+  // in clutter from working through every shell (and from being handed over) only to end up alone.
   auto never_merges = [&]() -> bool {
     bool any = false;
     for (int base = 1; base < m; base += 64) {
       const int x = base + lane;
-      if (x < m) {
-        // the cheap bound alone: "not provably isolated" just means the voxel takes the normal path
-        const float ub = vm_weight_bound_da(R(0), R(x), W);
-        any = any || !(ub <= thr0);
-      }
+      bool heavy = false;
+      if (x < m && !(vm_weight_bound_da(R(0), R(x), W) <= thr0)) heavy = vm_pair_weight(R(0), R(x), W) > thr0;
+      any = any || heavy;
     }
     return __ballot(any) == 0ull;
   };
-  // In-place compaction of the candidates [from, from + count) that `live` keeps; returns the number kept.
+  // In-place compaction of the entries [from, from + count) that are not dropped (0); returns the new end of the list.
   auto close_gaps = [&](int from, int count) -> int {
     int kept = from;
     for (int base = from; base < from + count; base += 64) {
