@@ -144,6 +144,12 @@ vgs_status vgs_grid_state_init(vgs_grid_state* g);
 /* advance g over this context's points in index order (what inserting them after all earlier ranks' points does
  * to the octree box); call on rank r after receiving g from rank r-1 */
 vgs_status vgs_grid_advance(vgs_ctx* ctx, vgs_grid_state* g);
+/* shortcut of the chain: bounding box (min x, y, z, max x, y, z) and number of the finite points of this context's cloud,
+ * and the replay of the growth over a cloud of which only that box is known (host arithmetic, no context).  The replay
+ * advances g while the growth step is the same for every point outside the box and sets *need_scan when it is not (or
+ * when g is still undefined): then vgs_grid_advance on the owner of the cloud continues from the state reached. */
+vgs_status vgs_points_bbox(vgs_ctx* ctx, float* bbox6, int64_t* n_finite);
+vgs_status vgs_grid_advance_bbox(vgs_grid_state* g, double voxel_size, const float* bbox6, int32_t* need_scan);
 /* pin the final grid before vgs_voxelize: every rank bins with the state left by the last rank */
 vgs_status vgs_set_grid(vgs_ctx* ctx, const vgs_grid_state* g);
 /* this rank owns the voxels whose centre lies in [lo, hi) in x and y; others are halo (computed redundantly,

@@ -65,7 +65,7 @@ def _run_tiled(gpu, parts, params_kw, pitch, world=2):
             seg = TiledSegmenter(gpu.default_params(2, **params_kw), fd, tiles=(world, 1), rank=r, world=world, pitch=pitch)
             seg.set_points_device(d, parts[r])
             seg.run()
-            out[r] = (seg.point_labels(), seg.kept, seg.engine.counts())
+            out[r] = (seg.point_labels(), seg.kept, seg.engine.counts(), seg.engine.bbox(), seg.chain_scans)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             fd.bar.abort()
@@ -97,6 +97,11 @@ def test_two_tiles_match_single_engine(gpu):
     out = _run_tiled(gpu, tiles, kw, pitch)
     tiled = np.concatenate([out[r][0] for r in range(world)])
     assert out[0][1] == out[1][1]
+    # the shared grid is the single engine's octree box, and only the first tile had to scan its points for it: the second
+    # lies beside the box, so its bounding box decides every growth step (vgs_grid_advance_bbox)
+    for r in range(world):
+        np.testing.assert_array_equal(out[r][3], eng.bbox())
+    assert out[0][4] == out[1][4] == 1
     # the tolerance covers closestCheck only (its eligibility test looks one neighbourhood further than the halo)
     agree = partition_agreement(tiled, ref)
     assert agree >= 0.999, agree

@@ -126,3 +126,67 @@ def test_schedule_bounds_dominate_weight(oracle):
                 continue
             assert np.isnan(ub_da) or ub_da >= w, (w, ub_da)
             assert ub_d >= w, (w, ub_d)
+
+
+def _pcl_grow(state, pts, res):
+    """PCL OctreePointCloud::adoptBoundingBoxToPoint over pts in order (SURVEY B.1), as k_adopt / OctreeBox::adopt do it.
+    state = (min[3], shift[3], depth) of a defined box; returns the new state."""
+    eps = 1.1920928955078125e-07
+    mn, sh, depth = [float(v) for v in state[0]], [int(v) for v in state[1]], int(state[2])
+    for p in pts:
+        while True:
+            side = float(1 << depth) * res
+            mx = [mn[a] + side - eps for a in range(3)]
+            hi = [float(p[a]) >= mx[a] for a in range(3)]
+            if not any(hi[a] or float(p[a]) < mn[a] for a in range(3)):
+                break
+            for a in range(3):
+                if not hi[a]:
+                    mn[a] -= side
+                    sh[a] += 1 << depth
+            depth += 1
+    return mn, sh, depth
+
+
+def test_grid_replay_from_bounding_boxes(vgs):
+    """vgs_grid_advance_bbox (host arithmetic of the tile chain): wherever it advances the grid from a cloud's bounding box
+    alone, the state equals PCL's growth over the points themselves; wherever it asks for a scan, continuing with the
+    points from the state it reached ends where the growth over the points from the start ends."""
+    import ctypes as C
+    from vgs_svgs_segmentation_amd._lib import VgsGridState, lib
+    L = lib()
+    rng = np.random.default_rng(3)
+    res = float(np.float32(0.1))
+    n_direct = n_scan = 0
+    for trial in range(300):
+        depth = int(rng.integers(3, 9))
+        side = (1 << depth) * res
+        mn = (rng.random(3) * 20.0 - 10.0)
+        start = (mn.tolist(), [int(x) for x in rng.integers(0, 1000, 3)], depth)
+        # a tile somewhere around the box: inside, beside on one axis, on a diagonal, below ...
+        centre = mn + side * (0.5 + rng.integers(-2, 3, 3) * rng.random(3) * 1.5)
+        ext = side * (0.05 + rng.random(3))
+        pts = (centre + (rng.random((200, 3)) - 0.5) * ext).astype(np.float32)
+        g = VgsGridState()
+        L.vgs_grid_state_init(C.byref(g))
+        for a in range(3):
+            g.min[a] = start[0][a]
+            g.shift[a] = start[1][a]
+        g.depth, g.defined = depth, 1
+        bb = np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32)
+        need = C.c_int32(0)
+        assert L.vgs_grid_advance_bbox(C.byref(g), C.c_double(res), bb.ctypes.data_as(C.c_void_p), C.byref(need)) == 0
+        want = _pcl_grow(start, pts, res)
+        reached = ([g.min[a] for a in range(3)], [int(g.shift[a]) for a in range(3)], int(g.depth))
+        if need.value:
+            n_scan += 1
+            reached = _pcl_grow(reached, pts, res)
+        else:
+            n_direct += 1
+        assert reached[2] == want[2] and reached[1] == want[1] and reached[0] == want[0], (trial, need.value, reached, want)
+    assert n_direct > 50 and n_scan > 20, (n_direct, n_scan)
+    # an undefined grid always needs the points: its first box is placed around the first point
+    g = VgsGridState()
+    L.vgs_grid_state_init(C.byref(g))
+    need = C.c_int32(0)
+    assert L.vgs_grid_advance_bbox(C.byref(g), C.c_double(res), np.zeros(6, np.float32).ctypes.data_as(C.c_void_p), C.byref(need)) == 0 and need.value == 1

@@ -80,6 +80,8 @@ SYMBOLS = [
     ("vgs_get_clusters", C.c_int, [_P, _P, _P]),
     ("vgs_grid_state_init", C.c_int, [C.POINTER(VgsGridState)]),
     ("vgs_grid_advance", C.c_int, [_P, C.POINTER(VgsGridState)]),
+    ("vgs_points_bbox", C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
+    ("vgs_grid_advance_bbox", C.c_int, [C.POINTER(VgsGridState), C.c_double, _P, C.POINTER(C.c_int32)]),
     ("vgs_set_grid", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_set_owned_region", C.c_int, [_P, _P, _P]),
     ("vgs_get_boundary", C.c_int, [_P, _P, _P, _P]),

@@ -150,7 +150,99 @@ __global__ void k_scatter_labels(const int32_t* __restrict__ root, const int32_t
   root_label[r] = label[k];
 }
 
+// per-workgroup bounding box of the finite points: out[6 * block + (min x, y, z, max x, y, z)]
+__global__ __launch_bounds__(256) void k_points_bbox(const float* __restrict__ xyz, int stride_f, int64_t n, float* __restrict__ out,
+                                                     unsigned long long* __restrict__ n_finite) {
+  __shared__ float s_v[6][4];
+  __shared__ unsigned long long s_n[4];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  unsigned long long cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = xyz + i * stride_f;
+    const float x = p[0], y = p[1], z = p[2];
+    const bool fin = (vm_bits(x) & 0x7f800000u) != 0x7f800000u && (vm_bits(y) & 0x7f800000u) != 0x7f800000u && (vm_bits(z) & 0x7f800000u) != 0x7f800000u;
+    if (fin) {
+      lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+      hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+      ++cnt;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { for (int a = 0; a < 3; ++a) { s_v[a][wave] = lo[a]; s_v[3 + a][wave] = hi[a]; } s_n[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) {
+      out[6 * blockIdx.x + a] = fminf(fminf(s_v[a][0], s_v[a][1]), fminf(s_v[a][2], s_v[a][3]));
+      out[6 * blockIdx.x + 3 + a] = fmaxf(fmaxf(s_v[3 + a][0], s_v[3 + a][1]), fmaxf(s_v[3 + a][2], s_v[3 + a][3]));
+    }
+    atomicAdd(n_finite, s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+  }
+}
+
 extern "C" {
+
+vgs_status vgs_points_bbox(vgs_ctx* c, float* bbox6, int64_t* n_finite) {
+  if (!c || !bbox6 || !n_finite) return VGS_E_ARG;
+  if (c->stage < ST_POINTS) { c->err = "vgs_points_bbox: no input cloud"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  *n_finite = 0;
+  for (int a = 0; a < 3; ++a) { bbox6[a] = 0.f; bbox6[3 + a] = 0.f; }
+  if (c->N == 0) return VGS_OK;
+  const int NBLK = 512;
+  VGS_HIP_TRY(c, c->sort_tmp.ensure((size_t)NBLK * 6 * sizeof(float) + 16));
+  VGS_HIP_TRY(c, c->counters.ensure(64));
+  float* d_out = (float*)c->sort_tmp.p;
+  unsigned long long* d_n = (unsigned long long*)(c->counters.p + 34);
+  VGS_HIP_TRY(c, hipMemsetAsync(d_n, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_points_bbox, dim3(NBLK), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_out, d_n);
+  std::vector<float> h((size_t)NBLK * 6);
+  unsigned long long nf = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(h.data(), d_out, h.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_n, 8, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_HIP_TRY(c, hipGetLastError());
+  *n_finite = (int64_t)nf;
+  if (nf == 0) return VGS_OK;
+  for (int a = 0; a < 3; ++a) { bbox6[a] = 3.0e38f; bbox6[3 + a] = -3.0e38f; }
+  for (int b = 0; b < NBLK; ++b)
+    for (int a = 0; a < 3; ++a) { bbox6[a] = std::min(bbox6[a], h[6 * b + a]); bbox6[3 + a] = std::max(bbox6[3 + a], h[6 * b + 3 + a]); }
+  return VGS_OK;
+}
+
+// Host replay of the octree growth over a cloud of which only the bounding box is known.  PCL grows the box for the first
+// point outside it, per axis upwards if the point lies at or above the box's max and downwards otherwise (also on the axes
+// where the point is inside).  When every point outside the box gives the same answer on every axis -- points stick out
+// above the max on exactly one axis and nowhere below, or only below mins -- the step does not depend on WHICH point is
+// first, so it can be taken from the bounding box alone; the test is repeated for the grown box.  Otherwise *need_scan = 1
+// and g is left at the last state reached: vgs_grid_advance continues from there with the points themselves (every point
+// in front of the next violator is inside the current box, so scanning from the first point finds the same violator).
+vgs_status vgs_grid_advance_bbox(vgs_grid_state* g, double voxel_size, const float* bbox6, int32_t* need_scan) {
+  if (!g || !bbox6 || !need_scan || !(voxel_size > 0.0)) return VGS_E_ARG;
+  *need_scan = 0;
+  if (!g->defined) { *need_scan = 1; return VGS_OK; }   // the first box is placed around the first point itself
+  const double eps = 1.1920928955078125e-07;
+  for (int guard = 0; guard < 64; ++guard) {
+    const double side = (double)(1u << g->depth) * voxel_size;
+    int n_hi = 0, n_lo = 0, a_hi = -1;
+    for (int a = 0; a < 3; ++a) {
+      const double mx = g->min[a] + side - eps;
+      if ((double)bbox6[3 + a] >= mx) { ++n_hi; a_hi = a; }
+      if ((double)bbox6[a] < g->min[a]) ++n_lo;
+    }
+    if (n_hi == 0 && n_lo == 0) return VGS_OK;   // every point is inside
+    const bool det = (n_lo == 0 && n_hi == 1) || (n_hi == 0);
+    if (!det || g->depth >= 30) { *need_scan = 1; return VGS_OK; }
+    for (int a = 0; a < 3; ++a)
+      if (a != a_hi || n_hi == 0) { g->min[a] -= side; g->shift[a] += (1ull << g->depth); }   // old root becomes the upper child
+    g->depth++;
+  }
+  *need_scan = 1;
+  return VGS_OK;
+}
 
 vgs_status vgs_grid_state_init(vgs_grid_state* g) {
   if (!g) return VGS_E_ARG;

@@ -220,14 +220,37 @@ class TiledSegmenter:
         self.engine._ck(self.engine._L.vgs_set_owned_region(self.engine._h, _ptr(lo), _ptr(hi)))
 
     def _chain_grid(self):
+        """The shared grid: what inserting the ranks' clouds one after the other does to the octree box.
+        One all-gather of the clouds' bounding boxes lets every rank replay the growth on the host wherever the box alone
+        decides it (vgs_grid_advance_bbox: the usual case for tiles that lie beside the box); only a rank whose cloud leaves
+        the step open -- the first one always: its box starts at its first point -- scans its points on the GPU
+        (vgs_grid_advance) and broadcasts the state.  All ranks run the same replay on the same gathered numbers."""
         import torch
+        L, eng = self.engine._L, self.engine
+        bb = np.zeros(6, dtype=np.float32)
+        nf = C.c_int64(0)
+        eng._ck(L.vgs_points_bbox(eng._h, _ptr(bb), C.byref(nf)))
+        mine = torch.tensor([float(v) for v in bb] + [float(nf.value)], dtype=torch.float64, device=self.coll_device)
+        allbb = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allbb, mine)
+        allbb = [t.cpu().numpy() for t in allbb]
         g = VgsGridState()
-        L = self.engine._L
         L.vgs_grid_state_init(C.byref(g))
-        buf = torch.zeros(8, dtype=torch.float64, device=self.coll_device)
+        self.chain_scans = 0
         for r in range(self.world):
+            if allbb[r][6] == 0:      # no finite point: the cloud changes nothing
+                continue
+            need = C.c_int32(0)
+            box = np.ascontiguousarray(allbb[r][:6], dtype=np.float32)   # float values, exactly as gathered
+            st = L.vgs_grid_advance_bbox(C.byref(g), C.c_double(float(np.float32(self.p.voxel_size))), _ptr(box), C.byref(need))
+            if st != _lib.VGS_OK:
+                raise _lib.VgsError(st, "vgs_grid_advance_bbox")
+            if not need.value:
+                continue
+            self.chain_scans += 1
+            buf = torch.zeros(8, dtype=torch.float64, device=self.coll_device)
             if self.rank == r:
-                self.engine._ck(L.vgs_grid_advance(self.engine._h, C.byref(g)))
+                eng._ck(L.vgs_grid_advance(eng._h, C.byref(g)))
                 vals = [g.min[0], g.min[1], g.min[2], float(g.shift[0]), float(g.shift[1]), float(g.shift[2]), float(g.depth), float(g.defined)]
                 buf = torch.tensor(vals, dtype=torch.float64, device=self.coll_device)
             self.dist.broadcast(buf, src=r)
@@ -236,7 +259,7 @@ class TiledSegmenter:
                 g.min[a] = float(v[a])
                 g.shift[a] = int(v[3 + a])
             g.depth, g.defined = int(v[6]), int(v[7])
-        self.engine._ck(L.vgs_set_grid(self.engine._h, C.byref(g)))
+        eng._ck(L.vgs_set_grid(eng._h, C.byref(g)))
 
     def run(self):
         import os, time
