@@ -686,6 +686,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
   if (nabc[3] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[12], 0));
+  if (getenv("VGS_NO_OVERLAP")) {   // diagnostics: the merge stage starts behind the hand-over kernels
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
+    VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
+  }
   c->lc_tail.open = true; c->lc_tail.grid_f = grid_f; c->lc_tail.grid_g = GRID_G;
   for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
   c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
