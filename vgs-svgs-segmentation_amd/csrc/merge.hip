@@ -29,6 +29,11 @@ struct MgParams {
 };
 
 // ------------------------------------------------------------------ crossValidation
+// CX_ROWS rows per wavefront, 64 / CX_ROWS lanes each (see k_union_mutual: a row of about 120 entries leaves a whole
+// wavefront waiting on its chain of dependent loads; several rows per wavefront keep more of them in flight).
+#ifndef CX_ROWS
+#define CX_ROWS 2
+#endif
 __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_ids, const uint32_t* __restrict__ used_rank, int64_t U,
                                               const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                               int adj_stride, const uint8_t* __restrict__ conn, uint8_t* __restrict__ mutual,
@@ -39,11 +44,26 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
   // (work != null): the rows put off.
+  constexpr int W = 64 / CX_ROWS;
+  const int lane = threadIdx.x, grp = lane / W, sub = lane % W;
+  // rows of the voxel lattice carry a table of where each group of equal offset length starts: the reverse entry has
+  // the same length, so only that group (a handful of entries) is searched instead of the whole row
+  __shared__ uint32_t s_rank4[64];   // length -> group index (256 bytes)
+  if (gtab) s_rank4[lane] = ((const uint32_t*)nrank)[lane];
+  __syncthreads();
+  const uint8_t* s_rank = (const uint8_t*)s_rank4;
   int64_t u;
-  if (work) { if ((int)blockIdx.x >= n_work) return; u = (int64_t)work[blockIdx.x]; }
-  else { u = vgs_xcd_item(blockIdx.x, U); if (u >= U) return; }
-  const int lane = threadIdx.x;
-  if (pending && pending[u]) { if (lane == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; return; }
+  if (work) {
+    const int w = (int)blockIdx.x * CX_ROWS + grp;
+    if (w >= n_work) return;
+    u = (int64_t)work[w];
+  } else {
+    const int64_t ngroups = (U + CX_ROWS - 1) / CX_ROWS;
+    const int64_t g = vgs_xcd_item(blockIdx.x, ngroups);   // consecutive rows share a wavefront, consecutive groups an XCD
+    u = g * CX_ROWS + grp;
+    if (g >= ngroups || u >= U) return;
+  }
+  if (pending && pending[u]) { if (sub == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; return; }
   bool touches_pending = false;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
@@ -52,18 +72,12 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   uint8_t* mrow = mutual + u * adj_stride;
   // a list of length <= 1 is left alone (VS:2120): it is {self}
   int len = 0;
-  for (int k = lane; k < n; k += 64) len += crow[k] ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);
-  // rows of the voxel lattice carry a table of where each group of equal offset length starts: the reverse entry has
-  // the same length, so only that group (a handful of entries) is searched instead of the whole row
+  for (int k = sub; k < n; k += W) len += crow[k] ? 1 : 0;
+  for (int o = W / 2; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);   // xor with o < W stays inside the row's lanes
   const bool own_tab = gtab && gtab[u * gstride] != 0xffffu;
-  __shared__ uint32_t s_rank4[64];   // length -> group index (256 bytes)
-  if (gtab) s_rank4[lane] = ((const uint32_t*)nrank)[lane];
-  __syncthreads();
-  const uint8_t* s_rank = (const uint8_t*)s_rank4;
   int kept = 0;
   uint32_t best = i;  // first hook of the union-find (see k_cc_init): smallest mutual neighbour below i
-  for (int k = lane; k < n; k += 64) {
+  for (int k = sub; k < n; k += W) {
     uint8_t mflag = 0;
     if (crow[k]) {
       const uint64_t key = row[k];
@@ -104,15 +118,18 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
     mrow[k] = mflag;
     kept += mflag;
   }
-  if (pending && __ballot(touches_pending) != 0ull) {   // what was written to the row is overwritten by the second pass
-    if (lane == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u;
-    return;
+  if (pending) {   // what was written to a row that is put off is overwritten by the second pass
+    const unsigned long long mine = (W == 64) ? ~0ull : (((1ull << W) - 1ull) << (grp * W));
+    if ((__ballot(touches_pending) & mine) != 0ull) {
+      if (sub == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u;
+      return;
+    }
   }
-  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
-  if (lane == 0) csize[i] = (uint32_t)kept;
+  for (int o = W / 2; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+  if (sub == 0) csize[i] = (uint32_t)kept;
   if (parent) {  // single-tile runs: the hook needs no ownership test, so it is taken here instead of re-reading the row
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
-    if (lane == 0) parent[i] = best;
+    for (int o = W / 2; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64); best = other < best ? other : best; }
+    if (sub == 0) parent[i] = best;
   }
 }
 
@@ -239,11 +256,20 @@ __global__ __launch_bounds__(64) void k_cc_init(const uint32_t* __restrict__ use
   if (threadIdx.x == 0) parent[i] = best;
 }
 
+// UM_ROWS rows per wavefront, 64 / UM_ROWS lanes each: a row holds about 120 entries, so a whole wavefront per row spends
+// its time waiting for three dependent loads (row header -> keys and flags -> parents); sharing the wavefront keeps several
+// rows' loads in flight at the same occupancy.
+#ifndef UM_ROWS
+#define UM_ROWS 4
+#endif
 __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
                                                      const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent) {
-  const int64_t u = blockIdx.x;  // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
+  constexpr int W = 64 / UM_ROWS;
+  // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
+  const int64_t u = (int64_t)blockIdx.x * UM_ROWS + (threadIdx.x / W);
+  const int sub = threadIdx.x % W;
   if (u >= U) return;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
   // after the first hook and the pointer jumping most neighbours already hang under the same node: equal parents mean
   // one tree, whatever other wavefronts do meanwhile (links are only ever added), and cost one load instead of two finds
   const uint32_t pi = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int k = threadIdx.x; k < n; k += 64) {
+  for (int k = sub; k < n; k += W) {
     if (!mrow[k]) continue;
     const uint32_t t = (uint32_t)row[k];
     // tiled runs: a connection is trusted only if one endpoint is owned (both neighbourhoods are then complete)
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
       uf_union(parent, i, t);
     }
   }
-  if (threadIdx.x == 0) {
+  if (sub == 0) {
     const int32_t t = attach[i];
     if (t >= 0 && (!owned || owned[i])) uf_union(parent, i, (uint32_t)t);
   }
@@ -372,7 +398,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     unsigned int* d_ndefer = (unsigned int*)(c->counters.p + 13);   // zeroed with the local cut's counters
     // crossValidation starts while the hand-over kernels of the local cut still run (vgs_stage_localcut): rows that touch a
     // handed-over voxel are put off, ...
-    hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+    hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                        c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0);
     // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
@@ -382,7 +408,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       if (sf != VGS_OK) return sf;
     }
     if (n_defer > 0)
-      hipLaunchKernelGGL(k_cross, dim3(n_defer), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+      hipLaunchKernelGGL(k_cross, dim3((n_defer + CX_ROWS - 1) / CX_ROWS), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                          (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer);
     // closestCheck
@@ -417,7 +443,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   if (U > 0) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0)
-    hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)U), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+    hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
   // cluster filter + labels
