@@ -50,6 +50,10 @@
 #ifndef LW_TRIP
 #define LW_TRIP 3
 #endif
+// groups of four vertices whose near-pair list entries are requested together (first shells)
+#ifndef LW_NEAR_GROUPS
+#define LW_NEAR_GROUPS 2
+#endif
 
 struct LwParams {
   LcParams lc;
@@ -405,32 +409,36 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       return inside;
     };
     const int j = lane & 15;
-    // two groups of four vertices per trip: their list entries are requested together (the ids come out of registers,
-    // so the only memory round trip of a trip is the entries themselves)
-    for (int base = 0; base < m; base += 8) {
-      const int va0 = base + (lane >> 4), va1 = va0 + 4;
-      const bool a0 = va0 < m, a1 = va1 < m;
-      const size_t o0 = (size_t)vertex_id(va0) * NL_S + (size_t)j, o1 = (size_t)vertex_id(va1) * NL_S + (size_t)j;
-      float2 e0 = make_float2(0.f, 0.f), e1 = make_float2(0.f, 0.f);
-      uint32_t s0 = 0, s1 = 0;
-      if (a0) { e0 = P.near.dw[o0]; s0 = P.near.slot[o0]; }
-      if (a1) { e1 = P.near.dw[o1]; s1 = P.near.slot[o1]; }
-      const bool in0 = take(va0, a0, e0, s0);
-      const bool in1 = take(va1, a1, e1, s1);
+    // LW_NEAR_GROUPS groups of four vertices per trip: their list entries are requested together (the ids come out of
+    // registers, so the only memory round trip of a trip is the entries themselves)
+    for (int base = 0; base < m; base += 4 * LW_NEAR_GROUPS) {
+      float2 e[LW_NEAR_GROUPS];
+      uint32_t sl[LW_NEAR_GROUPS];
+      bool act[LW_NEAR_GROUPS], in[LW_NEAR_GROUPS];
+#pragma unroll
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
+        const int va = base + 4 * g + (lane >> 4);
+        act[g] = va < m;
+        const size_t o = (size_t)vertex_id(va) * NL_S + (size_t)j;
+        e[g] = make_float2(0.f, 0.f); sl[g] = 0;
+        if (act[g]) { e[g] = P.near.dw[o]; sl[g] = P.near.slot[o]; }
+      }
+#pragma unroll
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(base + 4 * g + (lane >> 4), act[g], e[g], sl[g]);
       // the shell may go on behind entry 15 of a vertex: the rest of that list gets a step of its own
-      const unsigned long long more0 = __ballot(in0 && j == 15), more1 = __ballot(in1 && j == 15);
-      for (int g = 0; g < 2; ++g) {
-        unsigned long long more = g ? more1 : more0;
+#pragma unroll
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
+        unsigned long long more = __ballot(in[g] && j == 15);
         while (more) {
           const int l0 = __ffsll((long long)more) - 1;
           more &= more - 1ull;
           const int va = base + (l0 >> 4) + 4 * g;
-          const bool act = lane < NL_S - 16;
+          const bool a2 = lane < NL_S - 16;
           const size_t o = (size_t)vertex_id(va) * NL_S + 16 + (size_t)(lane & 15);
-          float2 e = make_float2(0.f, 0.f);
-          uint32_t sl = 0;
-          if (act) { e = P.near.dw[o]; sl = P.near.slot[o]; }
-          take(va, act, e, sl);
+          float2 e2 = make_float2(0.f, 0.f);
+          uint32_t s2 = 0;
+          if (a2) { e2 = P.near.dw[o]; s2 = P.near.slot[o]; }
+          take(va, a2, e2, s2);
         }
       }
     }

@@ -301,11 +301,22 @@ __global__ void k_compress(uint32_t* __restrict__ parent, int64_t V) {
   if (r != (uint32_t)v) __hip_atomic_store(&parent[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The unions are complete: every voxel gets its ROOT as parent.  The walk must not write on the way (no path halving
+// here): a halving store of another thread that lands after this voxel's final store would leave it pointing at an
+// ancestor below the root, and the labels read parent[v] as the root (seen once in ~20 runs of a 90 k-point scene as a
+// voxel dropped from its segment).  With read-only walks the only writes are the final ones, each a root.
+__device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t x) {
+  while (true) {
+    const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
 __global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, const uint8_t* __restrict__ owned, uint32_t* __restrict__ csz) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
-  const uint32_t r = uf_find(parent, (uint32_t)v);
-  parent[v] = r;   // only shortens paths: concurrent finds stay correct
+  const uint32_t r = uf_root(parent, (uint32_t)v);
+  __hip_atomic_store(&parent[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address)
   unsigned long long todo = __ballot(!owned || owned[v]);   // tiled runs count owned voxels only
   if (owned && !owned[v]) return;
