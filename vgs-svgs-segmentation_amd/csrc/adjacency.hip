@@ -348,6 +348,10 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   const double r = (double)c->P.graph_size;
   const double res = (double)c->P.voxel_size;
   *r2_out = (float)(r * r);  // static_cast<float>(radius * radius) in pcl::KdTreeFLANN::radiusSearch
+  // everything below depends on graph_size / voxel_size only: built and uploaded once per parameter pair, not per run
+  // (four blocking uploads were 0.2 ms of every step)
+  if (c->adj_tab_valid && c->adj_tab_graph == c->P.graph_size && c->adj_tab_voxel == c->P.voxel_size) return VGS_OK;
+  c->adj_tab_valid = false;
   const int R = (int)std::ceil(r / res) + 1;
   if (R > 127) { c->err = "graph_size / voxel_size > 126 voxels"; return VGS_E_UNSUPPORTED; }
   std::vector<std::pair<int, int32_t>> offs;
@@ -410,6 +414,7 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
     VGS_HIP_TRY(c, hipMemcpy(c->adj_nvals.p, nvals.data(), nvals.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     VGS_HIP_TRY(c, hipMemcpy(c->adj_nrank.p, nrank.data(), 256, hipMemcpyHostToDevice));
   }
+  c->adj_tab_graph = c->P.graph_size; c->adj_tab_voxel = c->P.voxel_size; c->adj_tab_valid = true;
   return VGS_OK;
 }
 

@@ -104,9 +104,10 @@ __global__ __launch_bounds__(FEAT_TB) void k_features(const float* __restrict__ 
 }
 
 __global__ void k_compact_used(const uint32_t* __restrict__ used_flag, const uint32_t* __restrict__ excl, int64_t V,
-                               uint32_t* __restrict__ used_ids, uint32_t* __restrict__ used_rank) {
+                               uint32_t* __restrict__ used_ids, uint32_t* __restrict__ used_rank, unsigned long long* __restrict__ n_used) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
+  if (v == V - 1) *n_used = (unsigned long long)excl[v] + used_flag[v];
   if (used_flag[v]) { used_ids[excl[v]] = (uint32_t)v; used_rank[v] = excl[v]; }
   else used_rank[v] = 0xffffffffu;
 }
@@ -128,13 +129,14 @@ vgs_status vgs_stage_features(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, bytes, used_flag, excl, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
   VGS_HIP_TRY(c, c->sort_tmp.ensure(bytes));
   VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, bytes, used_flag, excl, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
-  hipLaunchKernelGGL(k_compact_used, dim3(nb), dim3(FEAT_TB), 0, c->stream, used_flag, excl, V, c->used_ids.p, c->used_rank.p);
-  uint32_t last_e = 0, last_f = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&last_e, excl + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipMemcpyAsync(&last_f, used_flag + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, c->counters.ensure(64));
+  unsigned long long* d_nu = (unsigned long long*)(c->counters.p + 36);
+  hipLaunchKernelGGL(k_compact_used, dim3(nb), dim3(FEAT_TB), 0, c->stream, used_flag, excl, V, c->used_ids.p, c->used_rank.p, d_nu);
+  unsigned long long nu = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(&nu, d_nu, 8, hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
-  c->U = (int64_t)last_e + last_f;
+  c->U = (int64_t)nu;
   c->counts[VGS_N_USED] = c->U;
   return VGS_OK;
 }

@@ -350,11 +350,13 @@ __global__ __launch_bounds__(1024) void k_root_flags(const uint32_t* __restrict_
 }
 
 __global__ void k_voxel_labels(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ keep_flag,
-                               const uint32_t* __restrict__ keep_rank, int64_t V, int32_t* __restrict__ vox_label) {
+                               const uint32_t* __restrict__ keep_rank, int64_t V, int32_t* __restrict__ vox_label,
+                               unsigned int* __restrict__ n_kept) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint32_t r = parent[v];
   vox_label[v] = keep_flag[r] ? (int32_t)keep_rank[r] : -1;
+  if (v == V - 1) *n_kept = keep_rank[v] + keep_flag[v];   // number of kept segments, for the stage's one read-back
 }
 
 __global__ void k_point_labels(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, const int32_t* __restrict__ vox_label,
@@ -431,16 +433,20 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     VGS_HIP_TRY(c, hipMemcpyAsync(&n_cand, d_ncand, 4, hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n_cand > 0) {
-      for (int it = 0; it < 1 << 20; ++it) {
-        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
-        hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
-                           c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
+      // fixed point of "re-attachment succeeds": passes are queued four at a time, each with its own change counter, and
+      // only the last counter is read back (a pass after the fixed point changes nothing and costs microseconds; a host
+      // round trip per pass cost more than the passes)
+      unsigned int* d_chg4 = (unsigned int*)(mcnt + 4);   // words 4-5: four 32-bit counters
+      for (int round = 0; round < 1 << 18; ++round) {
+        VGS_HIP_TRY(c, hipMemsetAsync(d_chg4, 0, 16, c->stream));
+        for (int q = 0; q < 4; ++q)
+          hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
+                             c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_chg4 + q);
         unsigned int ch = 0;
-        VGS_HIP_TRY(c, hipMemcpyAsync(&ch, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+        VGS_HIP_TRY(c, hipMemcpyAsync(&ch, d_chg4 + 3, 4, hipMemcpyDeviceToHost, c->stream));
         VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!ch) break;
       }
-      VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
       hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
                          c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_changed);
     }
@@ -468,20 +474,20 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
   VGS_HIP_TRY(c, c->sort_tmp.ensure(bytes));
   VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
-  hipLaunchKernelGGL(k_voxel_labels, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, keep_flag, c->kept_rank.p, V, c->vox_label.p);
+  hipLaunchKernelGGL(k_voxel_labels, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, keep_flag, c->kept_rank.p, V, c->vox_label.p,
+                     (unsigned int*)(mcnt + 3));
   hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
                      N, c->pt_label.p);
   VGS_HIP_TRY(c, hipGetLastError());
-  unsigned int n_roots = 0;
-  uint32_t last_rank = 0, last_flag = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&n_roots, d_nroots, 4, hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipMemcpyAsync(&last_rank, c->kept_rank.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipMemcpyAsync(&last_flag, keep_flag + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  // one read-back: words 1-3 = re-attachments, roots, kept segments
+  uint64_t hm[4] = {0, 0, 0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(hm, mcnt, sizeof(hm), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (U > 0 && n_cand > 0) VGS_HIP_TRY(c, hipMemcpy(&n_succ, (unsigned int*)(mcnt + 1), 4, hipMemcpyDeviceToHost));
+  const unsigned int n_roots = (unsigned int)hm[2];
+  if (U > 0 && n_cand > 0) n_succ = (unsigned int)hm[1];
   c->counts[VGS_N_REATTACHED] = n_succ;
   c->counts[VGS_N_CLUSTERS] = n_roots;
-  c->counts[VGS_N_KEPT] = (int64_t)last_rank + last_flag;
+  c->counts[VGS_N_KEPT] = (int64_t)(unsigned int)hm[3];
   c->counts[VGS_N_ISOLATED] = n_cand;
   return VGS_OK;
 }

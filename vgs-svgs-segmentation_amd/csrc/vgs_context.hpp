@@ -125,6 +125,8 @@ struct vgs_ctx {
   DevBuf<int32_t> offsets;  // packed dx,dy,dz
   DevBuf<uint64_t> adj_masks;  // ball cells per (voxel position in its brick, brick offset): k_adjacency_masks
   int adj_mask_nb = 0;         // bricks per axis the ball can touch (0 = no mask table)
+  bool adj_tab_valid = false;  // offsets / masks / length tables are on the device for (adj_tab_graph, adj_tab_voxel)
+  float adj_tab_graph = 0.f, adj_tab_voxel = 0.f;
   // per adjacency row: start position of every group of equal integer offset length (crossValidation searches only
   // inside the group of the wanted distance); adj_nvals = the distinct lengths, adj_nrank[length] = its index
   DevBuf<uint16_t> adj_gtab;

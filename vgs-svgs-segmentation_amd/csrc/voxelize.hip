@@ -219,6 +219,7 @@ __global__ void k_count_valid(const uint64_t* __restrict__ code, int64_t n, unsi
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (code[mid] != 0) lo = mid + 1; else hi = mid; }
   *n_valid = (unsigned long long)lo;
 }
+__global__ void k_copy_last(const uint32_t* __restrict__ scan, int64_t n, unsigned long long* __restrict__ out) { *out = (unsigned long long)scan[n - 1]; }
 
 __global__ void k_voxel_table(const uint64_t* __restrict__ code, const uint32_t* __restrict__ head,
                               const uint32_t* __restrict__ scan, int64_t n, uint64_t mask, uint32_t* __restrict__ pt_vox,
@@ -343,11 +344,12 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, c->stream, c->code_b.p, N, d_cnt);
   uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
   VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
-  unsigned long long nf = 0;
-  uint32_t v_total = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&nf, d_cnt, sizeof(nf), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipMemcpyAsync(&v_total, scan + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
+  unsigned long long h2[2] = {0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(h2, d_cnt, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const unsigned long long nf = h2[0];
+  const uint32_t v_total = (uint32_t)h2[1];
   c->Nf = (int64_t)nf;
   c->V = (int64_t)v_total;
   VGS_HIP_TRY(c, c->vox_code.ensure(c->V + 1)); VGS_HIP_TRY(c, c->vox_start.ensure(c->V + 1));
