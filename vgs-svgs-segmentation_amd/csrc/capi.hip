@@ -131,7 +131,7 @@ void vgs_destroy(vgs_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->owned_xyz.release(); c->d_epochs.release(); c->grow_state.release();
+  c->owned_xyz.release(); c->grow_state.release();
   c->code_a.release(); c->code_b.release(); c->perm_a.release(); c->perm_b.release(); c->sort_tmp.release();
   c->head_flag.release(); c->pt_vox.release(); c->vox_code.release(); c->vox_start.release();
   c->xs.release(); c->ys.release(); c->zs.release();

@@ -69,13 +69,6 @@ struct Epoch {  // keys of points with index >= first use this box
 
 #define VGS_MAX_EPOCHS 96
 
-struct EpochTable {
-  int n;
-  int64_t first[VGS_MAX_EPOCHS];
-  double min[VGS_MAX_EPOCHS][3];
-  uint32_t dshift[VGS_MAX_EPOCHS][3];  // final shift - shift at insertion
-};
-
 enum Stage { ST_NONE = 0, ST_POINTS = 1, ST_VOXELS = 2, ST_FEATURES = 3, ST_ADJACENCY = 4, ST_SEGMENTED = 5 };
 
 struct vgs_ctx {
@@ -97,8 +90,7 @@ struct vgs_ctx {
   // octree
   OctreeBox box;
   bool grid_pinned = false;
-  std::vector<Epoch> epochs;
-  DevBuf<EpochTable> d_epochs;
+  int n_epochs = 0;   // growth epochs of the last voxelize (the epochs themselves stay in grow_state on the device)
 
   // voxelize
   DevBuf<uint64_t> code_a, code_b;

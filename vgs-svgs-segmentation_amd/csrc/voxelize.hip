@@ -5,6 +5,7 @@
 // HBM-bound integer work: one 12/16-byte read per point for the code, one stable LSD radix sort
 // of (code, index) pairs, one run-length pass, one gather of the points into leaf order (SoA) so that
 // the PCA stage reads each voxel's points as one contiguous, ascending-index run.
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
@@ -185,7 +186,8 @@ __global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* 
 }
 
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
-__global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const EpochTable* __restrict__ ep,
+// The epochs are read where the growth left them (GrowState on the device): no table goes through the host.
+__global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const GrowState* __restrict__ gs,
                              double res, int code_bits, uint64_t* __restrict__ code, uint32_t* __restrict__ perm) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -193,11 +195,13 @@ __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_
   float x = p[0], y = p[1], z = p[2];
   uint64_t c = 0;
   if (finite3(x, y, z)) {
-    int e = ep->n - 1;
-    while (e > 0 && i < ep->first[e]) --e;
-    uint32_t kx = vm_axis_key(x, ep->min[e][0], res) + ep->dshift[e][0];
-    uint32_t ky = vm_axis_key(y, ep->min[e][1], res) + ep->dshift[e][1];
-    uint32_t kz = vm_axis_key(z, ep->min[e][2], res) + ep->dshift[e][2];
+    int e = gs->n_epochs - 1;
+    while (e > 0 && i < gs->epochs[e].first) --e;   // epoch 0 also covers what lies in front of its first point (nothing finite)
+    const Epoch& ep = gs->epochs[e];
+    // keys are generated with the box of the insertion epoch and shifted by what the box has grown downwards since
+    uint32_t kx = vm_axis_key(x, ep.min[0], res) + (uint32_t)(gs->shift[0] - ep.shift[0]);
+    uint32_t ky = vm_axis_key(y, ep.min[1], res) + (uint32_t)(gs->shift[1] - ep.shift[1]);
+    uint32_t kz = vm_axis_key(z, ep.min[2], res) + (uint32_t)(gs->shift[2] - ep.shift[2]);
     c = (1ull << code_bits) | vm_morton(kx, ky, kz);
   }
   code[i] = c;
@@ -263,7 +267,7 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
     e.first = 0;
     for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
   }
-  VGS_HIP_TRY(c, hipMemcpyAsync(d_g, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(d_g, &h, offsetof(GrowState, epochs) + sizeof(Epoch), hipMemcpyHostToDevice, c->stream));   // header + the epoch a pinned grid starts with
   const int pinned = (c->grid_pinned && record_epochs) ? 1 : 0;
   // few enough threads that the scan moves through the cloud front to back (a growth step is found within the first
   // trip or two: the points come in random order), enough to keep the HBM pipes full on the one scan that reads everything
@@ -274,7 +278,7 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
       hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g);
       hipLaunchKernelGGL(k_adopt, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_g, pinned);
     }
-    VGS_HIP_TRY(c, hipMemcpyAsync(&h, d_g, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipMemcpyAsync(&h, d_g, offsetof(GrowState, epochs), hipMemcpyDeviceToHost, c->stream));   // the epochs stay on the device
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h.done) break;
   }
@@ -282,7 +286,7 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   if (h.overflow || !h.done) { c->err = "octree grew more than VGS_MAX_EPOCHS times"; return VGS_E_UNSUPPORTED; }
   for (int a = 0; a < 3; ++a) { box.min[a] = h.min[a]; box.max[a] = h.max[a]; box.shift[a] = h.shift[a]; }
   box.depth = h.depth; box.defined = h.defined != 0;
-  if (record_epochs) c->epochs.assign(h.epochs, h.epochs + h.n_epochs);
+  if (record_epochs) c->n_epochs = h.n_epochs;
   return VGS_OK;
 }
 
@@ -299,32 +303,19 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   c->V = 0; c->Nf = 0; c->U = 0;
   vgs_status st = grow_box(c);
   if (st != VGS_OK) return st;
-  if (c->epochs.empty()) {  // no finite point at all
+  if (c->n_epochs == 0) {  // no finite point at all
     c->counts[VGS_N_FINITE] = 0; c->counts[VGS_N_VOXELS] = 0; c->counts[VGS_N_DEPTH] = 0;
     return VGS_OK;
   }
   if (c->box.depth > 21) { c->err = "octree depth > 21 (64-bit voxel codes exhausted)"; return VGS_E_UNSUPPORTED; }
   c->code_bits = 3 * c->box.depth;
 
-  EpochTable T;
-  T.n = (int)c->epochs.size();
-  for (int e = 0; e < T.n; ++e) {
-    T.first[e] = c->epochs[e].first;
-    for (int a = 0; a < 3; ++a) {
-      T.min[e][a] = c->epochs[e].min[a];
-      T.dshift[e][a] = (uint32_t)(c->box.shift[a] - c->epochs[e].shift[a]);
-    }
-  }
-  T.first[0] = 0;
-  VGS_HIP_TRY(c, c->d_epochs.ensure(1));
-  VGS_HIP_TRY(c, hipMemcpyAsync(c->d_epochs.p, &T, sizeof(T), hipMemcpyHostToDevice, c->stream));
-
   VGS_HIP_TRY(c, c->code_a.ensure(N)); VGS_HIP_TRY(c, c->code_b.ensure(N));
   VGS_HIP_TRY(c, c->perm_a.ensure(N)); VGS_HIP_TRY(c, c->perm_b.ensure(N));
   VGS_HIP_TRY(c, c->head_flag.ensure(N)); VGS_HIP_TRY(c, c->pt_vox.ensure(N));
   const int TB = 256;
   const unsigned nb = (unsigned)((N + TB - 1) / TB);
-  hipLaunchKernelGGL(k_make_codes, dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, c->d_epochs.p, c->box.res,
+  hipLaunchKernelGGL(k_make_codes, dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, (const GrowState*)c->grow_state.p, c->box.res,
                      c->code_bits, c->code_a.p, c->perm_a.p);
 
   // stable LSD radix sort, descending code (= PCL LeafNodeIterator order: children visited 7 -> 0),
