@@ -445,8 +445,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
 #undef LAUNCH_ADJM
     unsigned int n_redo = 0;
-    VGS_HIP_TRY(c, hipMemcpyAsync(&n_redo, d_nredo, 4, hipMemcpyDeviceToHost, c->stream));
-    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VGS_READBACK(c, &n_redo, d_nredo, 4);
     if (n_redo > 0) LAUNCH_ADJ(1024, false, n_redo, c->work_ids.p, d_nredo, nullptr);
   } else if (c->n_off <= 1024) {
     if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);

@@ -121,6 +121,7 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
     delete c;
     return VGS_E_HIP;
   }
+  if (hipHostMalloc(&c->pin, 4096, hipHostMallocDefault) != hipSuccess) c->pin = nullptr;   // read-backs fall back to pageable copies
   for (int i = 0; i < 14; ++i)
     if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
   *out = c;
@@ -146,6 +147,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->owned.release(); c->straddle.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
+  if (c->pin) (void)hipHostFree(c->pin);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);

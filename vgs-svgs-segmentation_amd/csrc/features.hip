@@ -133,8 +133,7 @@ vgs_status vgs_stage_features(vgs_ctx* c) {
   unsigned long long* d_nu = (unsigned long long*)(c->counters.p + 36);
   hipLaunchKernelGGL(k_compact_used, dim3(nb), dim3(FEAT_TB), 0, c->stream, used_flag, excl, V, c->used_ids.p, c->used_rank.p, d_nu);
   unsigned long long nu = 0;
-  VGS_HIP_TRY(c, hipMemcpyAsync(&nu, d_nu, 8, hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_READBACK(c, &nu, d_nu, 8);
   VGS_HIP_TRY(c, hipGetLastError());
   c->U = (int64_t)nu;
   c->counts[VGS_N_USED] = c->U;

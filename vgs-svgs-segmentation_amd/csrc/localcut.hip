@@ -551,8 +551,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                      0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, a1_max, ids_a, ids_b, ids_c,
                      ids_d, ids_a1, d_nabc);
   unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(nabc, d_nabc, sizeof(nabc), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
 #ifdef VGS_PROF
   if (const char* oc = getenv("VGS_ONLY_CLASS")) {  // diagnostics: run a single class (results are incomplete)
     for (int k = 0; k < LC_NCLASS; ++k) if (k != atoi(oc)) nabc[k] = 0;
@@ -739,8 +738,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   // one read-back: the kernels' flags (words 0-7), the lengths of the hand-over lists (word 11), the rows put off (word 13)
   unsigned long long hc[14] = {0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_READBACK(c, hc, cnt, sizeof(hc));
   const unsigned long long* h = hc;
   const unsigned int nfg[2] = {(unsigned int)(hc[11] & 0xffffffffull), (unsigned int)(hc[11] >> 32)};
   const unsigned int nf = nfg[0] + nfg[1];

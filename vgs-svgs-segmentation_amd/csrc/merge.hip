@@ -430,8 +430,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     unsigned int* d_changed = (unsigned int*)(mcnt + 1);
     hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_mused.p,
                        c->csize.p, MP.adjacency_min, c->cc_flags.p, c->work_ids.p, d_ncand);
-    VGS_HIP_TRY(c, hipMemcpyAsync(&n_cand, d_ncand, 4, hipMemcpyDeviceToHost, c->stream));
-    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VGS_READBACK(c, &n_cand, d_ncand, 4);
     if (n_cand > 0) {
       // fixed point of "re-attachment succeeds": passes are queued four at a time, each with its own change counter, and
       // only the last counter is read back (a pass after the fixed point changes nothing and costs microseconds; a host
@@ -443,8 +442,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
           hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
                              c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_chg4 + q);
         unsigned int ch = 0;
-        VGS_HIP_TRY(c, hipMemcpyAsync(&ch, d_chg4 + 3, 4, hipMemcpyDeviceToHost, c->stream));
-        VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        VGS_READBACK(c, &ch, d_chg4 + 3, 4);
         if (!ch) break;
       }
       hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
@@ -481,8 +479,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipGetLastError());
   // one read-back: words 1-3 = re-attachments, roots, kept segments
   uint64_t hm[4] = {0, 0, 0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(hm, mcnt, sizeof(hm), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_READBACK(c, hm, mcnt, sizeof(hm));
   const unsigned int n_roots = (unsigned int)hm[2];
   if (U > 0 && n_cand > 0) n_succ = (unsigned int)hm[1];
   c->counts[VGS_N_REATTACHED] = n_succ;

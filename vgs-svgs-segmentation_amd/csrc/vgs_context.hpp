@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -80,6 +81,7 @@ struct vgs_ctx {
   hipStream_t stream4 = nullptr;
   std::string err;
   int stage = ST_NONE;
+  void* pin = nullptr;   // 4 KB of pinned host memory: small read-backs land here (a pageable destination makes the copy blocking and slower)
 
   // input
   const float* xyz = nullptr;  // device pointer (owned_xyz or caller's)
@@ -200,6 +202,20 @@ struct vgs_ctx {
       return VGS_E_HIP;                                                                              \
     }                                                                                                \
   } while (0)
+
+// small device -> host read-back through the context's pinned scratch, followed by a wait for the stream
+static inline vgs_status vgs_readback(vgs_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+  if (bytes > 4096 || !c->pin) {
+    VGS_HIP_TRY(c, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VGS_OK;
+  }
+  VGS_HIP_TRY(c, hipMemcpyAsync(c->pin, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  memcpy(dst, c->pin, bytes);
+  return VGS_OK;
+}
+#define VGS_READBACK(ctx, dst, src, bytes) do { vgs_status _s = vgs_readback((ctx), (dst), (src), (bytes)); if (_s != VGS_OK) return _s; } while (0)
 
 // stage implementations (one .hip file each)
 vgs_status vgs_stage_voxelize(vgs_ctx* c);

@@ -278,8 +278,7 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
       hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g);
       hipLaunchKernelGGL(k_adopt, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_g, pinned);
     }
-    VGS_HIP_TRY(c, hipMemcpyAsync(&h, d_g, offsetof(GrowState, epochs), hipMemcpyDeviceToHost, c->stream));   // the epochs stay on the device
-    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    VGS_READBACK(c, &h, d_g, offsetof(GrowState, epochs));   // the epochs stay on the device
     if (h.done) break;
   }
   if (h.done == 2) { c->err = "a point lies outside the pinned grid"; return VGS_E_ARG; }
@@ -337,8 +336,7 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
   hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
   unsigned long long h2[2] = {0, 0};
-  VGS_HIP_TRY(c, hipMemcpyAsync(h2, d_cnt, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
-  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  VGS_READBACK(c, h2, d_cnt, sizeof(h2));
   const unsigned long long nf = h2[0];
   const uint32_t v_total = (uint32_t)h2[1];
   c->Nf = (int64_t)nf;
