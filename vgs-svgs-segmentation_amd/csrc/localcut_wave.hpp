@@ -696,6 +696,9 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       if (merges >= m - 1) break;
       if (final_round || !(level > thr0)) { phase_a_complete = true; break; }
       if (rounds == 1 && ssz[seg[0]] == 1 && never_merges()) break;  // the voxel stays alone: its connect list is itself
+      // only the segment of vertex 0 (the voxel itself) is reported: once it is frozen its membership is final -- the usual
+      // end on a surface, so it is tested before the bookkeeping of the next shell, not after
+      if (!(thr[seg[0]] < level)) break;
       // ---- 5. freeze (fact F) and carry ----
       int n_new = 0;
       for (int base = 0; base < n_act; base += 64) {
@@ -737,8 +740,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         active_segs += __popcll(__ballot((c < m) && (ssz[c] != 0) && (thr[c] < level)));
       }
       if (active_segs < 2) break;  // nothing can merge at any weight <= level
-      // only the segment of vertex 0 (the voxel itself) is reported: once it is frozen its membership is final
-      if (!(thr[seg[0]] < level)) break;
       int kept = 0;
       for (int base = pos; base < n_list; base += 64) {
         const int e = base + lane;
