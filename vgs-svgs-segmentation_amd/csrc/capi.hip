@@ -131,7 +131,11 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
 void vgs_destroy(vgs_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // the side streams may still carry hand-over kernels if a stage sequence was cut short
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+  if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   c->owned_xyz.release(); c->grow_state.release();
   c->code_a.release(); c->code_b.release(); c->perm_a.release(); c->perm_b.release(); c->sort_tmp.release();
   c->head_flag.release(); c->pt_vox.release(); c->vox_code.release(); c->vox_start.release();

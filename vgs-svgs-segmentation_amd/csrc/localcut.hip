@@ -507,6 +507,12 @@ static DevBuf<uint32_t> s_dbg;   // per-voxel cycle / round counters of the diag
 vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const int64_t U = c->U;
   c->counts[VGS_N_PAIRS] = 0;
+  if (c->lc_tail.open) {
+    // a previous run of this stage was never completed by the merge stage (an error in between): its hand-over kernels may
+    // still be running on the side streams, and they use the counters and lists this run is about to reset
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream2)); VGS_HIP_TRY(c, hipStreamSynchronize(c->stream3)); VGS_HIP_TRY(c, hipStreamSynchronize(c->stream4));
+    c->lc_tail.open = false;
+  }
   if (U == 0) return VGS_OK;
   LcParams LP;
   LP.W = make_weight_params(c->P);
