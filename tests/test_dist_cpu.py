@@ -53,7 +53,12 @@ def _worker(rank, world, path, port, out_path):
     is_b = np.isin(roots[0], broot)
     local_kept = (~is_b) & (roots[1] > vmin)
     payload = np.concatenate([[ucode.size, int(local_kept.sum())], ucode.view(np.int64), broot.astype(np.int64), bcnt]).astype(np.int64)
-    gathered = all_gather_varlen(dist, payload)
+    from vgs_svgs_segmentation_amd.dist import all_gather_records
+    gathered = all_gather_records(dist, payload)   # what TiledSegmenter.run uses: one fixed-size collective when everything fits
+    assert all(np.array_equal(a, b) for a, b in zip(gathered, all_gather_varlen(dist, payload)))
+    # ... and the two-step fallback when some rank's payload does not fit the fixed size
+    small = all_gather_records(dist, payload, cap=2 + 3 * 4 + rank)
+    assert all(np.array_equal(a, b) for a, b in zip(gathered, small))
     records, kept_local = [], []
     for g in gathered:
         m = int(g[0]); kept_local.append(int(g[1]))

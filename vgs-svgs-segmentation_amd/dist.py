@@ -165,6 +165,26 @@ def all_gather_varlen(dist, arr, device=None):
     return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
 
 
+def all_gather_records(dist, payload, device=None, cap=3 * 8192 + 2):
+    """all_gather of the per-rank record payloads (payload[0] = number of records, 3 int64 words each).  One collective
+    of a fixed size when every rank's payload fits `cap` words (the usual case: a few thousand boundary voxels); if some
+    rank's does not, all ranks see that in the gathered headers and fall back to the two-step variable-length gather."""
+    import torch
+    world = dist.get_world_size()
+    buf = np.zeros(cap, dtype=np.int64)
+    n = min(payload.size, cap)
+    buf[:n] = payload[:n]
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    outs = [o.cpu().numpy() for o in outs]
+    if all(2 + 3 * int(o[0]) <= cap for o in outs):
+        return [o[:2 + 3 * int(o[0])] for o in outs]
+    return all_gather_varlen(dist, payload, device)
+
+
 class TiledSegmenter:
     """Drives one Engine per rank over one tile of a tiles[0] x tiles[1] layout."""
 
@@ -223,22 +243,43 @@ class TiledSegmenter:
         """The shared grid: what inserting the ranks' clouds one after the other does to the octree box.
         One all-gather of the clouds' bounding boxes lets every rank replay the growth on the host wherever the box alone
         decides it (vgs_grid_advance_bbox: the usual case for tiles that lie beside the box); only a rank whose cloud leaves
-        the step open -- the first one always: its box starts at its first point -- scans its points on the GPU
-        (vgs_grid_advance) and broadcasts the state.  All ranks run the same replay on the same gathered numbers."""
+        the step open scans its points on the GPU (vgs_grid_advance) and broadcasts the state -- except rank 0, whose box
+        starts at its first point: it always scans, before the all-gather, and its state travels with its bounding box.
+        All ranks run the same replay on the same gathered numbers."""
         import torch
         L, eng = self.engine._L, self.engine
         bb = np.zeros(6, dtype=np.float32)
         nf = C.c_int64(0)
         eng._ck(L.vgs_points_bbox(eng._h, _ptr(bb), C.byref(nf)))
-        mine = torch.tensor([float(v) for v in bb] + [float(nf.value)], dtype=torch.float64, device=self.coll_device)
+
+        def pack(gs):
+            return [gs.min[0], gs.min[1], gs.min[2], float(gs.shift[0]), float(gs.shift[1]), float(gs.shift[2]), float(gs.depth), float(gs.defined)]
+
+        def unpack(gs, v):
+            for a in range(3):
+                gs.min[a] = float(v[a])
+                gs.shift[a] = int(v[3 + a])
+            gs.depth, gs.defined = int(v[6]), int(v[7])
+
+        # rank 0 starts the chain from nothing, so it needs no one else's numbers for its own growth: it scans its points
+        # first and sends the state it reaches along with its bounding box (no broadcast of its own)
+        g0 = VgsGridState()
+        L.vgs_grid_state_init(C.byref(g0))
+        self.chain_scans = 0
+        if self.rank == 0 and nf.value > 0:
+            eng._ck(L.vgs_grid_advance(eng._h, C.byref(g0)))
+        mine = torch.tensor([float(v) for v in bb] + [float(nf.value)] + pack(g0), dtype=torch.float64, device=self.coll_device)
         allbb = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(allbb, mine)
         allbb = [t.cpu().numpy() for t in allbb]
         g = VgsGridState()
         L.vgs_grid_state_init(C.byref(g))
-        self.chain_scans = 0
         for r in range(self.world):
             if allbb[r][6] == 0:      # no finite point: the cloud changes nothing
+                continue
+            if r == 0:
+                unpack(g, allbb[0][7:15])
+                self.chain_scans += 1
                 continue
             need = C.c_int32(0)
             box = np.ascontiguousarray(allbb[r][:6], dtype=np.float32)   # float values, exactly as gathered
@@ -251,14 +292,9 @@ class TiledSegmenter:
             buf = torch.zeros(8, dtype=torch.float64, device=self.coll_device)
             if self.rank == r:
                 eng._ck(L.vgs_grid_advance(eng._h, C.byref(g)))
-                vals = [g.min[0], g.min[1], g.min[2], float(g.shift[0]), float(g.shift[1]), float(g.shift[2]), float(g.depth), float(g.defined)]
-                buf = torch.tensor(vals, dtype=torch.float64, device=self.coll_device)
+                buf = torch.tensor(pack(g), dtype=torch.float64, device=self.coll_device)
             self.dist.broadcast(buf, src=r)
-            v = buf.cpu().numpy()
-            for a in range(3):
-                g.min[a] = float(v[a])
-                g.shift[a] = int(v[3 + a])
-            g.depth, g.defined = int(v[6]), int(v[7])
+            unpack(g, buf.cpu().numpy())
         eng._ck(L.vgs_set_grid(eng._h, C.byref(g)))
 
     def run(self):
@@ -288,7 +324,7 @@ class TiledSegmenter:
         mark(f"boundary download ({n.value} boundary voxels, {nkl.value} local segments)")
         # the one data-path exchange: a fixed-size header (record count, local segment count) and the records
         payload = np.concatenate([[n.value, nkl.value], rec[:, :n.value].reshape(-1)]).astype(np.int64)
-        gathered = all_gather_varlen(self.dist, payload, self.coll_device)
+        gathered = all_gather_records(self.dist, payload, self.coll_device)
         mark("all-gather")
         records, kept_local = [], []
         for g in gathered:
