@@ -57,7 +57,7 @@ def _worker(rank, world, path, port, out_path):
     gathered = all_gather_records(dist, payload)   # what TiledSegmenter.run uses: one fixed-size collective when everything fits
     assert all(np.array_equal(a, b) for a, b in zip(gathered, all_gather_varlen(dist, payload)))
     # ... and the two-step fallback when some rank's payload does not fit the fixed size
-    small = all_gather_records(dist, payload, cap=2 + 3 * 4 + rank)
+    small = all_gather_records(dist, payload, cap=2 + 3 * 4)
     assert all(np.array_equal(a, b) for a, b in zip(gathered, small))
     records, kept_local = [], []
     for g in gathered:
