@@ -118,3 +118,27 @@ def test_labels_stable_across_fresh_engines(gpu):
                 want.append(lab)
             else:
                 np.testing.assert_array_equal(lab, want[k])
+
+
+def test_one_context_many_parameter_sets(gpu):
+    """A context keeps parameter-only tables (lattice offsets, ball masks, length groups) and per-run state across runs:
+    walking one context through parameter changes -- graph size (new tables), voxel size (new lattice), cut and sigmas (new
+    near-pair lists), back to the start -- must give what a fresh context gives for every set."""
+    xyz = gpu.scenes.urban_scene(80_000)
+    sets = [dict(voxel_size=0.1), dict(voxel_size=0.1, graph_size=0.35), dict(voxel_size=0.1, graph_size=0.65), dict(voxel_size=0.12),
+            dict(voxel_size=0.1, cut_thred=0.5, sig_n=0.3), dict(voxel_size=0.1, points_min=5), dict(voxel_size=0.1)]
+    eng = gpu.Engine(gpu.default_params(2, **sets[0]))
+    eng.set_points(xyz)
+    for kw in sets:
+        p = gpu.default_params(2, **kw)
+        eng.set_params(p)
+        eng.run()
+        fresh = gpu.Engine(p)
+        fresh.set_points(xyz)
+        fresh.run()
+        np.testing.assert_array_equal(eng.point_labels(), fresh.point_labels())
+        for which in ("adjacency", "connect_final"):
+            a, b = eng.lists(which), fresh.lists(which)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+        assert eng.counts()["kept"] == fresh.counts()["kept"]
