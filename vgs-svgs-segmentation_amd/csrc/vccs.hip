@@ -128,50 +128,82 @@ __global__ void k_vccs_plant(const unsigned long long* __restrict__ seed_key, in
   count[k] = 1;
 }
 
-// one synchronous round: every voxel looks at the labels its 26 neighbours (and itself) had at the start of the round
-__global__ void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, const float* __restrict__ nrm,
-                              const int32_t* __restrict__ label_in, const float* __restrict__ dist_in, const VccsState* __restrict__ st,
-                              float w_s_over_seed, float w_n, int32_t* __restrict__ label_out, float* __restrict__ dist_out,
-                              long long* __restrict__ sums, unsigned int* __restrict__ count) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  int best_l = label_in[v];
-  float best_d = dist_in[v];
-  const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
-  const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
-  const int own = best_l;
-  // all 26 neighbour ids, then all 26 labels: independent loads in flight together (the serial walk was latency bound)
-  int nl[26];
-#pragma unroll
-  for (int o = 0; o < 26; ++o) nl[o] = nbr[(int64_t)o * V + v];
-#pragma unroll
-  for (int o = 0; o < 26; ++o) nl[o] = nl[o] >= 0 ? label_in[nl[o]] : -1;
-  int last = own;
-#pragma unroll
-  for (int o = 0; o < 26; ++o) {
-    const int l = nl[o];
-    if (l < 0 || l == own || l == last) continue;  // the label just tried gives the same distance again
-    last = l;
-    const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
-    if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
+// one synchronous round: every voxel looks at the labels its 26 neighbours (and itself) had at the start of the round.
+// The per-supervoxel sums move with the voxels that change owner.  A workgroup's 256 voxels are neighbours in space (Morton
+// order) and belong to a handful of supervoxels, so their contributions are first added up in a small LDS table keyed by
+// label and only the table goes to memory: one global atomic per (workgroup, supervoxel, component) instead of fourteen
+// per voxel that changes -- the contended 64-bit atomics were half of the stage's time.  Integer sums: any order, same result.
+#define VX_SLOTS 128
+__global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen,
+                              const float* __restrict__ nrm, const int32_t* __restrict__ label_in, const float* __restrict__ dist_in,
+                              const VccsState* __restrict__ st, float w_s_over_seed, float w_n, int32_t* __restrict__ label_out,
+                              float* __restrict__ dist_out, long long* __restrict__ sums, unsigned int* __restrict__ count) {
+  __shared__ int s_key[VX_SLOTS];
+  __shared__ unsigned long long s_sum[VX_SLOTS][6];
+  __shared__ int s_cnt[VX_SLOTS];
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x) {
+    s_key[k] = -1; s_cnt[k] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[k][a] = 0ull;
   }
-  label_out[v] = best_l;
-  dist_out[v] = best_d;
-  // the per-supervoxel sums are integers: moving this voxel's contribution from its old owner to the new one gives
-  // exactly the sums a full re-accumulation would (and after the first rounds only the frontier moves)
-  const int old_l = own;
-  if (best_l != old_l) {
-    for (int a = 0; a < 3; ++a) {
-      const long long fp = vccs_fix_pos(c[a]), fn = vccs_fix_nrm(n[a]);
-      if (old_l >= 0) {
-        atomicAdd((unsigned long long*)&sums[6 * old_l + a], (unsigned long long)(-fp));
-        atomicAdd((unsigned long long*)&sums[6 * old_l + 3 + a], (unsigned long long)(-fn));
-      }
-      atomicAdd((unsigned long long*)&sums[6 * best_l + a], (unsigned long long)fp);
-      atomicAdd((unsigned long long*)&sums[6 * best_l + 3 + a], (unsigned long long)fn);
+  __syncthreads();
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) {
+    int best_l = label_in[v];
+    float best_d = dist_in[v];
+    const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
+    const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
+    const int own = best_l;
+    // all 26 neighbour ids, then all 26 labels: independent loads in flight together (the serial walk was latency bound)
+    int nl[26];
+#pragma unroll
+    for (int o = 0; o < 26; ++o) nl[o] = nbr[(int64_t)o * V + v];
+#pragma unroll
+    for (int o = 0; o < 26; ++o) nl[o] = nl[o] >= 0 ? label_in[nl[o]] : -1;
+    int last = own;
+#pragma unroll
+    for (int o = 0; o < 26; ++o) {
+      const int l = nl[o];
+      if (l < 0 || l == own || l == last) continue;  // the label just tried gives the same distance again
+      last = l;
+      const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
+      if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
     }
-    if (old_l >= 0) atomicSub(&count[old_l], 1u);
-    atomicAdd(&count[best_l], 1u);
+    label_out[v] = best_l;
+    dist_out[v] = best_d;
+    // moving this voxel's contribution from its old owner to the new one gives exactly the sums a full re-accumulation
+    // would (and after the first rounds only the frontier moves)
+    if (best_l != own) {
+      long long f[6];
+      for (int a = 0; a < 3; ++a) { f[a] = vccs_fix_pos(c[a]); f[3 + a] = vccs_fix_nrm(n[a]); }
+      for (int side = 0; side < 2; ++side) {
+        const int l = side ? best_l : own;
+        if (l < 0) continue;
+        const long long sgn = side ? 1 : -1;
+        // slot of label l in the workgroup's table (open addressing); a full table sends the contribution straight to memory
+        int slot = -1;
+        unsigned int h = ((unsigned int)l * 2654435761u) >> 25;   // 7 bits
+        for (int probe = 0; probe < VX_SLOTS; ++probe) {
+          const int prev = atomicCAS(&s_key[h], -1, l);
+          if (prev == -1 || prev == l) { slot = (int)h; break; }
+          h = (h + 1) & (VX_SLOTS - 1);
+        }
+        if (slot >= 0) {
+          for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], (unsigned long long)(sgn * f[a]));
+          atomicAdd(&s_cnt[slot], (int)sgn);
+        } else {
+          for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)(sgn * f[a]));
+          if (side) atomicAdd(&count[l], 1u); else atomicSub(&count[l], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x) {
+    const int l = s_key[k];
+    if (l < 0) continue;
+    for (int a = 0; a < 6; ++a) { const unsigned long long x = s_sum[k][a]; if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], x); }
+    const int dc = s_cnt[k];
+    if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
   }
 }
 
@@ -195,16 +227,35 @@ __global__ void k_vccs_update(int K, const long long* __restrict__ sums, const u
   vccs_state_from_sums(&sums[6 * k], count[k], st[k].c, st[k].n);
 }
 
-// refinement: new seed = member voxel closest to the supervoxel centroid
-__global__ void k_vccs_reseed(int64_t V, const int32_t* __restrict__ label, const float* __restrict__ cen, const VccsState* __restrict__ st,
-                              unsigned long long* __restrict__ seed_key) {
+// refinement: new seed = member voxel closest to the supervoxel centroid (smallest (distance^2, voxel id) key).  The minimum
+// is first taken per workgroup in an LDS table keyed by label (see k_vccs_expand), then once per table entry in memory.
+__global__ __launch_bounds__(256) void k_vccs_reseed(int64_t V, const int32_t* __restrict__ label, const float* __restrict__ cen,
+                                                     const VccsState* __restrict__ st, unsigned long long* __restrict__ seed_key) {
+  __shared__ int s_key[VX_SLOTS];
+  __shared__ unsigned long long s_min[VX_SLOTS];
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x) { s_key[k] = -1; s_min[k] = ~0ull; }
+  __syncthreads();
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  const int l = label[v];
-  if (l < 0) return;
-  const float dx = cen[3 * v] - st[l].c[0], dy = cen[3 * v + 1] - st[l].c[1], dz = cen[3 * v + 2] - st[l].c[2];
-  const float d2 = (dx * dx + dy * dy) + dz * dz;
-  atomicMin(&seed_key[l], ((unsigned long long)vm_bits(d2) << 32) | (unsigned long long)v);
+  if (v < V) {
+    const int l = label[v];
+    if (l >= 0) {
+      const float dx = cen[3 * v] - st[l].c[0], dy = cen[3 * v + 1] - st[l].c[1], dz = cen[3 * v + 2] - st[l].c[2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const unsigned long long key = ((unsigned long long)vm_bits(d2) << 32) | (unsigned long long)v;
+      int slot = -1;
+      unsigned int h = ((unsigned int)l * 2654435761u) >> 25;
+      for (int probe = 0; probe < VX_SLOTS; ++probe) {
+        const int prev = atomicCAS(&s_key[h], -1, l);
+        if (prev == -1 || prev == l) { slot = (int)h; break; }
+        h = (h + 1) & (VX_SLOTS - 1);
+      }
+      if (slot >= 0) atomicMin(&s_min[slot], key);
+      else atomicMin(&seed_key[l], key);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x)
+    if (s_key[k] >= 0 && s_min[k] != ~0ull) atomicMin(&seed_key[s_key[k]], s_min[k]);
 }
 
 __global__ void k_vccs_point_labels(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, const int32_t* __restrict__ label,
