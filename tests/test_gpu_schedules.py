@@ -34,6 +34,10 @@ CASES = [
     ("urban_r6", "urban", 90_000, dict(voxel_size=0.08)),                               # ball of 6.25 voxels: beyond the offset map, lists off
     ("slab_overflow", "slab", 70_000, dict(voxel_size=0.1, cut_thred=0.9)),             # thr0 = 0.1: > 32 heavy near pairs -> no list
     ("slab_default", "slab", 70_000, dict(voxel_size=0.1)),
+    # coordinates whose float spacing (1.2e-4 m, 2e-3 m) puts centroids visibly outside their voxel's cube: the lists' reach
+    # argument needs every listed voxel's centroid inside its cube, so such voxels must end up without a list
+    ("urban_2km_away", "urban", 90_000, dict(voxel_size=0.1, shift=(2000.0, -1500.0, 30.0))),
+    ("urban_20km_away", "urban", 90_000, dict(voxel_size=0.1, shift=(20000.0, 100.0, 5.0))),
 ]
 
 
@@ -46,7 +50,11 @@ def _scene(gpu, kind, n):
 @pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
 def case(request, gpu, oracle):
     name, kind, n, kw = request.param
+    kw = dict(kw)
+    shift = kw.pop("shift", None)
     xyz = _scene(gpu, kind, n)
+    if shift is not None:
+        xyz = (xyz + np.array(shift, np.float32)).astype(np.float32)
     p = gpu.default_params(2, **kw)
     eng = gpu.Engine(p)
     eng.set_points(xyz)

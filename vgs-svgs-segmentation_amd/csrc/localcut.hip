@@ -587,7 +587,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // rounding puts a hair outside their voxel's cube.
     const float reach = (float)NL_REACH * c->P.voxel_size;
     WP.near.cnt = c->nl_cnt.p; WP.near.slot = c->nl_slot.p; WP.near.dw = c->nl_dw.p;
-    WP.near.d2max = reach * reach * 0.999f;
+    WP.near.d2max = reach * reach * NL_D2_SLACK;
     WP.near.enabled = c->nl_enabled ? 1 : 0;
   }
   // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the

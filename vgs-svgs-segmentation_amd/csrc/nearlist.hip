@@ -14,7 +14,8 @@
 __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                    const uint32_t* __restrict__ adj_cnt, int adj_stride, const NodeRec* __restrict__ node,
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
-                                                   float lat_d2_lim, float d2max,
+                                                   float lat_d2_lim, float d2max, const uint64_t* __restrict__ vox_code,
+                                                   float res_f, float min_x, float min_y, float min_z, float cube_tol,
                                                    uint8_t* __restrict__ out_cnt, uint16_t* __restrict__ out_slot, float2* __restrict__ out_dw) {
   __shared__ uint32_t q_t[NLB_QCAP];      // partner voxel id
   __shared__ float q_d2[NLB_QCAP], q_w[NLB_QCAP];   // centroid distance^2; weight, NaN = not kept
@@ -43,10 +44,22 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
       // a row whose centre distances are not within half a lattice step^2 of their offsets' integer lengths (coordinates so
       // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
       if (gtab[u * gstride] == 0xffffu) { if (lane == 0) s_kept[g] = -1; continue; }
+      const NodeRec& me = node[i];
+      {
+        // the reach argument (nearlist.hpp) wants the centroid inside the voxel's cube; float sums of large coordinates
+        // can leave it outside by more than the slack built into d2max: such a voxel gets no list
+        const uint64_t code = vox_code[i];
+        const float fx = vm_voxel_center(vm_compact21(code >> 2), res_f, min_x), fy = vm_voxel_center(vm_compact21(code >> 1), res_f, min_y),
+                    fz = vm_voxel_center(vm_compact21(code), res_f, min_z);
+        const float lim = 0.5f * res_f + cube_tol;
+        const float ulp = 1.2e-7f;   // the float centre itself is off by up to half a spacing of its magnitude
+        const bool inside = fabsf(me.c[0] - fx) + fabsf(fx) * ulp <= lim && fabsf(me.c[1] - fy) + fabsf(fy) * ulp <= lim &&
+                            fabsf(me.c[2] - fz) + fabsf(fz) * ulp <= lim;
+        if ((me.flags & VGS_F_POS) && !inside) { if (lane == 0) s_kept[g] = -1; continue; }
+      }
       if (lane == 0) s_kept[g] = 0;
       const int n = (int)adj_cnt[u];
       const uint64_t* row = adj_key + u * adj_stride;
-      const NodeRec& me = node[i];
       const uint32_t mpad = me.pad;
       const float ax = (me.flags & VGS_F_POS) ? me.c[0] : vm_nan();   // as the cut stages centroids: an unusable position is a NaN x
       const float ay = me.c[1], az = me.c[2];
@@ -146,7 +159,8 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   // a pair inside the reach has a lattice offset of at most 3 * NL_REACH^2 squared steps; half a step^2 of slack for the float centres
   const float lat_lim = ((float)(3 * NL_REACH * NL_REACH) + 0.5f) * res * res;
   hipLaunchKernelGGL(k_near_lists, dim3(vgs_xcd_grid((U + NLB_G - 1) / NLB_G)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                     c->node.p, c->adj_gtab.p, c->adj_gstride, W, thr0, lat_lim, reach * reach, c->nl_cnt.p, c->nl_slot.p, c->nl_dw.p);
+                     c->node.p, c->adj_gtab.p, c->adj_gstride, W, thr0, lat_lim, reach * reach, c->vox_code.p, res, (float)c->box.min[0],
+                     (float)c->box.min[1], (float)c->box.min[2], NL_CUBE_TOL * res, c->nl_cnt.p, c->nl_slot.p, c->nl_dw.p);
   VGS_HIP_TRY(c, hipGetLastError());
   c->nl_enabled = true;
   return VGS_OK;

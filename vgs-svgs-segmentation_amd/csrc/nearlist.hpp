@@ -9,9 +9,11 @@
 // weight is symmetric only up to an ulp; the cut needs w(first, second) in the order of i's adjacency row, so both
 // orientations exist, one in each voxel's list).  The cut then walks the lists of its vertices instead of testing all
 // n^2/2 pairs, and takes the stored weight instead of evaluating it.
-// Exactness: centroids lie inside their voxel's cube, so a pair more than NL_REACH lattice steps apart on some axis is
-// farther apart than NL_REACH voxel sizes: every pair with d2 < near_d2max is in the lists.  Pairs at or below the
-// singleton threshold 1 - cut are never stored by phase A of the cut either (fact S).
+// Exactness: a listed voxel's centroid lies inside its voxel's cube widened by NL_CUBE_TOL voxel sizes (the builder checks
+// it, counting the rounding of the float cube centre as well; a voxel that fails -- float sums of coordinates kilometres from
+// the origin -- gets NL_NONE), so two listed voxels more than NL_REACH lattice steps apart on some axis are farther apart
+// than (NL_REACH - 2 * NL_CUBE_TOL) voxel sizes: every pair with d2 < d2max = (NL_REACH * voxel_size)^2 * NL_D2_SLACK is in
+// the lists.  Pairs at or below the singleton threshold 1 - cut are never stored by phase A of the cut either (fact S).
 #ifndef NEARLIST_HPP_
 #define NEARLIST_HPP_
 
@@ -20,6 +22,8 @@
 #define NL_S 32       // entries per voxel; a voxel with more heavy near pairs is marked NL_NONE and its neighbourhoods take the general path
 #define NL_REACH 2    // Chebyshev reach of the lists in lattice steps
 #define NL_NONE 0xffu
+#define NL_CUBE_TOL 0.9e-3f   // centroid may sit this many voxel sizes outside its cube (per axis) and still be listed
+#define NL_D2_SLACK 0.998f    // (1 - 2 * 1e-3 / NL_REACH)^2 rounded down: what the tolerance above costs in reach
 #define NL_BALL 5     // largest lattice offset of a neighbour the consumer's offset map can hold ((2*5+1)^3 bytes of LDS)
 
 struct NearLists {
