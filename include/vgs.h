@@ -116,6 +116,13 @@ vgs_status svgs_get_supervoxel_labels(vgs_ctx* ctx, int32_t* labels, int32_t* ma
 /* ---- results ---------------------------------------------------------------------------- */
 vgs_status vgs_get_counts(vgs_ctx* ctx, int64_t* counts /* VGS_N_COUNTS */);
 vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
+/* Schedule diagnostics of the last local cut (no reference counterpart; tests use them to see that an input reached the
+ * path it was built for).  out[0..7]: 0 rounds the lazy schedule gave up in, 1 voxels it handed over because a shell or
+ * phase B overflowed its list, 2 handed over to the dense kernel (all causes), 3 sent on by the dense kernel to the
+ * general kernel (a list of 2048 edges overflowed), 4 handed over by the classes above 128 neighbours, 5 voxels
+ * outside every kernel's limits (result incomplete: vgs_segment reports it), 6 rows crossValidation put off, 7 voxels whose phase B the dense
+ * kernel took in bands of descending weight */
+vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
 vgs_status vgs_get_bbox(vgs_ctx* ctx, double* min3_max3);                 /* getBoundingBox (T:56) */
 /* voxel table in leaf order: key 3*V, start V+1 (offsets into point_idx), point_idx N' ; any may be NULL */
 vgs_status vgs_get_voxel_table(vgs_ctx* ctx, uint32_t* key, int32_t* start, int32_t* point_idx);

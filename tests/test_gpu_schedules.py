@@ -2,7 +2,10 @@
 (nearlist.hip: shells inside two lattice steps read stored weights), the split of the bulk class, and the brick-mask
 candidate search (k_adjacency_masks) are compared with the oracle (DevMath, lean: bit-exact bar) on inputs chosen to reach
 their corners -- lists that overflow (NL_NONE), balls wider than the lists' offset map, list ends behind entry 16,
-rows handed to the general adjacency kernel -- and against the same engine with each schedule switched off."""
+rows handed to the general adjacency kernel -- and against the same engine with each schedule switched off.  The dense
+hand-over kernel (localcut_dense.hpp) gets the scenes it exists for: fuzzy surfaces where the lazy schedule gives up on nine
+voxels out of ten, neighbourhoods whose heavy edges overflow its list (sent on to the general kernel), and a million-point
+urban scene that holds the few dozen voxels whose phase B runs in bands."""
 import os
 
 import numpy as np
@@ -25,6 +28,15 @@ def _slab_scene(n, seed, thickness=0.35):
     return np.stack([x, y, z], axis=1).astype(np.float32)
 
 
+def _fuzzy_scene(n, seed, sigma):
+    """An undulating surface under range noise as thick as the voxels: normals scatter, no segment freezes early."""
+    rng = np.random.default_rng(seed)
+    side = np.sqrt(n / 6000.0)
+    x, y = rng.random(n) * side, rng.random(n) * side
+    z = 0.3 * np.sin(2.0 * x) * np.cos(1.5 * y) + rng.normal(0, sigma, n) + 2.0
+    return np.stack([x + 0.011, y + 0.017, z], axis=1).astype(np.float32)
+
+
 CASES = [
     # name, scene, n, params
     ("urban_loose_cut", "urban", 90_000, dict(voxel_size=0.1, cut_thred=0.6)),          # thr0 = 0.4: long lists, entries behind 16
@@ -38,12 +50,20 @@ CASES = [
     # argument needs every listed voxel's centroid inside its cube, so such voxels must end up without a list
     ("urban_2km_away", "urban", 90_000, dict(voxel_size=0.1, shift=(2000.0, -1500.0, 30.0))),
     ("urban_20km_away", "urban", 90_000, dict(voxel_size=0.1, shift=(20000.0, 100.0, 5.0))),
+    # the dense hand-over kernel's workloads (schedule_counters says which path a case must reach, REACHES below)
+    ("fuzzy_dense", "fuzzy", 120_000, dict(voxel_size=0.1, graph_size=0.4)),
+    ("fuzzy_sent_on", "fuzzy", 120_000, dict(voxel_size=0.1, graph_size=0.45, cut_thred=0.4)),
+    ("urban_1M_bands", "urban", 1_000_000, dict(voxel_size=0.1)),
 ]
+REACHES = {"fuzzy_dense": ("handed_over",), "fuzzy_sent_on": ("handed_over", "dense_sent_on"), "slab_overflow": ("dense_sent_on", "handed_over_large"),
+           "urban_1M_bands": ("handed_over", "banded_phase_b", "handed_over_large", "cross_put_off"), "urban_loose_cut": ("handed_over",)}
 
 
 def _scene(gpu, kind, n):
     if kind == "slab":
         return _slab_scene(n, 5)
+    if kind == "fuzzy":
+        return _fuzzy_scene(n, 1, 0.03)
     return {"urban": gpu.scenes.urban_scene, "town": gpu.scenes.town_scene}[kind](n)
 
 
@@ -61,6 +81,13 @@ def case(request, gpu, oracle):
     eng.run()
     ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
     return dict(name=name, xyz=xyz, p=p, eng=eng, ref=ref)
+
+
+def test_case_reaches_its_path(case):
+    sc = case["eng"].schedule_counters()
+    assert sc["outside_limits"] == 0
+    for key in REACHES.get(case["name"], ()):
+        assert sc[key] > 0, f"{case['name']} was built to reach {key}: {sc}"
 
 
 def test_adjacency_exact_order(case):
@@ -86,7 +113,7 @@ def test_labels_identical(case):
     np.testing.assert_array_equal(eng.point_labels(), pl_ref)
 
 
-@pytest.mark.parametrize("knob", ["VGS_NO_NEAR", "VGS_NO_ADJMASKS", "VGS_A1MAX"])
+@pytest.mark.parametrize("knob", ["VGS_NO_NEAR", "VGS_NO_ADJMASKS", "VGS_A1MAX", "VGS_NO_DENSE"])
 def test_same_result_with_the_schedule_off(case, gpu, knob):
     """The knobs only schedule: rows, connect lists and labels are identical bit for bit (pair-evaluation counts may differ)."""
     old = os.environ.get(knob)

@@ -111,6 +111,12 @@ class Engine:
                  "supervoxels", "handed_over", "class_a", "class_bc", "class_d"]  # 12..15: local-cut scheduling diagnostics
         return {k: int(c[i]) for i, k in enumerate(names)}
 
+    def schedule_counters(self):
+        c = np.zeros(8, dtype=np.int64)
+        self._ck(self._L.vgs_get_schedule_counters(self._h, _ptr(c)))
+        names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded_phase_b")
+        return dict(zip(names, (int(x) for x in c)))
+
     def stage_times(self):
         t = np.zeros(_lib.T_COUNT, dtype=np.float64)
         self._ck(self._L.vgs_get_stage_times(self._h, _ptr(t)))

@@ -353,6 +353,12 @@ vgs_status vgs_get_stage_times(vgs_ctx* c, double* ms) {
   return VGS_OK;
 }
 
+vgs_status vgs_get_schedule_counters(vgs_ctx* c, int64_t* out) {
+  if (!c || !out) return VGS_E_ARG;
+  for (int i = 0; i < 8; ++i) out[i] = c->lc_diag[i];
+  return VGS_OK;
+}
+
 vgs_status vgs_get_bbox(vgs_ctx* c, double* b) {
   if (!c || !b) return VGS_E_ARG;
   if (c->stage < ST_VOXELS) { c->err = "vgs_get_bbox: voxelize first"; return VGS_E_STATE; }

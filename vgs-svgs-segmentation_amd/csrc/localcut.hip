@@ -26,7 +26,9 @@
 
 #include "vgs_context.hpp"
 
+#ifndef LC_TB
 #define LC_TB 256
+#endif
 #ifndef LC_SMALL_CAP
 #define LC_SMALL_CAP 4096   // edge list of the hand-over kernel for up to 128 neighbours
 #endif
@@ -36,6 +38,7 @@ struct LcParams {
   VgsWeightParams W;
   float cut;
   int prune_unused;
+  float d2_stop;   // squared centroid distance from which proximity alone proves w <= a singleton's threshold (+inf: never)
 };
 
 __device__ __forceinline__ int lc_bin1(float w) {
@@ -59,6 +62,15 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+
+#ifdef VGS_PROF
+__device__ unsigned long long g_lc_prof[2][16];   // per instantiation (small, large): cycles of wavefront 0 per phase
+#define LCP_T0() long long _lt0 = clock64()
+#define LCP_ACC(slot) do { long long _lt1 = clock64(); if (tid == 0) atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][slot], (unsigned long long)(_lt1 - _lt0)); _lt0 = _lt1; } while (0)
+#else
+#define LCP_T0() do {} while (0)
+#define LCP_ACC(slot) do {} while (0)
+#endif
 
 template <int MAXM, int CAP, bool NODES_LDS>
 __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__ work, int n_work, const unsigned int* __restrict__ n_work_dev,
@@ -131,6 +143,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
   const long long Ptot = (long long)m * (m - 1) / 2;
   unsigned long long my_pairs = 0;
+  LCP_T0();
+  LCP_ACC(0);   // (starts the clock; slot 0 = rows)
 
   // every thread walks the pairs (a < b) with stride LC_TB; f(a, b, w) sees each candidate pair whose
   // endpoints are in different segments and whose weight is not NaN (a NaN edge never merges, Q3)
@@ -224,6 +238,9 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   // 3. the few pairs between non-singleton segments still below thr0.  Falls back to the histogram rounds below
   //    (from a clean state) if a list overflows.
   bool fast_done = false;
+#ifdef VGS_PROF
+  int nq_dbg = 0;
+#endif
   if (m >= 2) {
     const float thr0 = vm_cut_threshold(1.0f, P.cut, 1);
     auto nd = [&](int a) -> const NodeRec& { return NODES_LDS ? lnode[a] : node[gid[a]]; };
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
       if (!(ub <= thr0)) { const float w = vm_pair_weight(A, B, P.W); if (w > thr0) s_sel = 1; }
     }
     __syncthreads();
+    LCP_ACC(1);   // incident edges
     if (s_sel == 0) {
       fast_done = true;  // the voxel stays alone
     } else {
@@ -271,7 +289,11 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
           qq += LC_TB;
         }
         __syncthreads();
+        LCP_ACC(2);   // screening pass
         const int nq = *q_n;
+#ifdef VGS_PROF
+        nq_dbg = nq;
+#endif
         if (nq > CAP) {
           if (tid == 0) s_nlist = CAP + 1;   // queue overflow: take the general rounds
         } else {
@@ -288,6 +310,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
           }
         }
         __syncthreads();
+        LCP_ACC(3);   // dense evaluation
         if (tid == 0) s_rdone = LC_NBIN * LC_NBIN;
       }
       __syncthreads();
@@ -295,7 +318,12 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
       __syncthreads();
       if (nlA <= CAP) {
         sort_desc(nlA);
+        LCP_ACC(4);   // sort A
         merge_all(nlA);
+        LCP_ACC(5);   // merge A
+#ifdef VGS_PROF
+        if (tid == 0) { atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][10], (unsigned long long)nlA); atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][11], (unsigned long long)nq_dbg); atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][12], 1ull); }
+#endif
         // phase B: vertices of non-singleton segments that can still merge below thr0
         const int s0 = seg[0];
         int active = 0;
@@ -330,9 +358,15 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
           __syncthreads();
           const int nlB = s_nlist;
           __syncthreads();
+          LCP_ACC(6);   // phase B pass
           if (nlB <= CAP) {
             sort_desc(nlB);
+            LCP_ACC(7);   // sort B
             merge_all(nlB);
+            LCP_ACC(8);   // merge B
+#ifdef VGS_PROF
+            if (tid == 0) { atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][13], (unsigned long long)nlB); atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][14], 1ull); }
+#endif
             fast_done = true;
           }
         }
@@ -434,6 +468,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
     if (tot < 2) break;
   }
   __syncthreads();
+  LCP_ACC(9);   // general rounds (when the fast path gave up)
+#ifdef VGS_PROF
+  if (tid == 0) atomicAdd(&g_lc_prof[MAXM > 128 ? 1 : 0][0], 1ull << 32);
+#endif
   // ---- result: the segment of vertex 0 (the voxel itself: first entry of its sorted adjacency row) ----
   if (m >= 1) {
     const uint16_t s0 = seg[0];
@@ -446,6 +484,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 }
 
 #include "localcut_wave.hpp"
+#include "localcut_dense.hpp"
 
 // split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.
 // Class A (the bulk) is split once more: voxels with few heavy near pairs of their own (short near-pair list) are the
@@ -486,6 +525,20 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
     if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }
 
+// Smallest squared distance (to the bisection's resolution) whose weight bound is at or below a singleton's threshold:
+// vm_weight_bound_d is monotone and host and device evaluate it alike (DevMath), so every pair at least this far apart
+// weighs <= bound(d2) <= bound(d2_stop) <= 1 - cut.
+static float lc_d2_stop(const VgsWeightParams& W, float cut, float d2_all) {
+  const float thr0 = vm_cut_threshold(1.0f, cut, 1);
+  if (!(vm_weight_bound_d(d2_all, W) <= thr0)) return __builtin_huge_valf();
+  float lo = 0.0f, hi = d2_all;
+  for (int it = 0; it < 24; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    if (vm_weight_bound_d(mid, W) <= thr0) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
 static VgsWeightParams make_weight_params(const vgs_params& p) {
   VgsWeightParams W;
   W.inv_sig_p = 1.0f / p.sig_p; W.inv_sig_n = 1.0f / p.sig_n; W.inv_sig_o = 1.0f / p.sig_o;
@@ -522,9 +575,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // (the adjacency stage already dropped the unused neighbours from the rows when that is the case)
   if (vgs_unused_are_inert(c->P) != c->adj_pruned) { c->err = "adjacency rows do not match the current sigma/cut parameters"; return VGS_E_STATE; }
   LP.prune_unused = 0;
+  LP.d2_stop = __builtin_huge_valf();   // set below, once the neighbourhood's reach is known
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure(7 * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure((8 + LW_HO_BINS) * (size_t)U + 16));
   VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
   VGS_HIP_TRY(c, c->counters.ensure(64));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
@@ -532,12 +586,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel, records in LDS
   uint32_t* ids_c = c->work_ids.p + 2 * U;    // m <= WAVE_C: one wavefront per voxel, centroids in LDS, records through L2
   uint32_t* ids_d = c->work_ids.p + 3 * U;    // the rest: one workgroup per voxel (k_localcut)
-  uint32_t* ids_f = c->work_ids.p + 4 * U;    // handed over by the A/B wave kernels (m <= WAVE_B)
+  uint32_t* ids_f = c->work_ids.p + 8 * U;    // handed over by the A/B wave kernels (m <= WAVE_B): LW_HO_BINS lists of U slots, by neighbourhood size
   uint32_t* ids_g = c->work_ids.p + 5 * U;    // handed over by the C wave kernel
   uint32_t* ids_a1 = c->work_ids.p + 6 * U;   // class A voxels with a short near-pair list of their own: they run first
+  uint32_t* ids_f2 = c->work_ids.p + 7 * U;   // sent on by the dense hand-over kernel (a list overflowed)
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 5 class counters (words 8-10)
-  unsigned int* d_nf = (unsigned int*)(c->counters.p + 11);
-  unsigned int* d_ng = d_nf + 1;
+  unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);        // lengths of the LW_HO_BINS lists (words 14-15)
+  unsigned int* d_ng = (unsigned int*)(c->counters.p + 11) + 1;    // word 11, upper half
+  unsigned int* d_nf2 = (unsigned int*)(c->counters.p + 12);
+  static_assert(LW_HO_BINS == 4, "four 32-bit list lengths in counter words 14-15");
 
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
   constexpr int LCAP_A = 448, LCAP_B = 312, LCAP_C = 2048;
@@ -572,6 +629,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // centroids within one voxel diagonal of their centres; SVGS: centroids within graph_size)
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     WP.d2_all = reach * reach * 1.01f;
+    LP.d2_stop = lc_d2_stop(LP.W, LP.cut, WP.d2_all);
+    WP.lc = LP;
   }
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
   WP.grow = 2.25f;
@@ -582,6 +641,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->lc_pending.ensure((size_t)U)); VGS_HIP_TRY(c, c->lc_defer.ensure((size_t)U));
   VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   WP.pending = c->lc_pending.p;
+  const bool dense = !getenv("VGS_NO_DENSE");   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
+  WP.ho_bins = dense ? LW_HO_BINS : 1;
+  WP.ho_stride = (int)U;
   {
     // Shells up to (NL_REACH voxels)^2 are complete in the near-pair lists; the margin covers centroids that float
     // rounding puts a hair outside their voxel's cube.
@@ -682,7 +744,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
     hipStream_t main_stream = c->stream;
     c->stream = c->stream3;  // launch_block uses c->stream
-    vgs_status st = launch_block(ids_f, grid_f, true, d_nf, 0);
+    vgs_status st = VGS_OK;
+    if (!dense) {
+      st = launch_block(ids_f, grid_f, true, d_nf, 0);
+    } else if (grid_f > 0) {
+      hipLaunchKernelGGL(k_localcut_dense, dim3(grid_f), dim3(LC_TB), 0, c->stream3, ids_f, (int)U, 0, d_nf, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+                         c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p);
+    }
     c->stream = main_stream;
     if (st != VGS_OK) return st;
     VGS_HIP_TRY(c, hipEventRecord(c->ev[4], c->stream3));
@@ -714,12 +782,16 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   const int64_t U = c->U;
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
   const unsigned int grid_f = c->lc_tail.grid_f, GRID_G = c->lc_tail.grid_g;
-  uint32_t* ids_f = c->work_ids.p + 4 * U;
+  uint32_t* ids_f = c->work_ids.p + 8 * U;
   uint32_t* ids_g = c->work_ids.p + 5 * U;
   LcParams LP;
   LP.W = make_weight_params(c->P);
   LP.cut = c->P.cut_thred;
   LP.prune_unused = 0;
+  {
+    const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
+    LP.d2_stop = lc_d2_stop(LP.W, LP.cut, reach * reach * 1.01f);
+  }
   constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
   auto launch_rest = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
@@ -743,16 +815,33 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   // one read-back: the kernels' flags (words 0-7), the lengths of the hand-over lists (word 11), the rows put off (word 13)
-  unsigned long long hc[14] = {0};
+  unsigned long long hc[16] = {0};
   VGS_READBACK(c, hc, cnt, sizeof(hc));
   const unsigned long long* h = hc;
-  const unsigned int nfg[2] = {(unsigned int)(hc[11] & 0xffffffffull), (unsigned int)(hc[11] >> 32)};
+  // hand-overs of the one-wavefront classes (all size lists together), of classes C/D
+  const unsigned int nfg[2] = {(unsigned int)((hc[14] & 0xffffffffull) + (hc[14] >> 32) + (hc[15] & 0xffffffffull) + (hc[15] >> 32)),
+                               (unsigned int)(hc[11] >> 32)};
   const unsigned int nf = nfg[0] + nfg[1];
   if (n_deferred) *n_deferred = (unsigned int)(hc[13] & 0xffffffffull);
-  if (nfg[0] > grid_f || nfg[1] > GRID_G) {
-    // lists longer than their fixed grids (not seen on the benchmark scenes): finish the rest
+  const bool dense = !getenv("VGS_NO_DENSE");
+  unsigned int nf2 = (unsigned int)(hc[12] & 0xffffffffull);   // sent on by the dense kernel
+  if (nfg[0] > grid_f || nfg[1] > GRID_G || nf2 > 0) {
+    // lists longer than their fixed grids, lists the dense kernel could not hold (neither seen on the benchmark scenes):
+    // finish the rest
     vgs_status st = VGS_OK;
-    if (nfg[0] > grid_f) st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true);
+    uint32_t* ids_f2 = c->work_ids.p + 7 * U;
+    if (nfg[0] > grid_f) {
+      if (dense) {
+        unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);
+        hipLaunchKernelGGL(k_localcut_dense, dim3(nfg[0] - grid_f), dim3(LC_TB), 0, c->stream, ids_f, (int)U, (int)grid_f, d_nf, c->adj_key.p, c->adj_cnt.p,
+                           c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, (unsigned int*)(c->counters.p + 12), c->evals.p);
+        VGS_READBACK(c, hc, cnt, sizeof(hc));
+        nf2 = (unsigned int)(hc[12] & 0xffffffffull);
+      } else {
+        st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true);
+      }
+    }
+    if (st == VGS_OK && nf2 > 0) st = launch_rest(ids_f2, nf2, true);
     if (st == VGS_OK && nfg[1] > GRID_G) st = launch_rest(ids_g + GRID_G, nfg[1] - GRID_G, false);
     if (st != VGS_OK) return st;
     VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
@@ -760,6 +849,8 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
+  c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2;
+  c->lc_diag[4] = (int64_t)nfg[1]; c->lc_diag[5] = (int64_t)h[1]; c->lc_diag[6] = (int64_t)(hc[13] & 0xffffffffull); c->lc_diag[7] = (int64_t)h[0];
   VGS_HIP_TRY(c, hipGetLastError());
   float kms = 0.f;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[6], c->ev[7]));
@@ -768,7 +859,14 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   c->times[VGS_T_LOCALCUT_BULK] = kms;
   if (getenv("VGS_DEBUG") && nfg[0] > 0) {
     std::vector<uint32_t> idf(nfg[0]), ev((size_t)U), ac((size_t)U);
-    VGS_HIP_TRY(c, hipMemcpy(idf.data(), ids_f, idf.size() * 4, hipMemcpyDeviceToHost));
+    {
+      const unsigned int nb4[4] = {(unsigned int)(hc[14] & 0xffffffffull), (unsigned int)(hc[14] >> 32), (unsigned int)(hc[15] & 0xffffffffull), (unsigned int)(hc[15] >> 32)};
+      size_t at = 0;
+      for (int k = 0; k < 4; ++k) {
+        if (nb4[k]) VGS_HIP_TRY(c, hipMemcpy(idf.data() + at, ids_f + (size_t)k * U, (size_t)nb4[k] * 4, hipMemcpyDeviceToHost));
+        at += nb4[k];
+      }
+    }
     VGS_HIP_TRY(c, hipMemcpy(ev.data(), c->evals.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     VGS_HIP_TRY(c, hipMemcpy(ac.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     double sm = 0, se = 0, sp = 0; uint32_t mn = ~0u, mx = 0;
@@ -790,6 +888,25 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   }
   if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
 #ifdef VGS_PROF
+  {
+    unsigned long long lp[2][16];
+    VGS_HIP_TRY(c, hipMemcpyFromSymbol(lp, HIP_SYMBOL(g_lc_prof), sizeof(lp)));
+    const char* nm[16] = {"rows<<32", "incident", "screen", "eval", "sortA", "mergeA", "passB", "sortB", "mergeB", "rounds", "sum_nlA", "sum_nq", "nA", "sum_nlB", "nB", ""};
+    for (int k = 0; k < 2; ++k) {
+      fprintf(stderr, "[vgs-prof] k_localcut %s:", k ? "large" : "small");
+      for (int j = 0; j < 15; ++j) fprintf(stderr, " %s=%.4g", nm[j], j == 0 ? (double)(lp[k][0] >> 32) : (double)lp[k][j]);
+      fprintf(stderr, "\n");
+    }
+    unsigned long long z[2][16] = {{0}};
+    VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_lc_prof), z, sizeof(z)));
+    unsigned long long dp[16];
+    VGS_HIP_TRY(c, hipMemcpyFromSymbol(dp, HIP_SYMBOL(g_dn_prof), sizeof(dp)));
+    const char* dn[16] = {"rows", "incident", "phaseA", "sortA", "mergeA", "passB", "sortB", "mergeB", "bands(+n>800k<<32)", "max_wall_10ns", "sum_nlA", "nA", "sum_nlB", "nB", "max_cycles", "n>400k"};
+    fprintf(stderr, "[vgs-prof] k_localcut_dense:");
+    for (int j = 0; j < 16; ++j) if (dn[j][0]) fprintf(stderr, " %s=%.4g", dn[j], j == 8 ? (double)(dp[j] >> 32) : (double)dp[j]);
+    fprintf(stderr, "\n");
+    VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_dn_prof), z, sizeof(dp)));
+  }
   {
     std::vector<uint32_t> dbg(4 * (size_t)U);
     VGS_HIP_TRY(c, hipMemcpy(dbg.data(), s_dbg.p, dbg.size() * 4, hipMemcpyDeviceToHost));

@@ -1,0 +1,452 @@
+// localcut_dense.hpp -- the local cut of the voxels the one-wavefront kernel hands over: ONE WORKGROUP PER VOXEL, every
+// pair examined once.  Included by localcut.hip behind localcut_wave.hpp (LcParams, wave_sync, LC_TB from there).
+//
+// Who gets here: neighbourhoods in clutter (vegetation, edges of scan shadows).  No segment forms early and freezes, so the
+// lazy schedule of localcut_wave.hpp ends up looking at almost every pair, shell after shell, and gives up.  The plain order
+// suits them better -- all n(n-1)/2 pairs once, but cheaply:
+//   * the neighbour records sit in LDS as one array per field (a lane walking consecutive vertices reads consecutive
+//     banks), so no pair costs an L2 round trip;
+//   * pass 1 puts every pair through the proximity + angle bound (vm_weight_bound_da) and queues the survivors, pass 2
+//     evaluates the queue on full wavefronts and keeps the edges heavier than a singleton's threshold (fact S of
+//     localcut_wave.hpp); the pairs are taken in blocks of DN_QCAP so that the queue cannot overflow;
+//   * the sequential merge is the claim scheme of the one-wavefront kernel (all edges of a 64-edge step that touch no
+//     segment of an earlier undecided edge act at once), and it stops as soon as the voxel's own segment is frozen (fact F);
+//   * phase B (pairs between non-singleton segments still below the singleton threshold) only when the voxel's segment
+//     is one of them.
+// Same sequential semantics as k_localcut; a list that overflows sends the voxel on to that kernel.
+#ifndef LOCALCUT_DENSE_HPP_
+#define LOCALCUT_DENSE_HPP_
+
+#define DN_MAXM 128     // the one-wavefront classes end here
+#define DN_LCAP 2048    // edges heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it)
+#define DN_QCAP 2048    // pairs per block of pass 1 = queue slots (16-bit pair ids)
+#define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
+#define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
+
+#ifdef VGS_PROF
+__device__ unsigned long long g_dn_prof[16];
+#define DNP_T0() long long _dt0 = clock64()
+#define DNP_ACC(slot) do { long long _dt1 = clock64(); if (tid == 0) atomicAdd(&g_dn_prof[slot], (unsigned long long)(_dt1 - _dt0)); _dt0 = _dt1; } while (0)
+#else
+#define DNP_T0() do {} while (0)
+#define DNP_ACC(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __restrict__ work, int work_stride, int offset, const unsigned int* __restrict__ n_work_dev,
+                                                          const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
+                                                          int adj_stride, const NodeRec* __restrict__ node, LcParams P,
+                                                          uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
+                                                          uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
+                                                          uint32_t* __restrict__ evals_out) {
+  __shared__ uint64_t lk[DN_LCAP];            // weight bits << 32 | ~pair id: one compare orders (w desc, pair asc)
+  __shared__ uint16_t queue[DN_QCAP];         // pair ids that passed the bound
+  static_assert(DN_NBIN * 4 <= DN_QCAP * 2, "the histogram lives in the queue");
+  __shared__ uint32_t rec[DN_NF][DN_MAXM];    // neighbour records, one array per field
+  __shared__ float thr[DN_MAXM];
+  __shared__ uint32_t claim[DN_MAXM];
+  __shared__ uint8_t seg[DN_MAXM], rep[DN_MAXM], ssz[DN_MAXM], alist[DN_MAXM];   // ssz: 128 is the largest size
+  __shared__ int s_nq, s_nlist, s_flag, s_nb;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // fixed grid, list lengths on the device: LW_HO_BINS lists (largest neighbourhoods first) taken one behind the other;
+  // workgroups beyond their end leave at once (offset = position of this launch in that order)
+  unsigned int wpos = (unsigned int)offset + blockIdx.x;
+  int wbin = 0;
+  while (wbin < LW_HO_BINS && wpos >= n_work_dev[wbin]) { wpos -= n_work_dev[wbin]; ++wbin; }
+  if (wbin == LW_HO_BINS) return;
+  const uint32_t u = work[(size_t)wbin * work_stride + wpos];
+  const int m = (int)adj_cnt[u];
+  const uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  uint8_t* crow = conn + (int64_t)u * adj_stride;
+  const VgsWeightParams& W = P.W;
+  const float cut = P.cut;
+  const float thr0 = vm_cut_threshold(1.0f, cut, 1);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  DNP_T0();
+#ifdef VGS_PROF
+  const long long t_begin = clock64();
+  const long long w_begin = wall_clock64();
+#endif
+
+  auto hand_on = [&]() {   // all threads
+    if (tid == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; atomicAdd(&counters[7], 1ull); }
+  };
+  if (m > DN_MAXM) { hand_on(); return; }   // not a one-wavefront voxel (cannot happen from the hand-over list)
+
+  // ---- records: 4 lanes per record read its four 16-byte quads, each word goes to its field array ----
+  for (int e = tid; e < m * 4; e += LC_TB) {
+    const int v = e >> 2, qd = e & 3;
+    const uint4 x = ((const uint4*)node)[(size_t)(uint32_t)row[v] * 4 + qd];
+    const int f0 = qd * 4;
+    rec[f0][v] = x.x;
+    if (f0 + 1 < DN_NF) rec[f0 + 1][v] = x.y;
+    if (f0 + 2 < DN_NF) rec[f0 + 2][v] = x.z;
+    if (f0 + 3 < DN_NF) rec[f0 + 3][v] = x.w;
+  }
+  for (int c = tid; c < m; c += LC_TB) { seg[c] = (uint8_t)c; rep[c] = (uint8_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu; }
+  if (tid == 0) { s_nq = 0; s_nlist = 0; s_flag = 0; s_nb = 0; }
+  __syncthreads();
+  auto load = [&](int v) -> NodeRec {
+    NodeRec r;
+    r.c[0] = __uint_as_float(rec[0][v]); r.c[1] = __uint_as_float(rec[1][v]); r.c[2] = __uint_as_float(rec[2][v]);
+    r.n[0] = __uint_as_float(rec[3][v]); r.n[1] = __uint_as_float(rec[4][v]); r.n[2] = __uint_as_float(rec[5][v]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.f[k] = __uint_as_float(rec[6 + k][v]);
+    r.flags = rec[14][v];
+    r.pad = 0;
+    return r;
+  };
+  auto load_cn = [&](int v) -> NodeRec {   // what the bound reads
+    NodeRec r;
+    r.c[0] = __uint_as_float(rec[0][v]); r.c[1] = __uint_as_float(rec[1][v]); r.c[2] = __uint_as_float(rec[2][v]);
+    r.n[0] = __uint_as_float(rec[3][v]); r.n[1] = __uint_as_float(rec[4][v]); r.n[2] = __uint_as_float(rec[5][v]);
+    r.flags = rec[14][v];
+    return r;
+  };
+  // pair p of the row-major triangle over nv vertices (a < b), decoded from the end (localcut_wave.hpp: enum_section)
+  auto decode = [&](uint32_t p, int nv, uint32_t Pn, int& a, int& b) {
+    const uint32_t q = Pn - 1u - p;
+    uint32_t r = (uint32_t)((__builtin_amdgcn_sqrtf((float)(8u * q + 1u)) - 1.0f) * 0.5f);
+    r += (((r + 1u) * (r + 2u)) >> 1) <= q ? 1u : 0u;
+    r -= ((r * (r + 1u)) >> 1) > q ? 1u : 0u;
+    a = nv - 2 - (int)r;
+    b = nv - 1 - (int)(q - ((r * (r + 1u)) >> 1));
+  };
+  // descending sort of lk[0, cnt): one-direction bitonic network, slots >= cnt never move (localcut_wave.hpp: sort_section)
+  auto sort_list = [&](int cnt) {
+    int np = 128;
+    while (np < cnt) np <<= 1;
+    auto cmpx = [&](int lo, int hi) {
+      if (hi >= cnt) return;
+      const uint64_t x = lk[lo], y = lk[hi];
+      if (x < y) { lk[lo] = y; lk[hi] = x; }
+    };
+    // comparators at distance < 128 stay inside a 128-key chunk: a wavefront runs them for its chunks back to back with
+    // no workgroup barrier in between (64 comparators per stage = one per lane)
+    auto chunk_tail = [&](int first_sl) {   // strides 2^first_sl .. 1 in every chunk
+      for (int ch = wave; ch < (np >> 7); ch += LC_TB / 64) {
+        if ((ch << 7) >= cnt) break;
+        for (int sl = first_sl; sl >= 0; --sl) {
+          const int lo = (ch << 7) + (((lane >> sl) << (sl + 1)) | (lane & ((1 << sl) - 1)));
+          cmpx(lo, lo + (1 << sl));
+          wave_sync();
+        }
+      }
+    };
+    __syncthreads();
+    // sizes 2 .. 128: entirely chunk-local
+    for (int ch = wave; ch < (np >> 7); ch += LC_TB / 64) {
+      if ((ch << 7) >= cnt) break;
+      for (int size = 2, sbit = 1; size <= 128; size <<= 1, ++sbit) {
+        {
+          const int blk = lane >> (sbit - 1), i = lane & ((size >> 1) - 1);
+          cmpx((ch << 7) + (blk << sbit) + i, (ch << 7) + (blk << sbit) + size - 1 - i);
+          wave_sync();
+        }
+        for (int sl = sbit - 2; sl >= 0; --sl) {
+          const int lo = (ch << 7) + (((lane >> sl) << (sl + 1)) | (lane & ((1 << sl) - 1)));
+          cmpx(lo, lo + (1 << sl));
+          wave_sync();
+        }
+      }
+    }
+    __syncthreads();
+    for (int size = 256, sbit = 8; size <= np; size <<= 1, ++sbit) {
+      for (int t = tid; t < (np >> 1); t += LC_TB) {
+        const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
+        cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
+      }
+      __syncthreads();
+      for (int sl = sbit - 2; sl >= 7; --sl) {
+        const int strd = 1 << sl;
+        for (int t = tid; t < (np >> 1); t += LC_TB) {
+          const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
+          cmpx(lo, lo + strd);
+        }
+        __syncthreads();
+      }
+      chunk_tail(6);
+      __syncthreads();
+    }
+  };
+  // Sequential merge of the sorted list on wavefront 0 (localcut_wave.hpp: merge_list, to the end of the list); stops early
+  // when one segment is left or the voxel's own segment can no longer merge.  Ends with a workgroup barrier.
+  int merges = 0;   // meaningful on wavefront 0
+  auto merge_list = [&](int cnt) {
+    if (wave == 0) {
+      // while the voxel is alone it can only merge through an edge of its own (vertex 0 is the first vertex of its pairs)
+      int last_own = -1;
+      for (int base = 0; base < cnt; base += 64) {
+        const int e = base + lane;
+        const bool own = e < cnt && ((0xffffu - (uint32_t)(lk[e] & 0xffffu)) >> 8) == 0u;
+        const unsigned long long mk = __ballot(own);
+        if (mk != 0ull) last_own = base + 63 - __builtin_clzll(mk);
+      }
+      int pos = 0;
+      while (pos < cnt) {
+        const int e = pos + lane;
+        float w = 0.f;
+        int sa = 0, sb = 0;
+        bool alive = false;
+        if (e < cnt) {
+          const uint64_t key = lk[e];
+          w = vm_from_bits((uint32_t)(key >> 32));
+          const uint32_t pid = 0xffffu - (uint32_t)(key & 0xffffu);
+          sa = seg[pid >> 8];
+          sb = seg[pid & 0xffu];
+          alive = true;
+        }
+        while (true) {
+          if (alive) {
+            int r;
+            while ((r = rep[sa]) != sa) sa = r;
+            while ((r = rep[sb]) != sb) sb = r;
+            alive = sa != sb;
+          }
+          if (__ballot(alive) == 0ull) break;
+          if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
+          wave_sync();
+          bool decided = false;
+          float ta = 0.f, tb = 0.f;
+          int nsz = 1;
+          if (alive) {
+            decided = (claim[sa] == (uint32_t)lane) && (claim[sb] == (uint32_t)lane);
+            ta = thr[sa]; tb = thr[sb];
+            nsz = (int)ssz[sa] + (int)ssz[sb];
+          }
+          wave_sync();
+          if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
+          const bool pass = decided && (w > ta) && (w > tb);
+          if (pass) {
+            const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
+            const int gone = (ta >= tb) ? sb : sa;
+            rep[gone] = (uint8_t)keep;
+            thr[keep] = vm_cut_threshold(w, cut, nsz);   // seg_int = w (VS:1988)
+            ssz[keep] = (uint8_t)nsz;
+            ssz[gone] = 0;
+          }
+          merges += __popcll(__ballot(pass));
+          alive = alive && !decided;
+          wave_sync();
+        }
+        pos += 64;
+        if (merges >= m - 1 || pos >= cnt) break;
+        // every edge from here on weighs at most wn: a segment whose threshold is not below that is frozen (fact F), and
+        // only the voxel's own segment is reported
+        const float wn = vm_from_bits((uint32_t)(lk[pos] >> 32));
+        int s0 = 0, r;
+        while ((r = rep[s0]) != s0) s0 = r;
+        if (!(thr[s0] < wn)) break;
+        if (ssz[s0] == 1 && pos > last_own) break;
+      }
+      for (int c = lane; c < m; c += 64) {
+        int s = seg[c];
+        while (rep[s] != s) s = rep[s];
+        seg[c] = (uint8_t)s;
+      }
+    }
+    __syncthreads();
+  };
+
+  unsigned int my_pairs = 0;
+  bool done = (m < 2);
+  bool handed = false;
+  // ---- 1. can the voxel merge at all?  (an incident edge heavier than a singleton's threshold) ----
+  if (!done) {
+    bool any = false;
+    const NodeRec A = load(0);
+    for (int x = 1 + tid; x < m; x += LC_TB) {
+      const NodeRec B = load(x);
+      ++my_pairs;
+      if (!(vm_weight_bound_da(A, B, W) <= thr0)) any = any || (vm_pair_weight(A, B, W) > thr0);
+    }
+    if (any) s_flag = 1;
+    __syncthreads();
+    done = s_flag == 0;
+  }
+  DNP_ACC(1);
+  if (!done) {
+    // ---- 2. phase A: every edge heavier than thr0 ----
+    const uint32_t Pall = (uint32_t)(m * (m - 1) / 2);
+    for (uint32_t base = 0; base < Pall; base += DN_QCAP) {
+      for (uint32_t p = base + (uint32_t)tid; p < base + DN_QCAP; p += LC_TB) {   // same trip count for every thread of a wavefront
+        bool keep = false;
+        int a = 0, b = 0;
+        if (p < Pall) {
+          decode(p, m, Pall, a, b);
+          ++my_pairs;
+          const NodeRec A = load_cn(a), B = load_cn(b);
+          // proximity alone settles the far pairs (w <= bound(d2) <= bound(d2_stop) <= thr0) for a tenth of the bound's cost
+          const float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
+          const bool far = ((A.flags & B.flags & VGS_F_POS) != 0u) && ((dx * dx + dy * dy) + dz * dz >= P.d2_stop);
+          keep = !far && !(vm_weight_bound_da(A, B, W) <= thr0);
+        }
+        const unsigned long long mk = __ballot(keep);
+        if (mk != 0ull) {
+          int qb = 0;
+          if (lane == 0) qb = atomicAdd(&s_nq, __popcll(mk));
+          qb = __shfl(qb, 0, 64);
+          if (keep) queue[qb + __popcll(mk & lt_mask)] = (uint16_t)(((uint32_t)a << 8) | (uint32_t)b);
+        }
+      }
+      __syncthreads();
+      const int nq = s_nq;
+      for (int e = tid; e < nq; e += LC_TB) {
+        const uint32_t pid = queue[e];
+        const float w = vm_pair_weight(load((int)(pid >> 8)), load((int)(pid & 0xffu)), W);
+        if (w > thr0) {
+          const int pos = atomicAdd(&s_nlist, 1);
+          if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - pid);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_nq = 0;
+      if (s_nlist > DN_LCAP) break;   // uniform: read after the barrier, written before it
+      __syncthreads();
+    }
+    DNP_ACC(2);
+    const int nlA = s_nlist;
+    if (nlA > DN_LCAP) { hand_on(); handed = true; }
+    else {
+      sort_list(nlA);
+      DNP_ACC(3);
+      merge_list(nlA);
+      DNP_ACC(4);
+#ifdef VGS_PROF
+      if (tid == 0) { atomicAdd(&g_dn_prof[10], (unsigned long long)nlA); atomicAdd(&g_dn_prof[11], 1ull); }
+#endif
+      // ---- 3. phase B: non-singleton segments still below thr0 merge through edges at or below thr0 ----
+      const int s0 = seg[0];
+      const bool s0_active = (ssz[s0] >= 2) && (thr[s0] < thr0);
+      if (s0_active) {   // uniform
+        if (tid == 0) s_nlist = 0;
+        if (wave == 0) {
+          int nb = 0;
+          for (int base = 0; base < m; base += 64) {
+            const int v = base + lane;
+            bool act = false;
+            if (v < m) { const int s = seg[v]; act = (ssz[s] >= 2) && (thr[s] < thr0); }
+            const unsigned long long mk = __ballot(act);
+            if (act) alist[nb + __popcll(mk & lt_mask)] = (uint8_t)v;
+            nb += __popcll(mk);
+          }
+          if (lane == 0) s_nb = nb;
+        }
+        __syncthreads();
+        const int nb = s_nb;
+        const uint32_t Pb = (uint32_t)(nb * (nb - 1) / 2);
+        for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+          int ia, ib;
+          decode(p, nb, Pb, ia, ib);
+          const int a = alist[ia], b = alist[ib];
+          if (seg[a] != seg[b]) {
+            const float w = vm_pair_weight(load(a), load(b), W);
+            ++my_pairs;
+            if (w <= thr0) {   // heavier edges were examined in phase A; NaN compares false
+              const int pos = atomicAdd(&s_nlist, 1);
+              if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - (((uint32_t)a << 8) | (uint32_t)b));
+            }
+          }
+        }
+        __syncthreads();
+        const int nlB = s_nlist;
+        DNP_ACC(5);
+        if (nlB <= DN_LCAP) {
+          sort_list(nlB);
+          DNP_ACC(6);
+          merge_list(nlB);
+          DNP_ACC(7);
+#ifdef VGS_PROF
+          if (tid == 0) { atomicAdd(&g_dn_prof[12], (unsigned long long)nlB); atomicAdd(&g_dn_prof[13], 1ull); }
+#endif
+        } else {
+          // More such pairs than the list holds (large neighbourhoods whose segments all stay below thr0): the scan takes
+          // them in bands of descending weight.  One pass histograms the weights (DN_NBIN bins over [0, thr0]; the
+          // queue's slots are free now), then every band -- the heaviest whole bins that fit the list -- is collected by a
+          // pass of its own, sorted and merged.  Pairs merged away meanwhile only make later bands shorter.  The bands end
+          // when the voxel's own segment is frozen below the next band (fact F).
+          if (tid == 0) atomicAdd(&counters[0], 1ull);
+          uint32_t* hist = (uint32_t*)queue;
+          const float scale = (float)DN_NBIN / thr0;
+          auto bin_of = [&](float w) -> int { const int bb = (int)(w * scale); return bb < 0 ? 0 : (bb > DN_NBIN - 1 ? DN_NBIN - 1 : bb); };
+          for (int k = tid; k < DN_NBIN; k += LC_TB) hist[k] = 0u;
+          __syncthreads();
+          for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+            int ia, ib;
+            decode(p, nb, Pb, ia, ib);
+            const int a = alist[ia], b = alist[ib];
+            if (seg[a] != seg[b]) {
+              const float w = vm_pair_weight(load(a), load(b), W);
+              ++my_pairs;
+              if (w <= thr0) atomicAdd(&hist[bin_of(w)], 1u);
+            }
+          }
+          __syncthreads();
+          int top = DN_NBIN;   // bins [top, DN_NBIN) are done
+          while (true) {
+            if (tid == 0) {
+              unsigned int acc = 0;
+              int lo = top;
+              while (lo > 0 && acc + hist[lo - 1] <= (unsigned int)DN_LCAP) { --lo; acc += hist[lo]; }
+              s_nb = lo;
+              s_nlist = 0;
+            }
+            __syncthreads();
+            const int lo = s_nb;
+            if (lo == top) { hand_on(); handed = true; break; }   // one bin alone overflows the list: degenerate ties
+            for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+              int ia, ib;
+              decode(p, nb, Pb, ia, ib);
+              const int a = alist[ia], b = alist[ib];
+              if (seg[a] != seg[b]) {
+                const float w = vm_pair_weight(load(a), load(b), W);
+                ++my_pairs;
+                if (w <= thr0) {
+                  const int bb = bin_of(w);
+                  if (bb >= lo && bb < top) {
+                    const int pos = atomicAdd(&s_nlist, 1);
+                    if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - (((uint32_t)a << 8) | (uint32_t)b));
+                  }
+                }
+              }
+            }
+            __syncthreads();
+            const int nband = s_nlist < DN_LCAP ? s_nlist : DN_LCAP;   // <= the histogram's count of these bins
+            sort_list(nband);
+            merge_list(nband);
+            if (lo == 0) break;
+            top = lo;
+            // every pair left has a bin below `top`, so it weighs less than this
+            const float wub = (float)top / scale * 1.0001f;
+            const int r0 = seg[0];   // flattened by merge_list
+            if (!(thr[r0] < wub) || (int)ssz[r0] == m) break;
+            __syncthreads();   // s_nb / s_nlist are rewritten at the top
+          }
+          DNP_ACC(8);
+        }
+      }
+    }
+  }
+  if (handed) return;   // k_localcut writes the row and the count
+  // ---- result: the segment of the voxel itself, the whole row (nobody zeroes the table first) ----
+  {
+    const int s0 = seg[0];
+    for (int c = tid; c < m; c += LC_TB) crow[c] = (seg[c] == s0) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
+  if (tid == 0) evals_out[u] = 0;
+  __syncthreads();
+  if (lane == 0 && my_pairs) atomicAdd(&evals_out[u], my_pairs);
+#ifdef VGS_PROF
+  if (tid == 0) {
+    atomicAdd(&g_dn_prof[0], 1ull);
+    const unsigned long long tt = (unsigned long long)(clock64() - t_begin);
+    atomicMax(&g_dn_prof[14], tt);
+    atomicMax(&g_dn_prof[9], (unsigned long long)(wall_clock64() - w_begin));
+    if (tt > 400000ull) atomicAdd(&g_dn_prof[15], 1ull);
+    if (tt > 800000ull) atomicAdd(&g_dn_prof[8], 1ull << 32);
+  }
+#endif
+}
+
+#endif

@@ -67,7 +67,14 @@ struct LwParams {
   int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
   NearLists near;   // per-voxel lists of the heavy pairs within two lattice steps (nearlist.hpp): the first shell walks them
   uint8_t* pending; // per used voxel: set when the voxel is handed over (its connect row is final only after the hand-over kernel)
+  int ho_bins;      // one-wavefront classes: hand-over lists by neighbourhood size (LW_HO_BINS, largest first) or 1
+  int ho_stride;    // distance between those lists in the hand-over array (= the number of used voxels)
 };
+
+// The hand-over kernel's cost grows with the square of the neighbourhood size and its launch ends with the slowest voxel:
+// the one-wavefront classes sort their hand-overs into lists by size, and the launch takes the list of the largest first.
+#define LW_HO_BINS 4
+__device__ __forceinline__ int lw_ho_bin(int m) { return m > 112 ? 0 : (m > 96 ? 1 : (m > 64 ? 2 : 3)); }
 
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
@@ -162,7 +169,11 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   auto R = [&](int v) -> const NodeRec& { return node[GID_LDS ? gid[v] : (uint32_t)row[v]]; };
   const int m = n;
   if (m > MAXM || (P.dbg_max_m > 0 && m > P.dbg_max_m)) {  // beyond this kernel's arrays: hand over to the general kernel
-    if (threadIdx.x == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; P.pending[u] = 1; }
+    if (threadIdx.x == 0) {
+      const int bin = (SMALL && NW == 1 && P.ho_bins > 1) ? lw_ho_bin(m) : 0;
+      fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u;
+      P.pending[u] = 1;
+    }
     return;
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
@@ -830,7 +841,11 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     }
   }
   if (bail) {
-    if (lane == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; P.pending[u] = 1; }
+    if (lane == 0) {
+      const int bin = (SMALL && NW == 1 && P.ho_bins > 1) ? lw_ho_bin(m) : 0;
+      fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u;
+      P.pending[u] = 1;
+    }
     return;
   }
   // ---- result: the segment of vertex 0 (the voxel itself) ----

@@ -443,7 +443,16 @@ VGS_HD void vm_pair_distances(const VgsNode& v1, const VgsNode& v2, int svgs, fl
   }
   if (ev) {
     float ec = 0.0f, e1 = 0.0f, e2 = 0.0f;
-    for (int i = svgs ? 0 : 4; i < 8; ++i) {
+    // entries 4..7 (VS) or 0..7 (SS), summed in index order; two loops with constant bounds, so that records held in
+    // registers are never indexed with a run-time value
+    if (svgs) {
+      for (int i = 0; i < 4; ++i) {
+        ec = ec + v1.f[i] * v2.f[i];
+        e1 = e1 + v1.f[i] * v1.f[i];
+        e2 = e2 + v2.f[i] * v2.f[i];
+      }
+    }
+    for (int i = 4; i < 8; ++i) {
       ec = ec + v1.f[i] * v2.f[i];
       e1 = e1 + v1.f[i] * v1.f[i];
       e2 = e2 + v2.f[i] * v2.f[i];
