@@ -20,6 +20,7 @@
 //     not-yet-examined candidate weights picks the heaviest <= CAP edges, which are collected, sorted and
 //     merged before the next round (weights are recomputed instead of stored: flops are cheaper than HBM).
 #include <algorithm>
+#include <cmath>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -34,11 +35,16 @@
 #endif
 #define LC_NBIN 2048
 
+#define LC_TBINS 64
 struct LcParams {
   VgsWeightParams W;
   float cut;
   int prune_unused;
   float d2_stop;   // squared centroid distance from which proximity alone proves w <= a singleton's threshold (+inf: never)
+  // Screening table of the dense kernel: a pair of valid positions and normals with squared centroid distance in bin k
+  // (k = int(d2 * ctab_scale)) and dot(n1, n2) in [-1, ctab[k]] weighs <= 1 - cut (lc_screen_table)
+  float ctab_scale;
+  float ctab[LC_TBINS];
 };
 
 __device__ __forceinline__ int lc_bin1(float w) {
@@ -539,6 +545,36 @@ static float lc_d2_stop(const VgsWeightParams& W, float cut, float d2_all) {
   return hi;
 }
 
+// Screening table (LcParams::ctab).  A pair in bin k is at least d_k = sqrt(k / scale) apart; A_k is an angle with
+// bound_sa(d_k, A_k) <= thr0 (bisection on the float formula that vm_weight_bound_da ends in, monotone in both distances;
+// the 2e-6 on the threshold covers vm_exp's last-bit wobble), and ctab[k] a cosine no angle below A_k + 2e-6 reaches
+// (vm_acos is within an ulp of acos, 2.4e-7 at pi).  So dot <= ctab[k] -- with dot >= -1, or vm_acos gives NaN and the bound
+// says nothing -- means dist_angle >= A_k, hence w <= bound_da(pair) <= bound_sa(d_k, A_k) <= thr0.  ctab[k] = -2: no angle
+// settles bin k.
+static void lc_screen_table(const VgsWeightParams& W, float cut, float d2_stop, LcParams* out) {
+  const float thr0 = vm_cut_threshold(1.0f, cut, 1) * (1.0f - 2.0e-6f);
+  const bool bounded = d2_stop < __builtin_huge_valf();
+  const double width = bounded ? (double)d2_stop / LC_TBINS : 0.0;
+  out->ctab_scale = bounded ? (float)(1.0 / width) : 0.0f;   // unbounded: every pair reads bin 0 (distance 0)
+  for (int k = 0; k < LC_TBINS; ++k) {
+    // d2 * scale >= k in float => d2 >= k * width up to rounding: a relative 1e-6 below
+    const float dk = vm_sqrt((float)((double)k * width * (1.0 - 1.0e-6)));
+    float ck = -2.0f;
+    if (vm_weight_bound_sa(dk, 3.1415925f, W) <= thr0) {
+      float lo = 0.0f, hi = 3.1415925f;
+      if (vm_weight_bound_sa(dk, 0.0f, W) <= thr0) hi = 0.0f;
+      else
+        for (int it = 0; it < 30; ++it) {
+          const float mid = 0.5f * (lo + hi);
+          if (vm_weight_bound_sa(dk, mid, W) <= thr0) hi = mid; else lo = mid;
+        }
+      ck = (float)(cos((double)hi + 2.0e-6) - 1.0e-6);
+      if (!((double)hi + 2.0e-6 < 3.14159)) ck = -2.0f;
+    }
+    out->ctab[k] = ck;
+  }
+}
+
 static VgsWeightParams make_weight_params(const vgs_params& p) {
   VgsWeightParams W;
   W.inv_sig_p = 1.0f / p.sig_p; W.inv_sig_n = 1.0f / p.sig_n; W.inv_sig_o = 1.0f / p.sig_o;
@@ -630,6 +666,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     WP.d2_all = reach * reach * 1.01f;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, WP.d2_all);
+    lc_screen_table(LP.W, LP.cut, LP.d2_stop, &LP);
     WP.lc = LP;
   }
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
@@ -791,6 +828,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, reach * reach * 1.01f);
+    lc_screen_table(LP.W, LP.cut, LP.d2_stop, &LP);
   }
   constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;

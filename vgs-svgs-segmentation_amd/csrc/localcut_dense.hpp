@@ -46,6 +46,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
   __shared__ uint32_t claim[DN_MAXM];
   __shared__ uint8_t seg[DN_MAXM], rep[DN_MAXM], ssz[DN_MAXM], alist[DN_MAXM];   // ssz: 128 is the largest size
   __shared__ int s_nq, s_nlist, s_flag, s_nb;
+  __shared__ float s_ctab[LC_TBINS];          // LcParams::ctab where a lane can index it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // fixed grid, list lengths on the device: LW_HO_BINS lists (largest neighbourhoods first) taken one behind the other;
@@ -84,7 +85,11 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     if (f0 + 3 < DN_NF) rec[f0 + 3][v] = x.w;
   }
   for (int c = tid; c < m; c += LC_TB) { seg[c] = (uint8_t)c; rep[c] = (uint8_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu; }
-  if (tid == 0) { s_nq = 0; s_nlist = 0; s_flag = 0; s_nb = 0; }
+  if (tid == 0) {
+    s_nq = 0; s_nlist = 0; s_flag = 0; s_nb = 0;
+#pragma unroll
+    for (int k = 0; k < LC_TBINS; ++k) s_ctab[k] = P.ctab[k];
+  }
   __syncthreads();
   auto load = [&](int v) -> NodeRec {
     NodeRec r;
@@ -276,10 +281,20 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           decode(p, m, Pall, a, b);
           ++my_pairs;
           const NodeRec A = load_cn(a), B = load_cn(b);
-          // proximity alone settles the far pairs (w <= bound(d2) <= bound(d2_stop) <= thr0) for a tenth of the bound's cost
           const float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
-          const bool far = ((A.flags & B.flags & VGS_F_POS) != 0u) && ((dx * dx + dy * dy) + dz * dz >= P.d2_stop);
-          keep = !far && !(vm_weight_bound_da(A, B, W) <= thr0);
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
+          const uint32_t both = A.flags & B.flags;
+          if ((both & VGS_F_POS) != 0u && d2 >= P.d2_stop) {
+            keep = false;   // proximity alone: w <= bound(d2) <= bound(d2_stop) <= thr0
+          } else if ((both & (VGS_F_POS | VGS_F_NRM)) == (VGS_F_POS | VGS_F_NRM) && d2 > 0.0f) {
+            // the proximity + angle bound read from a table by distance (LcParams::ctab): a tenth of its cost
+            int k = (int)(d2 * P.ctab_scale);
+            k = k > LC_TBINS - 1 ? LC_TBINS - 1 : k;
+            const float dot = vm_dot3(A.n, B.n);
+            keep = !(dot <= s_ctab[k] && dot >= -1.0f);
+          } else {
+            keep = !(vm_weight_bound_da(A, B, W) <= thr0);
+          }
         }
         const unsigned long long mk = __ballot(keep);
         if (mk != 0ull) {

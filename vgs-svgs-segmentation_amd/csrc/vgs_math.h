@@ -495,6 +495,14 @@ VGS_HD float vm_weight_bound_d(float d2, const VgsWeightParams& P) {
   return vm_exp((-0.5f * D) * P.inv_sig_w2) * 1.000001f;
 }
 
+// the weight of a pair whose other three distances are zero
+VGS_HD float vm_weight_bound_sa(float dist_space, float dist_angle, const VgsWeightParams& P) {
+  float D;
+  if (!P.svgs) { const float s = dist_space * P.inv_sig_p, a = dist_angle * P.inv_sig_n; D = vm_sqrt(s * s + a * a); }
+  else D = vm_sqrt(dist_space * dist_space * P.inv_sig_p + dist_angle * dist_angle * P.inv_sig_n);
+  return vm_exp((-0.5f * D) * P.inv_sig_w2) * 1.000001f;
+}
+
 VGS_HD float vm_weight_bound_da(const VgsNode& v1, const VgsNode& v2, const VgsWeightParams& P) {
   float dist_space = 100.0f, dist_angle = 100.0f, d12 = 0.0f;
   if ((v1.flags & VGS_F_POS) && (v2.flags & VGS_F_POS)) {
@@ -506,10 +514,7 @@ VGS_HD float vm_weight_bound_da(const VgsNode& v1, const VgsNode& v2, const VgsW
     const bool guard = P.svgs ? (d12 != 0.0f) : (dist_space != 0.0f);
     if (guard) dist_angle = vm_acos(vm_dot3(v1.n, v2.n));
   }
-  float D;
-  if (!P.svgs) { const float s = dist_space * P.inv_sig_p, a = dist_angle * P.inv_sig_n; D = vm_sqrt(s * s + a * a); }
-  else D = vm_sqrt(dist_space * dist_space * P.inv_sig_p + dist_angle * dist_angle * P.inv_sig_n);
-  return vm_exp((-0.5f * D) * P.inv_sig_w2) * 1.000001f;
+  return vm_weight_bound_sa(dist_space, dist_angle, P);
 }
 
 // Threshold of a segment in the local cut (VS:1968-1969): seg_int - cut/size, float.
