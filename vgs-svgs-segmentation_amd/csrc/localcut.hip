@@ -939,9 +939,9 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_lc_prof), z, sizeof(z)));
     unsigned long long dp[16];
     VGS_HIP_TRY(c, hipMemcpyFromSymbol(dp, HIP_SYMBOL(g_dn_prof), sizeof(dp)));
-    const char* dn[16] = {"rows", "incident", "phaseA", "sortA", "mergeA", "passB", "sortB", "mergeB", "bands(+n>800k<<32)", "max_wall_10ns", "sum_nlA", "nA", "sum_nlB", "nB", "max_cycles", "n>400k"};
+    const char* dn[16] = {"rows", "incident", "phaseA", "sortA", "mergeA", "passB", "sortB", "mergeB", "unreachable_B(+band cycles)", "max_wall_10ns", "sum_nlA", "nA", "sum_nlB", "nB", "max_cycles", "n>400k"};
     fprintf(stderr, "[vgs-prof] k_localcut_dense:");
-    for (int j = 0; j < 16; ++j) if (dn[j][0]) fprintf(stderr, " %s=%.4g", dn[j], j == 8 ? (double)(dp[j] >> 32) : (double)dp[j]);
+    for (int j = 0; j < 16; ++j) if (dn[j][0]) fprintf(stderr, " %s=%.4g", dn[j], j == 8 ? (double)(dp[j] & 0xffffffffull) : (double)dp[j]);
     fprintf(stderr, "\n");
     VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_dn_prof), z, sizeof(dp)));
   }

@@ -336,24 +336,59 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
       if (s0_active) {   // uniform
         if (tid == 0) s_nlist = 0;
         if (wave == 0) {
-          int nb = 0;
+          // the vertices of the active segments, the voxel's own segment first
+          int n0 = 0;
+          for (int base = 0; base < m; base += 64) {
+            const int v = base + lane;
+            const bool own = v < m && seg[v] == s0;
+            const unsigned long long mk = __ballot(own);
+            if (own) alist[n0 + __popcll(mk & lt_mask)] = (uint8_t)v;
+            n0 += __popcll(mk);
+          }
+          int nb = n0;
           for (int base = 0; base < m; base += 64) {
             const int v = base + lane;
             bool act = false;
-            if (v < m) { const int s = seg[v]; act = (ssz[s] >= 2) && (thr[s] < thr0); }
+            if (v < m) { const int sv = seg[v]; act = sv != s0 && (ssz[sv] >= 2) && (thr[sv] < thr0); }
             const unsigned long long mk = __ballot(act);
             if (act) alist[nb + __popcll(mk & lt_mask)] = (uint8_t)v;
             nb += __popcll(mk);
           }
-          if (lane == 0) s_nb = nb;
+          if (lane == 0) { s_nb = nb; s_nq = n0; }
         }
         __syncthreads();
-        const int nb = s_nb;
+        const int nb = s_nb, n0 = s_nq;
+        // The voxel's segment changes only through an edge of its own heavier than its threshold L.  If no pair between
+        // it and another active segment weighs more than L (and at most thr0), nothing the other segments do among
+        // themselves can reach it: phase B is over before it starts.  n0 * (nb - n0) pairs instead of nb^2 / 2.
+        {
+          const float L = thr[s0];
+          const int no = nb - n0;
+          bool hit = false;
+          for (int idx = tid; idx < n0 * no; idx += LC_TB) {
+            const int x = alist[idx / no], y = alist[n0 + idx % no];
+            const int a = x < y ? x : y, b = x < y ? y : x;
+            const NodeRec A = load(a), B = load(b);
+            ++my_pairs;
+            if (!(vm_weight_bound_da(A, B, W) <= L)) {
+              const float w = vm_pair_weight(A, B, W);
+              hit = hit || (w > L && w <= thr0);
+            }
+          }
+          if (hit) s_flag = 2;
+          __syncthreads();
+        }
+        const bool reachable = s_flag == 2;
+#ifdef VGS_PROF
+        if (tid == 0 && !reachable) atomicAdd(&g_dn_prof[8], 1ull);
+#endif
+        if (reachable) {
         const uint32_t Pb = (uint32_t)(nb * (nb - 1) / 2);
         for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
           int ia, ib;
           decode(p, nb, Pb, ia, ib);
-          const int a = alist[ia], b = alist[ib];
+          const int xa = alist[ia], xb = alist[ib];
+          const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
           if (seg[a] != seg[b]) {
             const float w = vm_pair_weight(load(a), load(b), W);
             ++my_pairs;
@@ -389,7 +424,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
             int ia, ib;
             decode(p, nb, Pb, ia, ib);
-            const int a = alist[ia], b = alist[ib];
+            const int xa = alist[ia], xb = alist[ib];
+          const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
             if (seg[a] != seg[b]) {
               const float w = vm_pair_weight(load(a), load(b), W);
               ++my_pairs;
@@ -412,7 +448,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
             for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
               int ia, ib;
               decode(p, nb, Pb, ia, ib);
-              const int a = alist[ia], b = alist[ib];
+              const int xa = alist[ia], xb = alist[ib];
+          const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
               if (seg[a] != seg[b]) {
                 const float w = vm_pair_weight(load(a), load(b), W);
                 ++my_pairs;
@@ -439,6 +476,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           }
           DNP_ACC(8);
         }
+        }   // reachable
       }
     }
   }
