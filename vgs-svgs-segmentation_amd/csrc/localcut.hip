@@ -21,6 +21,7 @@
 //     merged before the next round (weights are recomputed instead of stored: flops are cheaper than HBM).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -44,7 +45,7 @@ struct LcParams {
   // Screening table of the dense kernel: a pair of valid positions and normals with squared centroid distance in bin k
   // (k = int(d2 * ctab_scale)) and dot(n1, n2) in [-1, ctab[k]] weighs <= 1 - cut (lc_screen_table)
   float ctab_scale;
-  float ctab[LC_TBINS];
+  const float* ctab;   // LC_TBINS floats on the device
 };
 
 __device__ __forceinline__ int lc_bin1(float w) {
@@ -491,6 +492,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 #include "localcut_wave.hpp"
 #include "localcut_dense.hpp"
+#define DN_SMALL 128, 2048, 2048, 256   // hand-overs of the one-wavefront classes
+#define DN_LARGE 512, 4096, 2048, 512   // hand-overs of classes C and D up to 512 neighbours
 
 // split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.
 // Class A (the bulk) is split once more: voxels with few heavy near pairs of their own (short near-pair list) are the
@@ -551,11 +554,11 @@ static float lc_d2_stop(const VgsWeightParams& W, float cut, float d2_all) {
 // (vm_acos is within an ulp of acos, 2.4e-7 at pi).  So dot <= ctab[k] -- with dot >= -1, or vm_acos gives NaN and the bound
 // says nothing -- means dist_angle >= A_k, hence w <= bound_da(pair) <= bound_sa(d_k, A_k) <= thr0.  ctab[k] = -2: no angle
 // settles bin k.
-static void lc_screen_table(const VgsWeightParams& W, float cut, float d2_stop, LcParams* out) {
+static void lc_screen_table(const VgsWeightParams& W, float cut, float d2_stop, float* ctab, float* ctab_scale) {
   const float thr0 = vm_cut_threshold(1.0f, cut, 1) * (1.0f - 2.0e-6f);
   const bool bounded = d2_stop < __builtin_huge_valf();
   const double width = bounded ? (double)d2_stop / LC_TBINS : 0.0;
-  out->ctab_scale = bounded ? (float)(1.0 / width) : 0.0f;   // unbounded: every pair reads bin 0 (distance 0)
+  *ctab_scale = bounded ? (float)(1.0 / width) : 0.0f;   // unbounded: every pair reads bin 0 (distance 0)
   for (int k = 0; k < LC_TBINS; ++k) {
     // d2 * scale >= k in float => d2 >= k * width up to rounding: a relative 1e-6 below
     const float dk = vm_sqrt((float)((double)k * width * (1.0 - 1.0e-6)));
@@ -571,7 +574,7 @@ static void lc_screen_table(const VgsWeightParams& W, float cut, float d2_stop, 
       ck = (float)(cos((double)hi + 2.0e-6) - 1.0e-6);
       if (!((double)hi + 2.0e-6 < 3.14159)) ck = -2.0f;
     }
-    out->ctab[k] = ck;
+    ctab[k] = ck;
   }
 }
 
@@ -612,6 +615,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   if (vgs_unused_are_inert(c->P) != c->adj_pruned) { c->err = "adjacency rows do not match the current sigma/cut parameters"; return VGS_E_STATE; }
   LP.prune_unused = 0;
   LP.d2_stop = __builtin_huge_valf();   // set below, once the neighbourhood's reach is known
+  LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
   VGS_HIP_TRY(c, c->work_ids.ensure((8 + LW_HO_BINS) * (size_t)U + 16));
@@ -629,7 +633,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 5 class counters (words 8-10)
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);        // lengths of the LW_HO_BINS lists (words 14-15)
   unsigned int* d_ng = (unsigned int*)(c->counters.p + 11) + 1;    // word 11, upper half
-  unsigned int* d_nf2 = (unsigned int*)(c->counters.p + 12);
+  unsigned int* d_nf2 = (unsigned int*)(c->counters.p + 12);       // sent on by the dense kernels: word 12, small | large
+  unsigned int* d_ng2 = d_nf2 + 1;
+  uint32_t* ids_g2 = c->work_ids.p + 4 * U;   // sent on by the large dense kernel
   static_assert(LW_HO_BINS == 4, "four 32-bit list lengths in counter words 14-15");
 
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
@@ -666,7 +672,18 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     WP.d2_all = reach * reach * 1.01f;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, WP.d2_all);
-    lc_screen_table(LP.W, LP.cut, LP.d2_stop, &LP);
+    // the screening table depends on the parameters only: rebuilt and sent when they change
+    const float key[8] = {LP.W.inv_sig_p, LP.W.inv_sig_n, LP.W.inv_sig_w2, LP.cut, LP.d2_stop, (float)LP.W.svgs, 0.f, 0.f};
+    VGS_HIP_TRY(c, c->lc_ctab.ensure(LC_TBINS));
+    if (!c->lc_ctab_valid || memcmp(key, c->lc_ctab_key, sizeof(key)) != 0) {
+      float tab[LC_TBINS];
+      lc_screen_table(LP.W, LP.cut, LP.d2_stop, tab, &c->lc_ctab_scale);
+      VGS_HIP_TRY(c, hipMemcpyAsync(c->lc_ctab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c->stream));
+      VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));   // tab is on the stack
+      memcpy(c->lc_ctab_key, key, sizeof(key));
+      c->lc_ctab_valid = true;
+    }
+    LP.ctab = c->lc_ctab.p; LP.ctab_scale = c->lc_ctab_scale;
     WP.lc = LP;
   }
   WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
@@ -749,7 +766,12 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
     vgs_status st = VGS_OK;
     const unsigned int ncd = nabc[2] + nabc[3];
-    if (ncd > 0) st = launch_block(ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
+    if (ncd > 0) {
+      if (!dense) st = launch_block(ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
+      else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
+        hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(ncd < 4 * GRID_G ? ncd : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
+                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p);
+    }
     c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
@@ -785,8 +807,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (!dense) {
       st = launch_block(ids_f, grid_f, true, d_nf, 0);
     } else if (grid_f > 0) {
-      hipLaunchKernelGGL(k_localcut_dense, dim3(grid_f), dim3(LC_TB), 0, c->stream3, ids_f, (int)U, 0, d_nf, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p);
+      hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p);
     }
     c->stream = main_stream;
     if (st != VGS_OK) return st;
@@ -828,7 +850,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, reach * reach * 1.01f);
-    lc_screen_table(LP.W, LP.cut, LP.d2_stop, &LP);
+    LP.ctab = c->lc_ctab.p; LP.ctab_scale = c->lc_ctab_scale;   // built by vgs_stage_localcut for these parameters
   }
   constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
@@ -862,32 +884,29 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   const unsigned int nf = nfg[0] + nfg[1];
   if (n_deferred) *n_deferred = (unsigned int)(hc[13] & 0xffffffffull);
   const bool dense = !getenv("VGS_NO_DENSE");
-  unsigned int nf2 = (unsigned int)(hc[12] & 0xffffffffull);   // sent on by the dense kernel
-  if (nfg[0] > grid_f || nfg[1] > GRID_G || nf2 > 0) {
-    // lists longer than their fixed grids, lists the dense kernel could not hold (neither seen on the benchmark scenes):
-    // finish the rest
+  const unsigned int nf2 = (unsigned int)(hc[12] & 0xffffffffull), ng2 = (unsigned int)(hc[12] >> 32);   // sent on by the dense kernels
+  {
     vgs_status st = VGS_OK;
-    uint32_t* ids_f2 = c->work_ids.p + 7 * U;
-    if (nfg[0] > grid_f) {
-      if (dense) {
-        unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);
-        hipLaunchKernelGGL(k_localcut_dense, dim3(nfg[0] - grid_f), dim3(LC_TB), 0, c->stream, ids_f, (int)U, (int)grid_f, d_nf, c->adj_key.p, c->adj_cnt.p,
-                           c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, (unsigned int*)(c->counters.p + 12), c->evals.p);
-        VGS_READBACK(c, hc, cnt, sizeof(hc));
-        nf2 = (unsigned int)(hc[12] & 0xffffffffull);
-      } else {
-        st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true);
-      }
+    bool more = false;
+    if (dense) {
+      // the dense kernels stride over their whole lists; what they could not hold (a list overflowed, more than 512
+      // neighbours) is finished by the general kernel here
+      if (nf2 > 0) { st = launch_rest(c->work_ids.p + 7 * U, nf2, true); more = true; }
+      if (st == VGS_OK && ng2 > 0) { st = launch_rest(c->work_ids.p + 4 * U, ng2, false); more = true; }
+    } else {
+      // diagnostics path: lists longer than the general kernel's fixed grids
+      if (nfg[0] > grid_f) { st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true); more = true; }
+      if (st == VGS_OK && nfg[1] > GRID_G) { st = launch_rest(ids_g + GRID_G, nfg[1] - GRID_G, false); more = true; }
     }
-    if (st == VGS_OK && nf2 > 0) st = launch_rest(ids_f2, nf2, true);
-    if (st == VGS_OK && nfg[1] > GRID_G) st = launch_rest(ids_g + GRID_G, nfg[1] - GRID_G, false);
     if (st != VGS_OK) return st;
-    VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-    VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (more) {
+      VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+      VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+      VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2;
+  c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
   c->lc_diag[4] = (int64_t)nfg[1]; c->lc_diag[5] = (int64_t)h[1]; c->lc_diag[6] = (int64_t)(hc[13] & 0xffffffffull); c->lc_diag[7] = (int64_t)h[0];
   VGS_HIP_TRY(c, hipGetLastError());
   float kms = 0.f;

@@ -1,5 +1,5 @@
 // localcut_dense.hpp -- the local cut of the voxels the one-wavefront kernel hands over: ONE WORKGROUP PER VOXEL, every
-// pair examined once.  Included by localcut.hip behind localcut_wave.hpp (LcParams, wave_sync, LC_TB from there).
+// pair examined once.  Included by localcut.hip behind localcut_wave.hpp (LcParams, wave_sync, TB from there).
 //
 // Who gets here: neighbourhoods in clutter (vegetation, edges of scan shadows).  No segment forms early and freezes, so the
 // lazy schedule of localcut_wave.hpp ends up looking at almost every pair, shell after shell, and gives up.  The plain order
@@ -8,7 +8,7 @@
 //     banks), so no pair costs an L2 round trip;
 //   * pass 1 puts every pair through the proximity + angle bound (vm_weight_bound_da) and queues the survivors, pass 2
 //     evaluates the queue on full wavefronts and keeps the edges heavier than a singleton's threshold (fact S of
-//     localcut_wave.hpp); the pairs are taken in blocks of DN_QCAP so that the queue cannot overflow;
+//     localcut_wave.hpp); the pairs are taken in blocks of QCAP so that the queue cannot overflow;
 //   * the sequential merge is the claim scheme of the one-wavefront kernel (all edges of a 64-edge step that touch no
 //     segment of an earlier undecided edge act at once), and it stops as soon as the voxel's own segment is frozen (fact F);
 //   * phase B (pairs between non-singleton segments still below the singleton threshold) only when the voxel's segment
@@ -17,9 +17,10 @@
 #ifndef LOCALCUT_DENSE_HPP_
 #define LOCALCUT_DENSE_HPP_
 
-#define DN_MAXM 128     // the one-wavefront classes end here
-#define DN_LCAP 2048    // edges heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it)
-#define DN_QCAP 2048    // pairs per block of pass 1 = queue slots (16-bit pair ids)
+// Two instantiations: <128, 2048, 2048, 256> for the one-wavefront classes (30 KB of LDS, five voxels per CU) and
+// <512, 4096, 2048, 512> for the hand-overs of the classes above (78 KB, two per CU).  MAXM neighbours at most; LCAP edges
+// heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it); QCAP pairs per block of
+// pass 1 = queue slots; TB threads.  The grid is fixed and strides over the hand-over list, whose length is on the device.
 #define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
 #define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
 
@@ -32,37 +33,41 @@ __device__ unsigned long long g_dn_prof[16];
 #define DNP_ACC(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __restrict__ work, int work_stride, int offset, const unsigned int* __restrict__ n_work_dev,
+template <int MAXM, int LCAP, int QCAP, int TB>
+__global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(const uint32_t* __restrict__ work, int work_stride, int n_lists, const unsigned int* __restrict__ n_work_dev,
                                                           const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                           int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                           uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                           uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
                                                           uint32_t* __restrict__ evals_out) {
-  __shared__ uint64_t lk[DN_LCAP];            // weight bits << 32 | ~pair id: one compare orders (w desc, pair asc)
-  __shared__ uint16_t queue[DN_QCAP];         // pair ids that passed the bound
-  static_assert(DN_NBIN * 4 <= DN_QCAP * 2, "the histogram lives in the queue");
-  __shared__ uint32_t rec[DN_NF][DN_MAXM];    // neighbour records, one array per field
-  __shared__ float thr[DN_MAXM];
-  __shared__ uint32_t claim[DN_MAXM];
-  __shared__ uint8_t seg[DN_MAXM], rep[DN_MAXM], ssz[DN_MAXM], alist[DN_MAXM];   // ssz: 128 is the largest size
+  constexpr bool SMALL = MAXM <= 255;   // vertex indices and segment sizes fit a byte, pair ids 16 bits
+  typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;
+  typedef typename std::conditional<SMALL, uint16_t, uint32_t>::type q_t;
+  constexpr int PSH = SMALL ? 8 : 16;   // pair id = (a << PSH) | b, a < b
+  constexpr uint32_t PMASK = (1u << PSH) - 1u;
+  constexpr uint32_t PCOMP = SMALL ? 0xffffu : 0xffffffffu;
+  __shared__ uint64_t lk[LCAP];               // weight bits << 32 | ~pair id: one compare orders (w desc, pair asc)
+  __shared__ q_t queue[QCAP];                 // pair ids that passed the bound
+  static_assert(DN_NBIN * 4 <= QCAP * sizeof(q_t), "the histogram lives in the queue");
+  __shared__ uint32_t rec[DN_NF][MAXM];       // neighbour records, one array per field
+  __shared__ float thr[MAXM];
+  __shared__ uint32_t claim[MAXM];
+  __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM], alist[MAXM];
   __shared__ int s_nq, s_nlist, s_flag, s_nb;
   __shared__ float s_ctab[LC_TBINS];          // LcParams::ctab where a lane can index it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // fixed grid, list lengths on the device: LW_HO_BINS lists (largest neighbourhoods first) taken one behind the other;
-  // workgroups beyond their end leave at once (offset = position of this launch in that order)
-  unsigned int wpos = (unsigned int)offset + blockIdx.x;
-  int wbin = 0;
-  while (wbin < LW_HO_BINS && wpos >= n_work_dev[wbin]) { wpos -= n_work_dev[wbin]; ++wbin; }
-  if (wbin == LW_HO_BINS) return;
-  const uint32_t u = work[(size_t)wbin * work_stride + wpos];
-  const int m = (int)adj_cnt[u];
-  const uint64_t* row = adj_key + (int64_t)u * adj_stride;
-  uint8_t* crow = conn + (int64_t)u * adj_stride;
   const VgsWeightParams& W = P.W;
   const float cut = P.cut;
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (tid < LC_TBINS) s_ctab[tid] = P.ctab[tid];
+  // n_lists hand-over lists (largest neighbourhoods first), work_stride apart, taken one behind the other; their lengths
+  // are on the device and the fixed grid strides over them
+  auto process = [&](const uint32_t u) {
+  const int m = __builtin_amdgcn_readfirstlane((int)adj_cnt[u]);
+  const uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  uint8_t* crow = conn + (int64_t)u * adj_stride;
   DNP_T0();
 #ifdef VGS_PROF
   const long long t_begin = clock64();
@@ -72,10 +77,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
   auto hand_on = [&]() {   // all threads
     if (tid == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; atomicAdd(&counters[7], 1ull); }
   };
-  if (m > DN_MAXM) { hand_on(); return; }   // not a one-wavefront voxel (cannot happen from the hand-over list)
+  if (m > MAXM) { hand_on(); return; }   // not a one-wavefront voxel (cannot happen from the hand-over list)
 
   // ---- records: 4 lanes per record read its four 16-byte quads, each word goes to its field array ----
-  for (int e = tid; e < m * 4; e += LC_TB) {
+  for (int e = tid; e < m * 4; e += TB) {
     const int v = e >> 2, qd = e & 3;
     const uint4 x = ((const uint4*)node)[(size_t)(uint32_t)row[v] * 4 + qd];
     const int f0 = qd * 4;
@@ -84,12 +89,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     if (f0 + 2 < DN_NF) rec[f0 + 2][v] = x.z;
     if (f0 + 3 < DN_NF) rec[f0 + 3][v] = x.w;
   }
-  for (int c = tid; c < m; c += LC_TB) { seg[c] = (uint8_t)c; rep[c] = (uint8_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu; }
-  if (tid == 0) {
-    s_nq = 0; s_nlist = 0; s_flag = 0; s_nb = 0;
-#pragma unroll
-    for (int k = 0; k < LC_TBINS; ++k) s_ctab[k] = P.ctab[k];
-  }
+  for (int c = tid; c < m; c += TB) { seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu; }
+  if (tid == 0) { s_nq = 0; s_nlist = 0; s_flag = 0; s_nb = 0; }
   __syncthreads();
   auto load = [&](int v) -> NodeRec {
     NodeRec r;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     // comparators at distance < 128 stay inside a 128-key chunk: a wavefront runs them for its chunks back to back with
     // no workgroup barrier in between (64 comparators per stage = one per lane)
     auto chunk_tail = [&](int first_sl) {   // strides 2^first_sl .. 1 in every chunk
-      for (int ch = wave; ch < (np >> 7); ch += LC_TB / 64) {
+      for (int ch = wave; ch < (np >> 7); ch += TB / 64) {
         if ((ch << 7) >= cnt) break;
         for (int sl = first_sl; sl >= 0; --sl) {
           const int lo = (ch << 7) + (((lane >> sl) << (sl + 1)) | (lane & ((1 << sl) - 1)));
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     };
     __syncthreads();
     // sizes 2 .. 128: entirely chunk-local
-    for (int ch = wave; ch < (np >> 7); ch += LC_TB / 64) {
+    for (int ch = wave; ch < (np >> 7); ch += TB / 64) {
       if ((ch << 7) >= cnt) break;
       for (int size = 2, sbit = 1; size <= 128; size <<= 1, ++sbit) {
         {
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     }
     __syncthreads();
     for (int size = 256, sbit = 8; size <= np; size <<= 1, ++sbit) {
-      for (int t = tid; t < (np >> 1); t += LC_TB) {
+      for (int t = tid; t < (np >> 1); t += TB) {
         const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
         cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
       }
       __syncthreads();
       for (int sl = sbit - 2; sl >= 7; --sl) {
         const int strd = 1 << sl;
-        for (int t = tid; t < (np >> 1); t += LC_TB) {
+        for (int t = tid; t < (np >> 1); t += TB) {
           const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
           cmpx(lo, lo + strd);
         }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
       int last_own = -1;
       for (int base = 0; base < cnt; base += 64) {
         const int e = base + lane;
-        const bool own = e < cnt && ((0xffffu - (uint32_t)(lk[e] & 0xffffu)) >> 8) == 0u;
+        const bool own = e < cnt && ((PCOMP - (uint32_t)lk[e]) >> PSH) == 0u;
         const unsigned long long mk = __ballot(own);
         if (mk != 0ull) last_own = base + 63 - __builtin_clzll(mk);
       }
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
         if (e < cnt) {
           const uint64_t key = lk[e];
           w = vm_from_bits((uint32_t)(key >> 32));
-          const uint32_t pid = 0xffffu - (uint32_t)(key & 0xffffu);
-          sa = seg[pid >> 8];
-          sb = seg[pid & 0xffu];
+          const uint32_t pid = PCOMP - (uint32_t)key;
+          sa = seg[pid >> PSH];
+          sb = seg[pid & PMASK];
           alive = true;
         }
         while (true) {
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           if (pass) {
             const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
             const int gone = (ta >= tb) ? sb : sa;
-            rep[gone] = (uint8_t)keep;
+            rep[gone] = (idx_t)keep;
             thr[keep] = vm_cut_threshold(w, cut, nsz);   // seg_int = w (VS:1988)
-            ssz[keep] = (uint8_t)nsz;
+            ssz[keep] = (idx_t)nsz;
             ssz[gone] = 0;
           }
           merges += __popcll(__ballot(pass));
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
       for (int c = lane; c < m; c += 64) {
         int s = seg[c];
         while (rep[s] != s) s = rep[s];
-        seg[c] = (uint8_t)s;
+        seg[c] = (idx_t)s;
       }
     }
     __syncthreads();
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
   if (!done) {
     bool any = false;
     const NodeRec A = load(0);
-    for (int x = 1 + tid; x < m; x += LC_TB) {
+    for (int x = 1 + tid; x < m; x += TB) {
       const NodeRec B = load(x);
       ++my_pairs;
       if (!(vm_weight_bound_da(A, B, W) <= thr0)) any = any || (vm_pair_weight(A, B, W) > thr0);
@@ -273,8 +274,8 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
   if (!done) {
     // ---- 2. phase A: every edge heavier than thr0 ----
     const uint32_t Pall = (uint32_t)(m * (m - 1) / 2);
-    for (uint32_t base = 0; base < Pall; base += DN_QCAP) {
-      for (uint32_t p = base + (uint32_t)tid; p < base + DN_QCAP; p += LC_TB) {   // same trip count for every thread of a wavefront
+    for (uint32_t base = 0; base < Pall; base += QCAP) {
+      for (uint32_t p = base + (uint32_t)tid; p < base + QCAP; p += TB) {   // same trip count for every thread of a wavefront
         bool keep = false;
         int a = 0, b = 0;
         if (p < Pall) {
@@ -286,12 +287,14 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           const uint32_t both = A.flags & B.flags;
           if ((both & VGS_F_POS) != 0u && d2 >= P.d2_stop) {
             keep = false;   // proximity alone: w <= bound(d2) <= bound(d2_stop) <= thr0
+#ifndef DN_NO_TABLE
           } else if ((both & (VGS_F_POS | VGS_F_NRM)) == (VGS_F_POS | VGS_F_NRM) && d2 > 0.0f) {
             // the proximity + angle bound read from a table by distance (LcParams::ctab): a tenth of its cost
             int k = (int)(d2 * P.ctab_scale);
             k = k > LC_TBINS - 1 ? LC_TBINS - 1 : k;
             const float dot = vm_dot3(A.n, B.n);
             keep = !(dot <= s_ctab[k] && dot >= -1.0f);
+#endif
           } else {
             keep = !(vm_weight_bound_da(A, B, W) <= thr0);
           }
@@ -301,27 +304,27 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           int qb = 0;
           if (lane == 0) qb = atomicAdd(&s_nq, __popcll(mk));
           qb = __shfl(qb, 0, 64);
-          if (keep) queue[qb + __popcll(mk & lt_mask)] = (uint16_t)(((uint32_t)a << 8) | (uint32_t)b);
+          if (keep) queue[qb + __popcll(mk & lt_mask)] = (q_t)(((uint32_t)a << PSH) | (uint32_t)b);
         }
       }
       __syncthreads();
       const int nq = s_nq;
-      for (int e = tid; e < nq; e += LC_TB) {
+      for (int e = tid; e < nq; e += TB) {
         const uint32_t pid = queue[e];
-        const float w = vm_pair_weight(load((int)(pid >> 8)), load((int)(pid & 0xffu)), W);
+        const float w = vm_pair_weight(load((int)(pid >> PSH)), load((int)(pid & PMASK)), W);
         if (w > thr0) {
           const int pos = atomicAdd(&s_nlist, 1);
-          if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - pid);
+          if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
         }
       }
       __syncthreads();
       if (tid == 0) s_nq = 0;
-      if (s_nlist > DN_LCAP) break;   // uniform: read after the barrier, written before it
+      if (s_nlist > LCAP) break;   // uniform: read after the barrier, written before it
       __syncthreads();
     }
     DNP_ACC(2);
     const int nlA = s_nlist;
-    if (nlA > DN_LCAP) { hand_on(); handed = true; }
+    if (nlA > LCAP) { hand_on(); handed = true; }
     else {
       sort_list(nlA);
       DNP_ACC(3);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
             const int v = base + lane;
             const bool own = v < m && seg[v] == s0;
             const unsigned long long mk = __ballot(own);
-            if (own) alist[n0 + __popcll(mk & lt_mask)] = (uint8_t)v;
+            if (own) alist[n0 + __popcll(mk & lt_mask)] = (idx_t)v;
             n0 += __popcll(mk);
           }
           int nb = n0;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
             bool act = false;
             if (v < m) { const int sv = seg[v]; act = sv != s0 && (ssz[sv] >= 2) && (thr[sv] < thr0); }
             const unsigned long long mk = __ballot(act);
-            if (act) alist[nb + __popcll(mk & lt_mask)] = (uint8_t)v;
+            if (act) alist[nb + __popcll(mk & lt_mask)] = (idx_t)v;
             nb += __popcll(mk);
           }
           if (lane == 0) { s_nb = nb; s_nq = n0; }
@@ -365,7 +368,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           const float L = thr[s0];
           const int no = nb - n0;
           bool hit = false;
-          for (int idx = tid; idx < n0 * no; idx += LC_TB) {
+#ifdef DN_NO_PRETEST
+          hit = true;
+#endif
+          for (int idx = tid; idx < n0 * no && !hit; idx += TB) {
             const int x = alist[idx / no], y = alist[n0 + idx % no];
             const int a = x < y ? x : y, b = x < y ? y : x;
             const NodeRec A = load(a), B = load(b);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
 #endif
         if (reachable) {
         const uint32_t Pb = (uint32_t)(nb * (nb - 1) / 2);
-        for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+        for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
           int ia, ib;
           decode(p, nb, Pb, ia, ib);
           const int xa = alist[ia], xb = alist[ib];
@@ -394,14 +400,14 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
             ++my_pairs;
             if (w <= thr0) {   // heavier edges were examined in phase A; NaN compares false
               const int pos = atomicAdd(&s_nlist, 1);
-              if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - (((uint32_t)a << 8) | (uint32_t)b));
+              if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - (((uint32_t)a << PSH) | (uint32_t)b));
             }
           }
         }
         __syncthreads();
         const int nlB = s_nlist;
         DNP_ACC(5);
-        if (nlB <= DN_LCAP) {
+        if (nlB <= LCAP) {
           sort_list(nlB);
           DNP_ACC(6);
           merge_list(nlB);
@@ -419,9 +425,9 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
           uint32_t* hist = (uint32_t*)queue;
           const float scale = (float)DN_NBIN / thr0;
           auto bin_of = [&](float w) -> int { const int bb = (int)(w * scale); return bb < 0 ? 0 : (bb > DN_NBIN - 1 ? DN_NBIN - 1 : bb); };
-          for (int k = tid; k < DN_NBIN; k += LC_TB) hist[k] = 0u;
+          for (int k = tid; k < DN_NBIN; k += TB) hist[k] = 0u;
           __syncthreads();
-          for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+          for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
             int ia, ib;
             decode(p, nb, Pb, ia, ib);
             const int xa = alist[ia], xb = alist[ib];
@@ -438,14 +444,14 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
             if (tid == 0) {
               unsigned int acc = 0;
               int lo = top;
-              while (lo > 0 && acc + hist[lo - 1] <= (unsigned int)DN_LCAP) { --lo; acc += hist[lo]; }
+              while (lo > 0 && acc + hist[lo - 1] <= (unsigned int)LCAP) { --lo; acc += hist[lo]; }
               s_nb = lo;
               s_nlist = 0;
             }
             __syncthreads();
             const int lo = s_nb;
             if (lo == top) { hand_on(); handed = true; break; }   // one bin alone overflows the list: degenerate ties
-            for (uint32_t p = (uint32_t)tid; p < Pb; p += LC_TB) {
+            for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
               int ia, ib;
               decode(p, nb, Pb, ia, ib);
               const int xa = alist[ia], xb = alist[ib];
@@ -457,13 +463,13 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
                   const int bb = bin_of(w);
                   if (bb >= lo && bb < top) {
                     const int pos = atomicAdd(&s_nlist, 1);
-                    if (pos < DN_LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(0xffffu - (((uint32_t)a << 8) | (uint32_t)b));
+                    if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - (((uint32_t)a << PSH) | (uint32_t)b));
                   }
                 }
               }
             }
             __syncthreads();
-            const int nband = s_nlist < DN_LCAP ? s_nlist : DN_LCAP;   // <= the histogram's count of these bins
+            const int nband = s_nlist < LCAP ? s_nlist : LCAP;   // <= the histogram's count of these bins
             sort_list(nband);
             merge_list(nband);
             if (lo == 0) break;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
   // ---- result: the segment of the voxel itself, the whole row (nobody zeroes the table first) ----
   {
     const int s0 = seg[0];
-    for (int c = tid; c < m; c += LC_TB) crow[c] = (seg[c] == s0) ? 1 : 0;
+    for (int c = tid; c < m; c += TB) crow[c] = (seg[c] == s0) ? 1 : 0;
   }
   for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
   if (tid == 0) evals_out[u] = 0;
@@ -497,9 +503,18 @@ __global__ __launch_bounds__(LC_TB) void k_localcut_dense(const uint32_t* __rest
     atomicMax(&g_dn_prof[14], tt);
     atomicMax(&g_dn_prof[9], (unsigned long long)(wall_clock64() - w_begin));
     if (tt > 400000ull) atomicAdd(&g_dn_prof[15], 1ull);
-    if (tt > 800000ull) atomicAdd(&g_dn_prof[8], 1ull << 32);
   }
 #endif
+  };   // process
+
+  for (unsigned int wi = blockIdx.x; ; wi += gridDim.x) {
+    unsigned int wpos = wi;
+    int wbin = 0;
+    while (wbin < n_lists && wpos >= n_work_dev[wbin]) { wpos -= n_work_dev[wbin]; ++wbin; }
+    if (wbin == n_lists) break;
+    process((uint32_t)__builtin_amdgcn_readfirstlane((int)work[(size_t)wbin * work_stride + wpos]));   // uniform, and the compiler should know
+    __syncthreads();   // the next voxel reuses every array
+  }
 }
 
 #endif

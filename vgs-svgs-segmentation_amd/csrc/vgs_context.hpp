@@ -151,6 +151,9 @@ struct vgs_ctx {
   DevBuf<uint32_t> lc_defer;
   struct { bool open = false; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; } lc_tail;
   int64_t lc_diag[8] = {0};   // vgs_get_schedule_counters
+  DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
+  float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;
+  bool lc_ctab_valid = false;
   DevBuf<uint32_t> csize;      // per voxel: list length after crossValidation (0 for unused)
   DevBuf<int32_t> attach;      // per voxel: closestCheck target or -1
   DevBuf<uint8_t> cc_flags;    // per voxel: bit0 candidate, bit1 success
