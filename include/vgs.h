@@ -120,8 +120,8 @@ vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
  * path it was built for).  out[0..7]: 0 rounds the lazy schedule gave up in, 1 voxels it handed over because a shell or
  * phase B overflowed its list, 2 handed over to the dense kernel (all causes), 3 sent on by the dense kernel to the
  * general kernel (a list of 2048 edges overflowed), 4 handed over by the classes above 128 neighbours, 5 voxels
- * outside every kernel's limits (result incomplete: vgs_segment reports it), 6 rows crossValidation put off, 7 voxels whose phase B the dense
- * kernel took in bands of descending weight */
+ * outside every kernel's limits (result incomplete: vgs_segment reports it), 6 rows crossValidation put off, 7 voxels for which a dense
+ * kernel took a phase in bands of descending weight (more edges than its list holds) */
 vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
 vgs_status vgs_get_bbox(vgs_ctx* ctx, double* min3_max3);                 /* getBoundingBox (T:56) */
 /* voxel table in leaf order: key 3*V, start V+1 (offsets into point_idx), point_idx N' ; any may be NULL */

@@ -61,6 +61,14 @@ def test_hand_over_from_the_wide_kernels(gpu, oracle, monkeypatch):
 def test_case_reaches_the_class(run):
     c = run["eng"].counts()
     assert run["pred"](c["class_a"], c["class_bc"], c["class_d"]), c
+    sc = run["eng"].schedule_counters()
+    assert sc["outside_limits"] == 0
+    if run["name"] in ("plane_r10", "slab_r10"):
+        # smooth surfaces seen through a ball of ten voxels: more heavy edges than the dense kernels' lists hold, taken in
+        # bands of descending weight (localcut_dense.hpp); the slab's neighbourhoods above 512 go on to the general kernel
+        assert sc["banded"] > 0, sc
+    if run["name"] == "slab_r10":
+        assert sc["dense_sent_on"] > 0 and sc["handed_over_large"] > 0, sc
 
 
 @pytest.mark.parametrize("which", ["connect_cut", "connect_final"])

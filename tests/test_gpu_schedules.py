@@ -4,7 +4,7 @@ candidate search (k_adjacency_masks) are compared with the oracle (DevMath, lean
 their corners -- lists that overflow (NL_NONE), balls wider than the lists' offset map, list ends behind entry 16,
 rows handed to the general adjacency kernel -- and against the same engine with each schedule switched off.  The dense
 hand-over kernel (localcut_dense.hpp) gets the scenes it exists for: fuzzy surfaces where the lazy schedule gives up on nine
-voxels out of ten, neighbourhoods whose heavy edges overflow its list (sent on to the general kernel), and a million-point
+voxels out of ten, neighbourhoods whose heavy edges overflow its list (taken in bands of descending weight), and a million-point
 urban scene that holds the few dozen voxels whose phase B runs in bands."""
 import os
 
@@ -52,11 +52,11 @@ CASES = [
     ("urban_20km_away", "urban", 90_000, dict(voxel_size=0.1, shift=(20000.0, 100.0, 5.0))),
     # the dense hand-over kernel's workloads (schedule_counters says which path a case must reach, REACHES below)
     ("fuzzy_dense", "fuzzy", 120_000, dict(voxel_size=0.1, graph_size=0.4)),
-    ("fuzzy_sent_on", "fuzzy", 120_000, dict(voxel_size=0.1, graph_size=0.45, cut_thred=0.4)),
+    ("fuzzy_banded", "fuzzy", 120_000, dict(voxel_size=0.1, graph_size=0.45, cut_thred=0.4)),
     ("urban_1M_bands", "urban", 1_000_000, dict(voxel_size=0.1)),
 ]
-REACHES = {"fuzzy_dense": ("handed_over",), "fuzzy_sent_on": ("handed_over", "dense_sent_on"), "slab_overflow": ("dense_sent_on", "handed_over_large"),
-           "urban_1M_bands": ("handed_over", "banded_phase_b", "handed_over_large", "cross_put_off"), "urban_loose_cut": ("handed_over",)}
+REACHES = {"fuzzy_dense": ("handed_over",), "fuzzy_banded": ("handed_over", "banded"), "slab_overflow": ("banded", "handed_over_large"),
+           "urban_1M_bands": ("handed_over", "banded", "handed_over_large", "cross_put_off"), "urban_loose_cut": ("handed_over",)}
 
 
 def _scene(gpu, kind, n):

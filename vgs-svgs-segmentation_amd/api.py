@@ -114,7 +114,7 @@ class Engine:
     def schedule_counters(self):
         c = np.zeros(8, dtype=np.int64)
         self._ck(self._L.vgs_get_schedule_counters(self._h, _ptr(c)))
-        names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded_phase_b")
+        names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded")
         return dict(zip(names, (int(x) for x in c)))
 
     def stage_times(self):

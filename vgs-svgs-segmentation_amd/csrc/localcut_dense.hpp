@@ -22,6 +22,7 @@
 // heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it); QCAP pairs per block of
 // pass 1 = queue slots; TB threads.  The grid is fixed and strides over the hand-over list, whose length is on the device.
 #define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
+#define DN_ABIN 256     // histogram bins of the banded phase A, over (thr0, 1]
 #define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
 
 #ifdef VGS_PROF
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
   __shared__ uint32_t claim[MAXM];
   __shared__ idx_t seg[MAXM], rep[MAXM], ssz[MAXM], alist[MAXM];
   __shared__ int s_nq, s_nlist, s_flag, s_nb;
+  __shared__ uint32_t s_hist_a[DN_ABIN];      // banded phase A
   __shared__ float s_ctab[LC_TBINS];          // LcParams::ctab where a lane can index it
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
   // Sequential merge of the sorted list on wavefront 0 (localcut_wave.hpp: merge_list, to the end of the list); stops early
   // when one segment is left or the voxel's own segment can no longer merge.  Ends with a workgroup barrier.
   int merges = 0;   // meaningful on wavefront 0
-  auto merge_list = [&](int cnt) {
+  auto merge_list = [&](int cnt, bool last_list) {   // last_list: no further list of this phase follows
     if (wave == 0) {
       // while the voxel is alone it can only merge through an edge of its own (vertex 0 is the first vertex of its pairs)
       int last_own = -1;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
         int s0 = 0, r;
         while ((r = rep[s0]) != s0) s0 = r;
         if (!(thr[s0] < wn)) break;
-        if (ssz[s0] == 1 && pos > last_own) break;
+        if (last_list && ssz[s0] == 1 && pos > last_own) break;   // (the other segments' states are left unfinished)
       }
       for (int c = lane; c < m; c += 64) {
         int s = seg[c];
@@ -274,62 +276,114 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
   if (!done) {
     // ---- 2. phase A: every edge heavier than thr0 ----
     const uint32_t Pall = (uint32_t)(m * (m - 1) / 2);
-    for (uint32_t base = 0; base < Pall; base += QCAP) {
-      for (uint32_t p = base + (uint32_t)tid; p < base + QCAP; p += TB) {   // same trip count for every thread of a wavefront
-        bool keep = false;
-        int a = 0, b = 0;
-        if (p < Pall) {
-          decode(p, m, Pall, a, b);
-          ++my_pairs;
-          const NodeRec A = load_cn(a), B = load_cn(b);
-          const float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
-          const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const uint32_t both = A.flags & B.flags;
-          if ((both & VGS_F_POS) != 0u && d2 >= P.d2_stop) {
-            keep = false;   // proximity alone: w <= bound(d2) <= bound(d2_stop) <= thr0
-#ifndef DN_NO_TABLE
-          } else if ((both & (VGS_F_POS | VGS_F_NRM)) == (VGS_F_POS | VGS_F_NRM) && d2 > 0.0f) {
-            // the proximity + angle bound read from a table by distance (LcParams::ctab): a tenth of its cost
-            int k = (int)(d2 * P.ctab_scale);
-            k = k > LC_TBINS - 1 ? LC_TBINS - 1 : k;
-            const float dot = vm_dot3(A.n, B.n);
-            keep = !(dot <= s_ctab[k] && dot >= -1.0f);
-#endif
-          } else {
-            keep = !(vm_weight_bound_da(A, B, W) <= thr0);
+    // weights above thr0 in DN_ABIN bins (banded phase A)
+    const float scale_a = (float)DN_ABIN / (1.0f - thr0);
+    auto bin_a = [&](float w) -> int { const int bb = (int)((w - thr0) * scale_a); return bb < 0 ? 0 : (bb > DN_ABIN - 1 ? DN_ABIN - 1 : bb); };
+    // One sweep over all pairs: bound -> queue -> weight, and for the edges heavier than thr0
+    //   mode 0: into the list (stops once the list overflows);  mode 1: count them per weight bin;
+    //   mode 2: into the list if their bin is in [lo, top).
+    auto sweep = [&](int mode, int lo, int top) {
+      if (tid == 0) s_nq = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < Pall; base += QCAP) {
+        for (uint32_t p = base + (uint32_t)tid; p < base + QCAP; p += TB) {   // same trip count for every thread of a wavefront
+          bool keep = false;
+          int a = 0, b = 0;
+          if (p < Pall) {
+            decode(p, m, Pall, a, b);
+            ++my_pairs;
+            const NodeRec A = load_cn(a), B = load_cn(b);
+            const float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const uint32_t both = A.flags & B.flags;
+            if ((both & VGS_F_POS) != 0u && d2 >= P.d2_stop) {
+              keep = false;   // proximity alone: w <= bound(d2) <= bound(d2_stop) <= thr0
+            } else if ((both & (VGS_F_POS | VGS_F_NRM)) == (VGS_F_POS | VGS_F_NRM) && d2 > 0.0f) {
+              // the proximity + angle bound read from a table by distance (LcParams::ctab): a tenth of its cost
+              int k = (int)(d2 * P.ctab_scale);
+              k = k > LC_TBINS - 1 ? LC_TBINS - 1 : k;
+              const float dot = vm_dot3(A.n, B.n);
+              keep = !(dot <= s_ctab[k] && dot >= -1.0f);
+            } else {
+              keep = !(vm_weight_bound_da(A, B, W) <= thr0);
+            }
+          }
+          const unsigned long long mk = __ballot(keep);
+          if (mk != 0ull) {
+            int qb = 0;
+            if (lane == 0) qb = atomicAdd(&s_nq, __popcll(mk));
+            qb = __shfl(qb, 0, 64);
+            if (keep) queue[qb + __popcll(mk & lt_mask)] = (q_t)(((uint32_t)a << PSH) | (uint32_t)b);
           }
         }
-        const unsigned long long mk = __ballot(keep);
-        if (mk != 0ull) {
-          int qb = 0;
-          if (lane == 0) qb = atomicAdd(&s_nq, __popcll(mk));
-          qb = __shfl(qb, 0, 64);
-          if (keep) queue[qb + __popcll(mk & lt_mask)] = (q_t)(((uint32_t)a << PSH) | (uint32_t)b);
+        __syncthreads();
+        const int nq = s_nq;
+        for (int e = tid; e < nq; e += TB) {
+          const uint32_t pid = queue[e];
+          const float w = vm_pair_weight(load((int)(pid >> PSH)), load((int)(pid & PMASK)), W);
+          if (w > thr0) {
+            bool store = mode == 0;
+            if (mode != 0) {
+              const int bb = bin_a(w);
+              if (mode == 1) atomicAdd(&s_hist_a[bb], 1u);
+              else store = bb >= lo && bb < top;
+            }
+            if (store) {
+              const int pos = atomicAdd(&s_nlist, 1);
+              if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
+            }
+          }
         }
+        __syncthreads();
+        if (tid == 0) s_nq = 0;
+        if (mode == 0 && s_nlist > LCAP) break;   // uniform: read after the barrier, written before it
+        __syncthreads();
       }
-      __syncthreads();
-      const int nq = s_nq;
-      for (int e = tid; e < nq; e += TB) {
-        const uint32_t pid = queue[e];
-        const float w = vm_pair_weight(load((int)(pid >> PSH)), load((int)(pid & PMASK)), W);
-        if (w > thr0) {
-          const int pos = atomicAdd(&s_nlist, 1);
-          if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) s_nq = 0;
-      if (s_nlist > LCAP) break;   // uniform: read after the barrier, written before it
-      __syncthreads();
-    }
+    };
+    sweep(0, 0, 0);
     DNP_ACC(2);
     const int nlA = s_nlist;
-    if (nlA > LCAP) { hand_on(); handed = true; }
-    else {
+    __syncthreads();
+    if (nlA <= LCAP) {
       sort_list(nlA);
       DNP_ACC(3);
-      merge_list(nlA);
+      merge_list(nlA, true);
       DNP_ACC(4);
+    } else {
+      // More heavy edges than the list holds (a large neighbourhood on one smooth surface that the lazy schedule could not
+      // finish): bands of descending weight as in phase B below, from a histogram of the weights above thr0.  Each band
+      // costs another sweep, but the voxel's segment usually freezes in the first.
+      if (tid == 0) atomicAdd(&counters[0], 1ull);
+      for (int k = tid; k < DN_ABIN; k += TB) s_hist_a[k] = 0u;
+      __syncthreads();
+      sweep(1, 0, 0);
+      int top = DN_ABIN;
+      while (true) {
+        if (tid == 0) {
+          unsigned int acc = 0;
+          int lo = top;
+          while (lo > 0 && acc + s_hist_a[lo - 1] <= (unsigned int)LCAP) { --lo; acc += s_hist_a[lo]; }
+          s_nb = lo;
+          s_nlist = 0;
+        }
+        __syncthreads();
+        const int lo = s_nb;
+        if (lo == top) { hand_on(); handed = true; break; }   // one bin alone overflows the list
+        sweep(2, lo, top);
+        const int nband = s_nlist < LCAP ? s_nlist : LCAP;
+        __syncthreads();
+        sort_list(nband);
+        merge_list(nband, lo == 0);
+        if (lo == 0) break;
+        top = lo;
+        const float wub = thr0 + ((float)top / scale_a) * 1.0001f + 1.0e-6f;   // every edge left weighs less
+        const int r0 = seg[0];
+        if (!(thr[r0] < wub) || (int)ssz[r0] == m) break;   // frozen above everything that is left (fact F)
+        __syncthreads();
+      }
+      DNP_ACC(4);
+    }
+    if (!handed) {
 #ifdef VGS_PROF
       if (tid == 0) { atomicAdd(&g_dn_prof[10], (unsigned long long)nlA); atomicAdd(&g_dn_prof[11], 1ull); }
 #endif
@@ -368,10 +422,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
           const float L = thr[s0];
           const int no = nb - n0;
           bool hit = false;
-#ifdef DN_NO_PRETEST
-          hit = true;
-#endif
-          for (int idx = tid; idx < n0 * no && !hit; idx += TB) {
+          for (int idx = tid; idx < n0 * no; idx += TB) {
             const int x = alist[idx / no], y = alist[n0 + idx % no];
             const int a = x < y ? x : y, b = x < y ? y : x;
             const NodeRec A = load(a), B = load(b);
@@ -410,7 +461,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
         if (nlB <= LCAP) {
           sort_list(nlB);
           DNP_ACC(6);
-          merge_list(nlB);
+          merge_list(nlB, true);
           DNP_ACC(7);
 #ifdef VGS_PROF
           if (tid == 0) { atomicAdd(&g_dn_prof[12], (unsigned long long)nlB); atomicAdd(&g_dn_prof[13], 1ull); }
@@ -471,7 +522,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
             __syncthreads();
             const int nband = s_nlist < LCAP ? s_nlist : LCAP;   // <= the histogram's count of these bins
             sort_list(nband);
-            merge_list(nband);
+            merge_list(nband, lo == 0);
             if (lo == 0) break;
             top = lo;
             // every pair left has a bin below `top`, so it weighs less than this
