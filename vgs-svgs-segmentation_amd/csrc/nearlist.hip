@@ -30,6 +30,26 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
   const int64_t u0 = grp * NLB_G;
   const int ng = (int)((U - u0 < NLB_G) ? (U - u0) : NLB_G);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  // The reach argument (nearlist.hpp) wants the centroid inside the voxel's cube; float sums of large coordinates can leave
+  // it outside by more than the slack built into d2max: such a voxel gets no list.  Lane g checks voxel g of the group, all
+  // of them at once (one round trip instead of one per voxel).
+  bool cube_lane_ok = true;   // balloted where the lists are closed: by then the loads have long arrived
+  {
+    bool ok = true;
+    if (lane < ng) {
+      const uint32_t vi = used_ids[u0 + lane];
+      const NodeRec& r = node[vi];
+      const uint64_t code = vox_code[vi];
+      const float fx = vm_voxel_center(vm_compact21(code >> 2), res_f, min_x), fy = vm_voxel_center(vm_compact21(code >> 1), res_f, min_y),
+                  fz = vm_voxel_center(vm_compact21(code), res_f, min_z);
+      const float lim = 0.5f * res_f + cube_tol;
+      const float ulp = 1.2e-7f;   // the float centre itself is off by up to half a spacing of its magnitude
+      const bool inside = fabsf(r.c[0] - fx) + fabsf(fx) * ulp <= lim && fabsf(r.c[1] - fy) + fabsf(fy) * ulp <= lim &&
+                          fabsf(r.c[2] - fz) + fabsf(fz) * ulp <= lim;
+      ok = inside || !(r.flags & VGS_F_POS);
+    }
+    cube_lane_ok = ok;
+  }
   int g = 0;
   while (g < ng) {
     // ---- 1. queue the candidates of as many voxels of the group as fit ----
@@ -45,18 +65,6 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
       // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
       if (gtab[u * gstride] == 0xffffu) { if (lane == 0) s_kept[g] = -1; continue; }
       const NodeRec& me = node[i];
-      {
-        // the reach argument (nearlist.hpp) wants the centroid inside the voxel's cube; float sums of large coordinates
-        // can leave it outside by more than the slack built into d2max: such a voxel gets no list
-        const uint64_t code = vox_code[i];
-        const float fx = vm_voxel_center(vm_compact21(code >> 2), res_f, min_x), fy = vm_voxel_center(vm_compact21(code >> 1), res_f, min_y),
-                    fz = vm_voxel_center(vm_compact21(code), res_f, min_z);
-        const float lim = 0.5f * res_f + cube_tol;
-        const float ulp = 1.2e-7f;   // the float centre itself is off by up to half a spacing of its magnitude
-        const bool inside = fabsf(me.c[0] - fx) + fabsf(fx) * ulp <= lim && fabsf(me.c[1] - fy) + fabsf(fy) * ulp <= lim &&
-                            fabsf(me.c[2] - fz) + fabsf(fz) * ulp <= lim;
-        if ((me.flags & VGS_F_POS) && !inside) { if (lane == 0) s_kept[g] = -1; continue; }
-      }
       if (lane == 0) s_kept[g] = 0;
       const int n = (int)adj_cnt[u];
       const uint64_t* row = adj_key + u * adj_stride;
@@ -128,11 +136,12 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
     }
     __syncthreads();
     // ---- 4. counts and end-of-list marks ----
+    const unsigned long long cube_ok = __ballot(cube_lane_ok);
     for (int x = lane; x < (g - g_first) * NL_S; x += 64) {
       const int gg = g_first + x / NL_S, j = x % NL_S;
       const int kept = s_kept[gg];
       if (kept >= 0 && kept <= NL_S && j >= kept) out_dw[(size_t)s_vid[gg] * NL_S + (size_t)j] = make_float2(__builtin_huge_valf(), 0.0f);
-      if (j == 0) out_cnt[s_vid[gg]] = (kept < 0 || kept > NL_S) ? (uint8_t)NL_NONE : (uint8_t)kept;
+      if (j == 0) out_cnt[s_vid[gg]] = (kept < 0 || kept > NL_S || !((cube_ok >> gg) & 1ull)) ? (uint8_t)NL_NONE : (uint8_t)kept;
     }
     __syncthreads();
   }
