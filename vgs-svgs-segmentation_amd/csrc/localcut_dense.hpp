@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
     for (int x = 1 + tid; x < m; x += TB) {
       const NodeRec B = load(x);
       ++my_pairs;
-      if (!(vm_weight_bound_da(A, B, W) <= thr0)) any = any || (vm_pair_weight(A, B, W) > thr0);
+      if (!(vm_weight_bound_da(A, B, W) <= thr0)) any = any || (vm_pair_weight_regs(A, B, W) > thr0);
     }
     if (any) s_flag = 1;
     __syncthreads();
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
         const int nq = s_nq;
         for (int e = tid; e < nq; e += TB) {
           const uint32_t pid = queue[e];
-          const float w = vm_pair_weight(load((int)(pid >> PSH)), load((int)(pid & PMASK)), W);
+          const float w = vm_pair_weight_regs(load((int)(pid >> PSH)), load((int)(pid & PMASK)), W);
           if (w > thr0) {
             bool store = mode == 0;
             if (mode != 0) {
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
             const NodeRec A = load(a), B = load(b);
             ++my_pairs;
             if (!(vm_weight_bound_da(A, B, W) <= L)) {
-              const float w = vm_pair_weight(A, B, W);
+              const float w = vm_pair_weight_regs(A, B, W);
               hit = hit || (w > L && w <= thr0);
             }
           }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
           const int xa = alist[ia], xb = alist[ib];
           const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
           if (seg[a] != seg[b]) {
-            const float w = vm_pair_weight(load(a), load(b), W);
+            const float w = vm_pair_weight_regs(load(a), load(b), W);
             ++my_pairs;
             if (w <= thr0) {   // heavier edges were examined in phase A; NaN compares false
               const int pos = atomicAdd(&s_nlist, 1);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
             const int xa = alist[ia], xb = alist[ib];
           const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
             if (seg[a] != seg[b]) {
-              const float w = vm_pair_weight(load(a), load(b), W);
+              const float w = vm_pair_weight_regs(load(a), load(b), W);
               ++my_pairs;
               if (w <= thr0) atomicAdd(&hist[bin_of(w)], 1u);
             }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
               const int xa = alist[ia], xb = alist[ib];
           const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
               if (seg[a] != seg[b]) {
-                const float w = vm_pair_weight(load(a), load(b), W);
+                const float w = vm_pair_weight_regs(load(a), load(b), W);
                 ++my_pairs;
                 if (w <= thr0) {
                   const int bb = bin_of(w);

@@ -391,7 +391,11 @@ struct VgsWeightParams {
 VGS_HD float vm_dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
 // The five distances S,A,T,E,C (VS:1597-1720; SVGS differences SS:1756-1878).
-VGS_HD void vm_pair_distances(const VgsNode& v1, const VgsNode& v2, int svgs, float* out) {
+// SPLIT: the eigen sum as two loops with constant bounds (same additions in the same order) -- for callers that hold the
+// records in registers, which a loop starting at a run-time index would force into scratch memory; the kernels that read
+// records through pointers keep the single loop (the split costs the one-wavefront local cut 16 bytes of spills per lane).
+template <bool SPLIT>
+VGS_HD void vm_pair_distances_t(const VgsNode& v1, const VgsNode& v2, int svgs, float* out) {
   float dist_space = 100.0f, dist_angle = 100.0f, dist_stair = 100.0f, dist_eigen = 100.0f, dist_convx = 100.0f;
   float d12 = 0.0f;
   float u[3] = {0.0f, 0.0f, 0.0f};
@@ -443,24 +447,32 @@ VGS_HD void vm_pair_distances(const VgsNode& v1, const VgsNode& v2, int svgs, fl
   }
   if (ev) {
     float ec = 0.0f, e1 = 0.0f, e2 = 0.0f;
-    // entries 4..7 (VS) or 0..7 (SS), summed in index order; two loops with constant bounds, so that records held in
-    // registers are never indexed with a run-time value
-    if (svgs) {
-      for (int i = 0; i < 4; ++i) {
+    // entries 4..7 (VS) or 0..7 (SS), summed in index order
+    if (SPLIT) {
+      if (svgs) {
+        for (int i = 0; i < 4; ++i) {
+          ec = ec + v1.f[i] * v2.f[i];
+          e1 = e1 + v1.f[i] * v1.f[i];
+          e2 = e2 + v2.f[i] * v2.f[i];
+        }
+      }
+      for (int i = 4; i < 8; ++i) {
+        ec = ec + v1.f[i] * v2.f[i];
+        e1 = e1 + v1.f[i] * v1.f[i];
+        e2 = e2 + v2.f[i] * v2.f[i];
+      }
+    } else {
+      for (int i = svgs ? 0 : 4; i < 8; ++i) {
         ec = ec + v1.f[i] * v2.f[i];
         e1 = e1 + v1.f[i] * v1.f[i];
         e2 = e2 + v2.f[i] * v2.f[i];
       }
     }
-    for (int i = 4; i < 8; ++i) {
-      ec = ec + v1.f[i] * v2.f[i];
-      e1 = e1 + v1.f[i] * v1.f[i];
-      e2 = e2 + v2.f[i] * v2.f[i];
-    }
     if (e1 != 0.0f && e2 != 0.0f) dist_eigen = 1.0f - ec / (vm_sqrt(e1) * vm_sqrt(e2));
   }
   out[0] = dist_space; out[1] = dist_angle; out[2] = dist_stair; out[3] = dist_eigen; out[4] = dist_convx;
 }
+VGS_HD void vm_pair_distances(const VgsNode& v1, const VgsNode& v2, int svgs, float* out) { vm_pair_distances_t<false>(v1, v2, svgs, out); }
 
 // VS:1736-1737 / SS:1900-1902.  Sigmas enter as reciprocals (computed once in float on the host).
 VGS_HD float vm_distance_weight(const float* d, const VgsWeightParams& P) {
@@ -478,6 +490,12 @@ VGS_HD float vm_distance_weight(const float* d, const VgsWeightParams& P) {
 VGS_HD float vm_pair_weight(const VgsNode& v1, const VgsNode& v2, const VgsWeightParams& P) {
   float d[5];
   vm_pair_distances(v1, v2, P.svgs, d);
+  return vm_distance_weight(d, P);
+}
+// the same value for records held in registers (see vm_pair_distances_t)
+VGS_HD float vm_pair_weight_regs(const VgsNode& v1, const VgsNode& v2, const VgsWeightParams& P) {
+  float d[5];
+  vm_pair_distances_t<true>(v1, v2, P.svgs, d);
   return vm_distance_weight(d, P);
 }
 
