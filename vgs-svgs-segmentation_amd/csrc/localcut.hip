@@ -696,6 +696,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   WP.pending = c->lc_pending.p;
   const bool dense = !getenv("VGS_NO_DENSE");   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
+  WP.near_min_own = getenv("VGS_NEARMINOWN") ? atoi(getenv("VGS_NEARMINOWN")) : 7;
   WP.ho_bins = dense ? LW_HO_BINS : 1;
   WP.ho_stride = (int)U;
   {
@@ -705,6 +706,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     WP.near.cnt = c->nl_cnt.p; WP.near.slot = c->nl_slot.p; WP.near.dw = c->nl_dw.p;
     WP.near.d2max = reach * reach * NL_D2_SLACK;
     WP.near.enabled = c->nl_enabled ? 1 : 0;
+    WP.near.direct = (c->nl_enabled && c->nl_direct) ? 1 : 0;
   }
   // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the
   // device (fixed grid of nw workgroups starting at list position `offset`); otherwise nw is the length.

@@ -67,6 +67,7 @@ struct LwParams {
   int dbg_max_m;    // tests: hand over neighbourhoods larger than this (0 = the kernel's own limit)
   NearLists near;   // per-voxel lists of the heavy pairs within two lattice steps (nearlist.hpp): the first shell walks them
   uint8_t* pending; // per used voxel: set when the voxel is handed over (its connect row is final only after the hand-over kernel)
+  int near_min_own; // multi-wavefront classes: first shells from the near-pair lists only if the vertices' lists hold this many entries on average
   int ho_bins;      // one-wavefront classes: hand-over lists by neighbourhood size (LW_HO_BINS, largest first) or 1
   int ho_stride;    // distance between those lists in the hand-over array (= the number of used voxels)
 };
@@ -130,9 +131,31 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   __shared__ idx_t alist[MAXM];  // vertices whose segment can still merge (ascending)
   __shared__ idx_t minor[MAXM];  // active vertices outside the largest active segment (ascending)
   __shared__ int sh_i[16];       // NW > 1: command and arguments of the current section, its results
-  __shared__ float sh_f[2];
-  enum { SH_CMD = 0, SH_NLIST, SH_NACT, SH_NMIN, SH_BIG, SH_MINOR, SH_FINAL, SH_MERGED, SH_PACT, SH_COUNT, SH_DROPPED, SH_CNT };
-  enum { CMD_QUIT = 0, CMD_ENUM, CMD_EVAL, CMD_SORT };
+  __shared__ float sh_f[4];
+  enum { SH_CMD = 0, SH_NLIST, SH_NACT, SH_NMIN, SH_BIG, SH_MINOR, SH_FINAL, SH_MERGED, SH_PACT, SH_COUNT, SH_DROPPED, SH_CNT, SH_NEARBAD, SH_NEARSUM };
+  enum { CMD_QUIT = 0, CMD_ENUM, CMD_EVAL, CMD_SORT, CMD_NEAR, CMD_STAGE };
+  // Multi-wavefront classes (NEARH): the near-pair lists are read through a HASH of "lattice offset from the voxel -> vertex"
+  // (search balls up to 15 voxels: the direct 31^3 map of the one-wavefront classes would not fit, a 21^3 one was measured
+  // and cost two of five workgroups per CU).  Entry = (packed offset + 1) << 16 | vertex, 0 = empty; linear probing at load
+  // <= 1/2; hlat[v] = v's packed offset, 5 bits per axis (offset + 16).
+  constexpr bool NEARH = !SMALL || NW > 1;
+  // Both live in the centroids' bytes (as the one-wavefront classes' map does): the general enumeration stages the
+  // centroids when it first runs, and the lists are not read after that -- with arrays of its own the class-C workgroup
+  // grew from 31.8 to 36.9 KB, four per CU instead of five, and every scene got 18 % slower.
+  constexpr int HCAP = NEARH ? (MAXM <= 512 ? 1024 : 2048) : 1;
+  static_assert(!NEARH || HCAP * 4 + 2 * MAXM <= CBUF_BYTES, "hash and offsets must fit the centroid buffer");
+  uint32_t* const htab = (uint32_t*)cbuf;
+  uint16_t* const hlat = (uint16_t*)(cbuf + (size_t)HCAP * 4);
+  auto h_slot = [&](uint32_t key15) -> uint32_t { return (key15 * 2654435761u) >> (32 - (HCAP == 1024 ? 10 : 11)); };
+  auto h_find = [&](uint32_t key15) -> int {   // vertex at that offset, -1 if none
+    uint32_t h = h_slot(key15);
+    while (true) {
+      const uint32_t e = htab[h & (HCAP - 1)];
+      if (e == 0u) return -1;
+      if ((e >> 16) == key15 + 1u) return (int)(e & 0xffffu);
+      ++h;
+    }
+  };
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto blk_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_sync(); };
@@ -182,11 +205,20 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   bool cen_ready = true;  // centroids are staged
   uint32_t pad0 = 0;
   if constexpr (NEAR) {
-    near_ok = P.near.enabled != 0;
+    near_ok = P.near.enabled != 0 && P.near.direct != 0;
     if (near_ok) {
       for (int k = lane; k < NMAP_BYTES / 4; k += 64) nmap4[k] = 0xffffffffu;
       pad0 = node[(uint32_t)row[0]].pad;   // vertex 0 is the voxel itself
       wave_sync();
+    }
+  }
+  if constexpr (NEARH) {
+    near_ok = P.near.enabled != 0;
+    if (near_ok) {
+      for (int k = (int)threadIdx.x; k < HCAP; k += 64 * NW) htab[k] = 0u;
+      if (threadIdx.x == 0) { sh_i[SH_NEARBAD] = 0; sh_i[SH_NEARSUM] = 0; }
+      pad0 = node[(uint32_t)row[0]].pad;
+      blk_sync();
     }
   }
   auto stage_centroids = [&]() {
@@ -198,6 +230,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     }
   };
   bool near_bad = false;
+  int near_sum = 0;   // multi-wavefront classes: sum of the vertices' near-list lengths
   uint32_t tid_reg0 = 0u, tid_reg1 = 0u;   // one-wavefront classes: global ids of vertices lane and lane + 64 (MAXM <= 128)
   for (int c = (int)threadIdx.x; c < m; c += 64 * NW) {
     const uint32_t t = (uint32_t)row[c];
@@ -217,6 +250,29 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         near_bad = near_bad || !inb || P.near.cnt[t] == NL_NONE;
       }
     }
+    if constexpr (NEARH) {
+      if (near_ok) {
+        const uint32_t pd = node[t].pad;
+        const int ox = nl_diff10(pd & 1023u, pad0 & 1023u) + 16, oy = nl_diff10((pd >> 10) & 1023u, (pad0 >> 10) & 1023u) + 16,
+                  oz = nl_diff10((pd >> 20) & 1023u, (pad0 >> 20) & 1023u) + 16;
+        const bool inb = (unsigned)ox < 32u && (unsigned)oy < 32u && (unsigned)oz < 32u;   // always: balls end at 15 voxels
+        if (inb) {
+          const uint32_t key15 = (uint32_t)ox | ((uint32_t)oy << 5) | ((uint32_t)oz << 10);
+          hlat[c] = (uint16_t)key15;
+          uint32_t h = h_slot(key15);
+          while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
+        }
+        const int nc = (int)P.near.cnt[t];
+        if (!inb || nc == NL_NONE) sh_i[SH_NEARBAD] = 1;
+        near_sum += nc;
+      }
+    }
+  }
+  if constexpr (NEARH) {
+    if (near_ok) {   // uniform
+      for (int o = 32; o > 0; o >>= 1) near_sum += __shfl_xor(near_sum, o, 64);
+      if (lane == 0) atomicAdd(&sh_i[SH_NEARSUM], near_sum);
+    }
   }
   if constexpr (NEAR) {
     if (near_ok) {
@@ -224,8 +280,18 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       cen_ready = false;
     }
   }
-  if (!near_ok) { if (!cen_ready) wave_sync(); stage_centroids(); cen_ready = true; }
-  blk_sync();
+  if constexpr (NEARH) {
+    blk_sync();
+    // not in clutter: where the vertices have few heavy near pairs the first shells are nearly empty in the lists -- rounds that
+    // cost their bookkeeping and bring no merges (measured on noisy surfaces: +9 %)
+    if (near_ok) near_ok = sh_i[SH_NEARBAD] == 0 && sh_i[SH_NEARSUM] >= P.near_min_own * m;
+    cen_ready = !near_ok;
+    if (!near_ok) { blk_sync(); stage_centroids(); }   // all wavefronts are still here
+    blk_sync();
+  } else {
+    if (!near_ok) { if (!cen_ready) wave_sync(); stage_centroids(); cen_ready = true; }
+    blk_sync();
+  }
 
   LW_ACC(0);  // gather
   if (P.shell0 < 0.0f) return;  // diagnostics: gather-only run
@@ -456,6 +522,58 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     return count;
   };
 
+  // The same for the multi-wavefront classes (a section: all wavefronts, candidates appended through the LDS counter):
+  // four vertices per trip and wavefront, partner vertices found through the hash.
+  auto near_enum_h = [&](int n_list, float cut_lo, float cut_hi, bool merged, float act_level) {
+    auto take = [&](int va, bool act, float2 e, uint32_t sl) -> bool {
+      bool inr = false;
+      uint32_t pid = 0;
+      const bool inside = act && e.x < cut_hi;
+      if (inside && e.x >= cut_lo) {
+        const uint32_t la = hlat[va];
+        const int bx = (int)(la & 31u) + (int)(sl & 15u) - NL_REACH, by = (int)((la >> 5) & 31u) + (int)((sl >> 4) & 15u) - NL_REACH,
+                  bz = (int)((la >> 10) & 31u) + (int)((sl >> 8) & 15u) - NL_REACH;
+        if ((unsigned)bx < 32u && (unsigned)by < 32u && (unsigned)bz < 32u) {
+          const int vb = h_find((uint32_t)bx | ((uint32_t)by << 5) | ((uint32_t)bz << 10));
+          if (vb >= 0 && va < vb) {
+            inr = true;
+            if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+            pid = ((uint32_t)va << PSH) | (uint32_t)vb;
+          }
+        }
+      }
+      const unsigned long long mk = __ballot(inr);
+      int b = 0;
+      if (mk != 0ull && lane == 0) b = atomicAdd(&sh_i[SH_COUNT], __popcll(mk));
+      b = __builtin_amdgcn_readfirstlane(b);
+      if (inr) {
+        const int pos = n_list + b + __popcll(mk & lt_mask);
+        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(e.y) << 32) | (uint64_t)(PCOMP - pid);
+      }
+      return inside;
+    };
+    const int j = lane & 15;
+    for (int base = wave * 4; base < m; base += NW * 4) {
+      const int va = base + (lane >> 4);
+      const bool act = va < m;
+      float2 e = make_float2(0.f, 0.f);
+      uint32_t sl = 0;
+      if (act) { const size_t o = (size_t)(uint32_t)row[va] * NL_S + (size_t)j; e = P.near.dw[o]; sl = P.near.slot[o]; }
+      const bool in = take(va, act, e, sl);
+      unsigned long long more = __ballot(in && j == 15);   // the shell goes on behind entry 15 of a vertex
+      while (more) {
+        const int l0 = __ffsll((long long)more) - 1;
+        more &= more - 1ull;
+        const int va2 = base + (l0 >> 4);
+        const bool a2 = lane < NL_S - 16;
+        float2 e2 = make_float2(0.f, 0.f);
+        uint32_t s2 = 0;
+        if (a2) { const size_t o = (size_t)(uint32_t)row[va2] * NL_S + 16 + (size_t)(lane & 15); e2 = P.near.dw[o]; s2 = P.near.slot[o]; }
+        take(va2, a2, e2, s2);
+      }
+    }
+  };
+
   // ---- wavefronts 1 .. NW-1: serve the sections until wavefront 0 is done ----
   if constexpr (NW > 1) {
     if (wave != 0) {
@@ -468,6 +586,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
                        sh_i[SH_PACT], sh_f[0], sh_f[1]);
         else if (cmd == CMD_EVAL)
           eval_section(sh_i[SH_NLIST], sh_i[SH_CNT]);
+        else if (cmd == CMD_NEAR)
+          near_enum_h(sh_i[SH_NLIST], sh_f[0], sh_f[1], sh_i[SH_MERGED] != 0, sh_f[2]);
+        else if (cmd == CMD_STAGE)
+          stage_centroids();
         else
           sort_section(sh_i[SH_CNT]);
         __syncthreads();
@@ -490,6 +612,22 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       __syncthreads();
       return sh_i[SH_COUNT];
     }
+  };
+  auto run_near = [&](int n_list, float cut_lo, float cut_hi, bool merged, float act_level) -> int {   // NW > 1
+    if (lane == 0) {
+      sh_i[SH_CMD] = CMD_NEAR; sh_i[SH_NLIST] = n_list; sh_i[SH_MERGED] = merged; sh_i[SH_COUNT] = 0;
+      sh_f[0] = cut_lo; sh_f[1] = cut_hi; sh_f[2] = act_level;
+    }
+    __syncthreads();
+    near_enum_h(n_list, cut_lo, cut_hi, merged, act_level);
+    __syncthreads();
+    return sh_i[SH_COUNT];
+  };
+  auto run_stage = [&]() {   // NW > 1: the hash gives way to the centroids
+    if (lane == 0) sh_i[SH_CMD] = CMD_STAGE;
+    __syncthreads();
+    stage_centroids();
+    __syncthreads();
   };
   auto run_eval = [&](int n_list, int count) -> int {
     if constexpr (NW == 1) {
@@ -653,9 +791,15 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int Pact = use_minor ? n_min * n_act : n_act * (n_act - 1) / 2;   // (upper bound of) candidate pairs
       // once every pair between the still-active vertices fits in the list there is no point in further shells
       const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
-      const bool near_round = NEAR && near_ok && !final_round && !(cut_hi > P.near.d2max);   // a shell inside the lists' reach
+      const bool near_round = (NEAR || NEARH) && near_ok && !final_round && !(cut_hi > P.near.d2max);   // a shell inside the lists' reach
       int count;
-      if constexpr (NEAR) {
+      if constexpr (NEARH && NW > 1) {
+        if (near_round) count = run_near(n_list, cut_lo, cut_hi, merges > 0, act_level);
+        else {
+          if (!cen_ready) { run_stage(); cen_ready = true; near_ok = false; }
+          count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
+        }
+      } else if constexpr (NEAR) {
         if (near_round) {
           count = near_enum(n_list, cut_lo, cut_hi, merges > 0, act_level);
         } else {

@@ -153,7 +153,9 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   c->nl_enabled = false;
   if (c->P.method != 2 || !c->adj_pruned || !c->adj_have_gtab || c->U == 0 || getenv("VGS_NO_NEAR")) return VGS_OK;
   const double rr = (double)c->P.graph_size / (double)c->P.voxel_size;
-  if (rr * rr * (1.0 + 1e-4) + 1e-3 >= (double)((NL_BALL + 1) * (NL_BALL + 1))) return VGS_OK;   // some offset reaches NL_BALL + 1 (adjacency.hip: lim2)
+  // some offset reaches NL_BALL + 1 (adjacency.hip: lim2): the one-wavefront classes cannot use the lists then (their offset
+  // map ends at NL_BALL), the multi-wavefront classes look partners up in a hash and still can
+  c->nl_direct = !(rr * rr * (1.0 + 1e-4) + 1e-3 >= (double)((NL_BALL + 1) * (NL_BALL + 1)));
   const int64_t V = c->V, U = c->U;
   VGS_HIP_TRY(c, c->nl_cnt.ensure(V)); VGS_HIP_TRY(c, c->nl_slot.ensure((size_t)V * NL_S));
   VGS_HIP_TRY(c, c->nl_dw.ensure((size_t)V * NL_S));

@@ -32,7 +32,8 @@ struct NearLists {
   const float2* dw;      // [V * NL_S] (squared centroid distance, vm_pair_weight(a, b)), ascending distance; unused entries
                          //            hold (+inf, 0), so a reader needs no count: "d2 < shell radius" ends the list
   float d2max;           // lists are complete for shells up to this squared centroid distance
-  int enabled;
+  int enabled;           // the lists exist
+  int direct;            // the search ball fits the one-wavefront classes' direct offset map (NL_BALL)
 };
 
 // signed difference of two 10-bit lattice coordinates (exact for |difference| < 512)
