@@ -123,6 +123,10 @@ vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
  * outside every kernel's limits (result incomplete: vgs_segment reports it), 6 rows crossValidation put off, 7 voxels for which a dense
  * kernel took a phase in bands of descending weight (more edges than its list holds) */
 vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
+/* Screening table of the dense hand-over kernels for a parameter set (host arithmetic, no context, no GPU; for tests): a
+ * pair of valid positions and normals whose squared centroid distance d2 is >= *d2_stop, or whose dot(n1, n2) lies in
+ * [-1, ctab[min(63, int(d2 * *ctab_scale))]], weighs at most 1 - cut_thred and is not evaluated (csrc/localcut.hip). */
+vgs_status vgs_screen_table(const vgs_params* params, float* d2_stop, float* ctab_scale, float* ctab /* 64 */);
 vgs_status vgs_get_bbox(vgs_ctx* ctx, double* min3_max3);                 /* getBoundingBox (T:56) */
 /* voxel table in leaf order: key 3*V, start V+1 (offsets into point_idx), point_idx N' ; any may be NULL */
 vgs_status vgs_get_voxel_table(vgs_ctx* ctx, uint32_t* key, int32_t* start, int32_t* point_idx);

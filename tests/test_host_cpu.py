@@ -128,6 +128,82 @@ def test_schedule_bounds_dominate_weight(oracle):
             assert ub_d >= w, (w, ub_d)
 
 
+def test_screen_table_never_drops_a_heavy_pair(vgs, oracle):
+    """The dense hand-over kernels (csrc/localcut_dense.hpp) do not evaluate a pair whose centroid distance reaches d2_stop or
+    whose normals' dot product is at or below the table's cosine for its distance bin.  Whatever they drop must weigh at most
+    1 - cut: the table (vgs_screen_table, host arithmetic of csrc/localcut.hip) against the DevMath weight of random pairs,
+    with the kernel's float expressions restated in numpy."""
+    import ctypes as C
+    f32 = np.float32
+    L = vgs._lib.lib()
+    rng = np.random.default_rng(23)
+    sets = [(False, vgs.default_params(2), oracle.vgs_params(math=1)),
+            (False, vgs.default_params(2, voxel_size=0.05, cut_thred=0.6, sig_n=0.5), oracle.vgs_params(math=1, voxel_size=0.05, cut_thred=0.6, sig_n=0.5)),
+            (False, vgs.default_params(2, sig_p=0.05, sig_w=0.7, cut_thred=0.1), oracle.vgs_params(math=1, sig_p=0.05, sig_w=0.7, cut_thred=0.1)),
+            (True, vgs.default_params(3), oracle.svgs_params(math=1))]
+    for svgs, p, P in sets:
+        d2_stop, scale = C.c_float(), C.c_float()
+        tab = np.zeros(64, dtype=np.float32)
+        assert L.vgs_screen_table(C.byref(p), C.byref(d2_stop), C.byref(scale), tab.ctypes.data_as(C.c_void_p)) == 0
+        d2_stop, scale = f32(d2_stop.value), f32(scale.value)
+        thr0 = f32(1.0) - f32(p.cut_thred) / f32(1.0)
+        valid = tab[tab > -2.0]
+        assert (valid[:-1] <= valid[1:]).all() and (valid <= 1.0).all()      # farther apart, smaller angles suffice
+        dropped = kept = 0
+        reach = np.sqrt(min(float(d2_stop), 4.0)) if np.isfinite(d2_stop) else 1.5
+        for _ in range(6000):
+            c1 = (rng.standard_normal(3) * 0.5 + np.array([3.0, -2.0, 1.0])).astype(np.float32)
+            c2 = (c1 + rng.standard_normal(3) * reach * rng.choice([0.1, 0.5, 1.0])).astype(np.float32)
+            n1 = rng.standard_normal(3); n1 /= np.linalg.norm(n1)
+            n2 = n1 + rng.standard_normal(3) * rng.choice([1e-3, 0.05, 0.3, 2.0]); n2 /= np.linalg.norm(n2)
+            a, b = oracle.node16(c1, n1, rng.random(8)), oracle.node16(c2, n2, rng.random(8))
+            if rng.random() < 0.05:
+                b[3:6] = a[3:6]                                            # identical normals: dot may round above 1
+            w, ub_da, _ = oracle.weight_and_bounds(a, b, P, svgs)
+            d = a[0:3] - b[0:3]
+            d2 = f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])
+            pos = bool((a[0:3] != 0).all() and (b[0:3] != 0).all())
+            nrm = bool((a[3:6] != 0).all() and (b[3:6] != 0).all())
+            if pos and d2 >= d2_stop:
+                drop = True
+            elif pos and nrm and d2 > 0:
+                k = min(63, int(f32(d2 * scale)))
+                dot = f32(f32(a[3] * b[3]) + f32(a[4] * b[4])) + f32(a[5] * b[5])
+                drop = bool(dot <= tab[k] and dot >= f32(-1.0))
+            else:
+                drop = bool(ub_da <= thr0)
+            if drop:
+                dropped += 1
+                assert not (w > thr0), (svgs, w, thr0, d2, ub_da)
+            else:
+                kept += 1
+        # at the table's edge: pairs whose dot product straddles the cosine of their bin by a few ulps -- a dropped pair's
+        # float bound (vm_weight_bound_da, which dominates the weight) must already be at or below the threshold
+        for _ in range(3000 if len(valid) else 0):
+            k = int(rng.integers(0, 64))
+            if tab[k] <= -2.0:
+                continue
+            dist = np.sqrt((k + rng.random()) / float(scale))
+            u = rng.standard_normal(3); u /= np.linalg.norm(u)
+            c1 = np.array([3.0, -2.0, 1.0]) + rng.standard_normal(3) * 0.3
+            n1 = rng.standard_normal(3); n1 /= np.linalg.norm(n1)
+            t = np.cross(n1, rng.standard_normal(3)); t /= np.linalg.norm(t)
+            ang = np.arccos(np.clip(float(tab[k]), -1, 1)) + rng.choice([-3e-6, -1e-6, -3e-7, 0.0, 3e-7, 1e-6, 3e-6])
+            n2 = np.cos(ang) * n1 + np.sin(ang) * t
+            a, b = oracle.node16(c1, n1, rng.random(8)), oracle.node16(c1 + dist * u, n2, rng.random(8))
+            w, ub_da, _ = oracle.weight_and_bounds(a, b, P, svgs)
+            d = a[0:3] - b[0:3]
+            d2 = f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])
+            if d2 >= d2_stop or not d2 > 0:
+                continue
+            kk = min(63, int(f32(d2 * scale)))
+            dot = f32(f32(a[3] * b[3]) + f32(a[4] * b[4])) + f32(a[5] * b[5])
+            if dot <= tab[kk] and dot >= f32(-1.0):
+                assert ub_da <= thr0 and not (w > thr0), (svgs, kk, dot, tab[kk], ub_da, thr0, w)
+        assert kept > 300 and (dropped > 500 or len(valid) == 0), (dropped, kept)     # the sample exercises both sides (a loose cut
+        # with wide sigmas has no table: nothing can be proved from distance and angle alone)
+
+
 def _pcl_grow(state, pts, res):
     """PCL OctreePointCloud::adoptBoundingBoxToPoint over pts in order (SURVEY B.1), as k_adopt / OctreeBox::adopt do it.
     state = (min[3], shift[3], depth) of a defined box; returns the new state."""

@@ -587,6 +587,16 @@ static VgsWeightParams make_weight_params(const vgs_params& p) {
   return W;
 }
 
+// include/vgs.h: the screening table of the dense hand-over kernels for a parameter set (host arithmetic only)
+vgs_status vgs_screen_table(const vgs_params* p, float* d2_stop, float* ctab_scale, float* ctab) {
+  if (!p || !d2_stop || !ctab_scale || !ctab) return VGS_E_ARG;
+  const VgsWeightParams W = make_weight_params(*p);
+  const float reach = 2.0f * p->graph_size + 4.0f * p->voxel_size;   // as vgs_stage_localcut: no pair of a neighbourhood is farther apart
+  *d2_stop = lc_d2_stop(W, p->cut_thred, reach * reach * 1.01f);
+  lc_screen_table(W, p->cut_thred, *d2_stop, ctab, ctab_scale);
+  return VGS_OK;
+}
+
 template <int MAXM, int CAP, bool NODES_LDS>
 static size_t lc_smem_bytes() {
   return (size_t)CAP * 8 + (NODES_LDS ? (size_t)MAXM * sizeof(NodeRec) : 0) + (size_t)MAXM * (4 + 4 + 2 + 2 + 2) + 64;
