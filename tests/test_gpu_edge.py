@@ -53,6 +53,23 @@ def test_tiny_clouds(gpu, oracle, n):
     _same(*_both(gpu, oracle, xyz))
 
 
+def test_no_voxel_with_enough_points(gpu, oracle):
+    """A cloud so sparse that no voxel reaches points_min: every stage runs on zero used voxels, and every getter must cope
+    (vgs_get_lists(3) read the re-attachment table of a merge stage that never allocated it: found by tools/fuzz_parity.py)."""
+    xyz = gpu.scenes.urban_scene(21_170, seed=206792296)
+    p = gpu.default_params(2, voxel_size=0.08, cut_thred=0.9)
+    eng = gpu.Engine(p); eng.set_points(xyz); eng.run()
+    c = eng.counts()
+    assert c["used"] == 0 and c["kept"] == 0 and c["clusters"] == c["voxels"] > 0
+    for which in ("adjacency", "connect_cut", "connect_cross", "connect_final"):
+        off, idx = eng.lists(which)
+        assert off[-1] == 0 and idx.size == 0
+    assert (eng.point_labels() == -1).all()
+    root, kept = eng.node_labels()
+    assert (root == np.arange(c["voxels"])).all() and (kept == -1).all()
+    eng.attributes(); eng.voxel_table(); eng.clusters(); eng.schedule_counters()
+
+
 def test_duplicate_points_and_sparse_voxels(gpu, oracle):
     rng = np.random.default_rng(9)
     base = (rng.standard_normal((300, 3)) * np.array([3.0, 3.0, 0.02])).astype(np.float32)

@@ -134,6 +134,28 @@ def test_same_result_with_the_schedule_off(case, gpu, knob):
             os.environ[knob] = old
 
 
+@pytest.mark.parametrize("kind,n,seed,kw", [
+    ("urban", 88_651, 804343104, dict(voxel_size=0.15, graph_size=0.3, cut_thred=0.7, sig_w=1.0, sig_n=0.5, sig_p=0.4)),
+    ("town", 68_733, 1010320390, dict(voxel_size=0.15, graph_size=0.3, cut_thred=0.1, sig_w=2.0, sig_n=0.5, sig_p=0.4)),
+    ("town", 60_000, 7, dict(voxel_size=0.15, graph_size=0.5, cut_thred=0.5, sig_p=0.4)),       # the reference's own ratio, 3.33 voxels
+    ("urban", 60_000, 11, dict(voxel_size=0.1, graph_size=0.18)),                                  # below sqrt(3) voxels: no lists
+])
+def test_near_lists_are_complete_only_inside_the_search_ball(gpu, oracle, kind, n, seed, kw):
+    """Regression (round 2, found by tools/fuzz_parity.py): the near-pair lists are built from the adjacency rows, so they hold
+    the partners inside the search ball only.  With graph_size = 2 voxels the lattice offset (2, 1, 0) is outside the ball while
+    centroids that far apart on the lattice can be one voxel apart; the cut read its first shells from lists it took for
+    complete up to two voxels and missed such pairs.  The reach now follows the ball (nearlist.hip)."""
+    xyz = {"urban": gpu.scenes.urban_scene, "town": gpu.scenes.town_scene}[kind](n, seed=seed)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p); eng.set_points(xyz); eng.run()
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    for which in ("connect_cut", "connect_final"):
+        gs, rs = ragged_sets(*eng.lists(which)), ragged_sets(*ref.lists(which))
+        bad = [v for v in range(len(rs)) if gs[v] != rs[v]]
+        assert not bad, f"{which}: {len(bad)} of {len(rs)} voxels differ, first {bad[:5]}"
+    np.testing.assert_array_equal(eng.point_labels(), ref.labels()[0])
+
+
 def test_labels_stable_across_fresh_engines(gpu):
     """Regression (round 2): k_flatten used to walk with path halving; a late halving store of another thread could leave a
     voxel pointing at an ancestor below its root, and the labels read parent[v] as the root -- about one run in twenty

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised differential test, GPU path against the oracle (DevMath + lean): random scenes, sizes and parameters for a time
+budget; every run compares the connect lists after the local cut and the point labels.  usage: fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "oracle"))
+import numpy as np
+import vgs_svgs_segmentation_amd as v
+import refcpu_py as oracle
+from helpers import oracle_params, ragged_sets
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def fuzzy(n, seed, sigma):
+    r = np.random.default_rng(seed)
+    side = np.sqrt(n / 6000.0)
+    x, y = r.random(n) * side, r.random(n) * side
+    z = 0.3 * np.sin(2.0 * x) * np.cos(1.5 * y) + r.normal(0, sigma, n) + 2.0
+    return np.stack([x + 0.011, y + 0.017, z], axis=1).astype(np.float32)
+
+
+def slab(n, seed, thick):
+    r = np.random.default_rng(seed)
+    side = np.sqrt(n / (2500.0 * max(thick / 0.1, 0.3)))
+    x = r.random(n) * side + 0.013; y = r.random(n) * side + 0.027
+    z = r.random(n) * thick + 0.02 * np.sin(3.0 * x) + 1.0
+    return np.stack([x, y, z], axis=1).astype(np.float32)
+
+
+t_end = time.time() + budget
+runs = bad = 0
+while time.time() < t_end:
+    kind = rng.choice(["urban", "town", "pc", "fuzzy", "slab"])
+    n = int(rng.integers(20_000, 90_000))
+    seed = int(rng.integers(0, 1 << 30))
+    if kind == "urban": xyz = v.scenes.urban_scene(n, seed=seed)
+    elif kind == "town": xyz = v.scenes.town_scene(n, seed=seed)
+    elif kind == "pc": xyz = v.scenes.pc_scene(n, seed=seed)
+    elif kind == "fuzzy": xyz = fuzzy(n, seed, float(rng.choice([0.01, 0.03, 0.06, 0.1])))
+    else: xyz = slab(n, seed, float(rng.choice([0.05, 0.2, 0.35])))
+    kw = dict(voxel_size=float(rng.choice([0.06, 0.08, 0.1, 0.15])), graph_size=float(rng.choice([0.3, 0.4, 0.5, 0.6])),
+              cut_thred=float(rng.choice([0.1, 0.3, 0.5, 0.7, 0.9])), sig_w=float(rng.choice([1.0, 2.0])),
+              sig_n=float(rng.choice([0.2, 0.5])), sig_p=float(rng.choice([0.1, 0.2, 0.4])))
+    if kw["graph_size"] / kw["voxel_size"] > 8.0:
+        kw["graph_size"] = 8.0 * kw["voxel_size"]
+    p = v.default_params(2, **kw)
+    print("start", kind, n, seed, kw, flush=True)
+    try:
+        e = v.Engine(p); e.set_points(xyz); e.run()
+    except v.VgsError as ex:
+        print("skip", kind, n, kw, str(ex)[:80], flush=True)
+        continue
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    ok = True
+    for which in ("connect_cut", "connect_final"):
+        off, idx = e.lists(which); roff, ridx = ref.lists(which)
+        if not (np.array_equal(off, roff) and ragged_sets(off, idx) == ragged_sets(roff, ridx)):
+            ok = False
+            print("MISMATCH", which, kind, n, seed, kw, flush=True)
+    if not np.array_equal(e.point_labels(), ref.labels()[0]):
+        ok = False
+        print("MISMATCH labels", kind, n, seed, kw, flush=True)
+    sc = e.schedule_counters()
+    runs += 1; bad += 0 if ok else 1
+    print(f"run {runs} {kind} n={n} used={e.counts()['used']} handed={sc['handed_over']}/{sc['handed_over_large']} banded={sc['banded']} sent_on={sc['dense_sent_on']} {'ok' if ok else 'BAD'}", flush=True)
+print(f"{runs} runs, {bad} mismatches")
+sys.exit(1 if bad else 0)

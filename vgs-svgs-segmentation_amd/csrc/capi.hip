@@ -477,7 +477,7 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
       if (which == 0 || flag[s]) L[i].push_back((int32_t)(uint32_t)keys[s]);
     }
   }
-  if (which == 3)
+  if (which == 3 && !attach.empty())   // no used voxel: nothing was cut, nothing re-attached
     for (int64_t i = 0; i < V; ++i)
       if (attach[i] >= 0) { L[i].push_back(attach[i]); L[attach[i]].push_back((int32_t)i); }
   int64_t o = 0;

@@ -712,9 +712,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   {
     // Shells up to (NL_REACH voxels)^2 are complete in the near-pair lists; the margin covers centroids that float
     // rounding puts a hair outside their voxel's cube.
-    const float reach = (float)NL_REACH * c->P.voxel_size;
+    const int steps = c->nl_enabled ? c->nl_reach_steps : NL_REACH;
+    const float reach = (float)steps * c->P.voxel_size;
     WP.near.cnt = c->nl_cnt.p; WP.near.slot = c->nl_slot.p; WP.near.dw = c->nl_dw.p;
-    WP.near.d2max = reach * reach * NL_D2_SLACK;
+    // centroids may sit NL_CUBE_TOL voxels outside their cubes: (1 - 2 * NL_CUBE_TOL / steps)^2, rounded down
+    WP.near.d2max = reach * reach * (steps >= 2 ? NL_D2_SLACK : 0.996f);
     WP.near.enabled = c->nl_enabled ? 1 : 0;
     WP.near.direct = (c->nl_enabled && c->nl_direct) ? 1 : 0;
   }

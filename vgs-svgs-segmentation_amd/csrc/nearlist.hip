@@ -156,6 +156,15 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   // some offset reaches NL_BALL + 1 (adjacency.hip: lim2): the one-wavefront classes cannot use the lists then (their offset
   // map ends at NL_BALL), the multi-wavefront classes look partners up in a hash and still can
   c->nl_direct = !(rr * rr * (1.0 + 1e-4) + 1e-3 >= (double)((NL_BALL + 1) * (NL_BALL + 1)));
+  // The builder takes a voxel's candidates from its adjacency row, so the lists hold the partners INSIDE the search ball
+  // only.  They are complete for pairs up to R lattice steps apart (Chebyshev) if every such offset lies strictly inside the
+  // ball: 3 R^2 < (graph_size / voxel_size)^2, with a margin for the float predicate that decides the ball's rim.  (Found by
+  // tools/fuzz_parity.py at graph_size = 2 voxels: the offset (2,1,0) is outside the ball, yet centroids that far apart on
+  // the lattice can be one voxel apart.)  The reference's own defaults (0.5 / 0.15 = 3.33 voxels) give R = 1.
+  int reach_steps = 0;
+  while (reach_steps < NL_REACH && 3.0 * (reach_steps + 1) * (reach_steps + 1) < rr * rr * (1.0 - 1e-3)) ++reach_steps;
+  c->nl_reach_steps = reach_steps;
+  if (reach_steps == 0) return VGS_OK;
   const int64_t V = c->V, U = c->U;
   VGS_HIP_TRY(c, c->nl_cnt.ensure(V)); VGS_HIP_TRY(c, c->nl_slot.ensure((size_t)V * NL_S));
   VGS_HIP_TRY(c, c->nl_dw.ensure((size_t)V * NL_S));

@@ -141,6 +141,7 @@ struct vgs_ctx {
   DevBuf<uint16_t> nl_slot;
   DevBuf<float2> nl_dw;
   bool nl_enabled = false;
+  int nl_reach_steps = 0;     // lattice steps up to which the lists are complete (nearlist.hip)
   bool nl_direct = false;     // the ball fits the direct offset map of the one-wavefront classes
 
   // local cut / merge
