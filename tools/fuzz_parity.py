@@ -10,6 +10,18 @@ import refcpu_py as oracle
 from helpers import oracle_params, ragged_sets
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+METHOD = int(sys.argv[3]) if len(sys.argv) > 3 else 2   # 3: SVGS from a grid labelling (everything behind pcl::SupervoxelClustering)
+
+
+def grid_supervoxels(xyz, seed_size, r):
+    cell = np.floor(xyz.astype(np.float64) / seed_size).astype(np.int64)
+    cell -= cell.min(0)
+    code = (cell[:, 0] * 4096 + cell[:, 1]) * 4096 + cell[:, 2]
+    _, inv = np.unique(code, return_inverse=True)
+    labels = (inv + 1).astype(np.int32)
+    labels[r.random(labels.size) < 0.01] = 0
+    return labels, int(labels.max())
+
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
@@ -45,14 +57,22 @@ while time.time() < t_end:
               sig_n=float(rng.choice([0.2, 0.5])), sig_p=float(rng.choice([0.1, 0.2, 0.4])))
     if kw["graph_size"] / kw["voxel_size"] > 8.0:
         kw["graph_size"] = 8.0 * kw["voxel_size"]
-    p = v.default_params(2, **kw)
+    if METHOD == 3:
+        kw = dict(graph_size=float(rng.choice([0.4, 0.5, 0.8, 1.2])), cut_thred=kw["cut_thred"], sig_w=kw["sig_w"], sig_n=kw["sig_n"], sig_p=kw["sig_p"])
+        seed_size = float(rng.choice([0.15, 0.25, 0.4]))
+    p = v.default_params(METHOD, **kw)
     print("start", kind, n, seed, kw, flush=True)
     try:
-        e = v.Engine(p); e.set_points(xyz); e.run()
+        e = v.Engine(p); e.set_points(xyz)
+        if METHOD == 3:
+            labels, max_label = grid_supervoxels(xyz, seed_size, rng)
+            e.set_supervoxel_labels(labels, max_label); e.svgs_segment()
+        else:
+            e.run()
     except v.VgsError as ex:
         print("skip", kind, n, kw, str(ex)[:80], flush=True)
         continue
-    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    ref = oracle.run_svgs_from_labels(xyz, labels, max_label, oracle_params(oracle, p)) if METHOD == 3 else oracle.run_vgs(xyz, oracle_params(oracle, p))
     ok = True
     for which in ("connect_cut", "connect_final"):
         off, idx = e.lists(which); roff, ridx = ref.lists(which)

@@ -11,9 +11,13 @@
 // n^2/2 pairs, and takes the stored weight instead of evaluating it.
 // Exactness: a listed voxel's centroid lies inside its voxel's cube widened by NL_CUBE_TOL voxel sizes (the builder checks
 // it, counting the rounding of the float cube centre as well; a voxel that fails -- float sums of coordinates kilometres from
-// the origin -- gets NL_NONE), so two listed voxels more than NL_REACH lattice steps apart on some axis are farther apart
-// than (NL_REACH - 2 * NL_CUBE_TOL) voxel sizes: every pair with d2 < d2max = (NL_REACH * voxel_size)^2 * NL_D2_SLACK is in
-// the lists.  Pairs at or below the singleton threshold 1 - cut are never stored by phase A of the cut either (fact S).
+// the origin -- gets NL_NONE), so two listed voxels more than R lattice steps apart on some axis are farther apart
+// than (R - 2 * NL_CUBE_TOL) voxel sizes.  The builder finds a voxel's partners in its adjacency row, i.e. inside the search
+// ball: the lists are complete up to R steps only if every offset of at most R steps lies strictly inside the ball,
+// 3 R^2 < (graph_size / voxel_size)^2 (nearlist.hip: nl_reach_steps, R <= NL_REACH).  Every pair with
+// d2 < d2max = (R * voxel_size)^2 * slack is then in the lists, and the cut reads them no farther (entries beyond d2max
+// are never taken: the general enumeration covers d2 >= d2max).  Pairs at or below the singleton threshold 1 - cut are
+// never stored by phase A of the cut either (fact S).
 #ifndef NEARLIST_HPP_
 #define NEARLIST_HPP_
 
