@@ -218,6 +218,12 @@ class TiledSegmenter:
         lo, hi = self.regions[self.rank]
         h = self.halo
         x, y = xyz_host[:, 0].astype(np.float64), xyz_host[:, 1].astype(np.float64)
+        # A rank is expected to load the points of ITS region.  Points it holds beyond the border still reach the owner of that
+        # ground through the strips below and take part in the owner's voxels, but their labels are read from this rank's
+        # halo computation, which knows a segment's global label only if the segment touches one of its own voxels: a few
+        # of them may come back -1 (seen with generated tiles whose objects reach over the border; tools/fuzz_tiles.py
+        # partitions by region).  n_outside says how many there are.
+        self.n_outside = int(((x < lo[0]) | (x >= hi[0]) | (y < lo[1]) | (y >= hi[1])).sum())
         near = (x < lo[0] + h) | (x >= hi[0] - h) | (y < lo[1] + h) | (y >= hi[1] - h)
         strips = all_gather_varlen(self.dist, np.ascontiguousarray(xyz_host[near]).reshape(-1), self.coll_device)
         extra = []
