@@ -57,6 +57,12 @@ while time.time() < t_end:
               sig_n=float(rng.choice([0.2, 0.5])), sig_p=float(rng.choice([0.1, 0.2, 0.4])))
     if kw["graph_size"] / kw["voxel_size"] > 8.0:
         kw["graph_size"] = 8.0 * kw["voxel_size"]
+    if METHOD == 2 and rng.random() < 0.5:   # the size filters, and inputs with holes: non-finite points, repeated points
+        kw.update(points_min=int(rng.choice([3, 5, 10, 20])), voxels_min=int(rng.choice([1, 3, 8])), adjacency_min=int(rng.choice([1, 3, 6])))
+        if rng.random() < 0.5:
+            xyz = xyz.copy()
+            xyz[rng.random(xyz.shape[0]) < 0.002] = np.nan
+            xyz = np.concatenate([xyz, xyz[rng.integers(0, xyz.shape[0], xyz.shape[0] // 50)]])
     if METHOD == 3:
         kw = dict(graph_size=float(rng.choice([0.4, 0.5, 0.8, 1.2])), cut_thred=kw["cut_thred"], sig_w=kw["sig_w"], sig_n=kw["sig_n"], sig_p=kw["sig_p"])
         seed_size = float(rng.choice([0.15, 0.25, 0.4]))
