@@ -38,9 +38,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   __shared__ uint8_t gl[CAP];    // integer squared length of each survivor's lattice offset (the table is sorted by it)
   __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
   const int lane = threadIdx.x;
-  int64_t u;
-  if (redo) { if (blockIdx.x >= *n_redo) return; u = (int64_t)redo[blockIdx.x]; }
-  else { u = vgs_xcd_item(blockIdx.x, U); if (u >= U) return; }
+  auto do_row = [&](const int64_t u) {
   const uint32_t i = used_ids[u];
   const uint64_t code = vox_code[i];
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
@@ -144,6 +142,17 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   }
   for (int k = lane; k < cnt; k += 64) row[k] = lst[k];
   if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }  // stored entries, all neighbours
+  };   // do_row
+  if (redo) {
+    // a fixed grid strides over the redo list, whose length stays on the device: no host round trip before this launch
+    for (unsigned int w = blockIdx.x; w < *n_redo; w += gridDim.x) {
+      do_row((int64_t)redo[w]);
+      __syncthreads();   // the next row reuses the list
+    }
+  } else {
+    const int64_t u = vgs_xcd_item(blockIdx.x, U);
+    if (u < U) do_row(u);
+  }
 }
 
 // ---- hot path for small balls: candidates from brick occupancy masks --------------------------------------------
@@ -444,9 +453,8 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
                        out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p)
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
 #undef LAUNCH_ADJM
-    unsigned int n_redo = 0;
-    VGS_READBACK(c, &n_redo, d_nredo, 4);
-    if (n_redo > 0) LAUNCH_ADJ(1024, false, n_redo, c->work_ids.p, d_nredo, nullptr);
+    // rows it passed on (more candidates than its list): the general kernel, a fixed grid striding over the device-side list
+    LAUNCH_ADJ(1024, false, (unsigned int)(U < 2048 ? U : 2048), c->work_ids.p, d_nredo, nullptr);
   } else if (c->n_off <= 1024) {
     if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);
   } else if (c->n_off <= 8192) {
@@ -456,7 +464,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
     VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
     if (full) LAUNCH_ADJ(2048, true, vgs_xcd_grid(U), nullptr, d_nredo, c->work_ids.p); else LAUNCH_ADJ(2048, false, vgs_xcd_grid(U), nullptr, d_nredo, c->work_ids.p);
-    const unsigned int g2 = (unsigned int)U;   // upper bound; workgroups beyond the list leave at once
+    const unsigned int g2 = (unsigned int)(U < 4096 ? U : 4096);   // the grid strides over the list
     if (full) LAUNCH_ADJ(8192, true, g2, c->work_ids.p, d_nredo, nullptr); else LAUNCH_ADJ(8192, false, g2, c->work_ids.p, d_nredo, nullptr);
   }
   else { c->err = "neighbour ball larger than 8192 lattice offsets (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
