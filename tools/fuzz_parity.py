@@ -10,6 +10,7 @@ import refcpu_py as oracle
 from helpers import oracle_params, ragged_sets
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+WIDE = len(sys.argv) > 4 and sys.argv[4] == "wide"   # search balls of 6-10 voxels: the multi-wavefront classes and their hand-overs
 METHOD = int(sys.argv[3]) if len(sys.argv) > 3 else 2   # 3: SVGS from a grid labelling (everything behind pcl::SupervoxelClustering)
 
 
@@ -55,8 +56,13 @@ while time.time() < t_end:
     kw = dict(voxel_size=float(rng.choice([0.06, 0.08, 0.1, 0.15])), graph_size=float(rng.choice([0.3, 0.4, 0.5, 0.6])),
               cut_thred=float(rng.choice([0.1, 0.3, 0.5, 0.7, 0.9])), sig_w=float(rng.choice([1.0, 2.0])),
               sig_n=float(rng.choice([0.2, 0.5])), sig_p=float(rng.choice([0.1, 0.2, 0.4])))
-    if kw["graph_size"] / kw["voxel_size"] > 8.0:
-        kw["graph_size"] = 8.0 * kw["voxel_size"]
+    if WIDE and METHOD == 2:
+        kw["voxel_size"] = float(rng.choice([0.04, 0.05, 0.06]))
+        kw["graph_size"] = float(rng.choice([0.3, 0.4, 0.5]))
+        n = min(n, 50_000)
+        xyz = xyz[: n]
+    if kw["graph_size"] / kw["voxel_size"] > (10.5 if WIDE else 8.0):
+        kw["graph_size"] = (10.0 if WIDE else 8.0) * kw["voxel_size"]
     if METHOD == 2 and rng.random() < 0.5:   # the size filters, and inputs with holes: non-finite points, repeated points
         kw.update(points_min=int(rng.choice([3, 5, 10, 20])), voxels_min=int(rng.choice([1, 3, 8])), adjacency_min=int(rng.choice([1, 3, 6])))
         if rng.random() < 0.5:
