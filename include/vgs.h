@@ -66,8 +66,8 @@ enum {
 
 /* stage timers (milliseconds, HIP events on the context's stream) */
 enum {
-  VGS_T_VOXELIZE = 0, VGS_T_FEATURES = 1, VGS_T_ADJACENCY = 2, VGS_T_LOCALCUT = 3, VGS_T_MERGE = 4,
-  VGS_T_LABELS = 5, VGS_T_TOTAL = 6, VGS_T_LOCALCUT_KERNEL = 7, VGS_T_SUPERVOXEL = 8,
+  VGS_T_VOXELIZE = 0, VGS_T_FEATURES = 1, VGS_T_ADJACENCY = 2, VGS_T_LOCALCUT = 3 /* incl. its hand-over kernels that end inside the merge stage */, VGS_T_MERGE = 4,
+  VGS_T_LABELS = 5 /* cluster filter + voxel and point labels: the last part of VGS_T_MERGE, not added to the total again */, VGS_T_TOTAL = 6, VGS_T_LOCALCUT_KERNEL = 7, VGS_T_SUPERVOXEL = 8,
   VGS_T_LOCALCUT_BULK = 9, /* the one launch of the bulk-class local-cut kernel (k_localcut_wave<96,448,1>), HIP events on its stream */
   VGS_T_COUNT = 12
 };
@@ -95,6 +95,20 @@ const char* vgs_last_error_string(const vgs_ctx* ctx); /* ctx may be NULL: last 
 vgs_status vgs_set_points(vgs_ctx* ctx, const float* xyz_host, int64_t n, int32_t stride_bytes);
 /* device variant: no copy, the caller keeps the buffer alive and unchanged until results are read */
 vgs_status vgs_set_points_device(vgs_ctx* ctx, const float* xyz_dev, int64_t n, int32_t stride_bytes);
+
+/* A sequence of clouds (no reference counterpart: the reference loads one PCD, T:41-49).  vgs_stage_points starts the copy
+ * of the NEXT cloud into the context's second input buffer on a copy stream and returns at once; the current cloud, its
+ * stages and its results stay untouched.  vgs_commit_points makes the staged cloud the current one, like vgs_set_points
+ * without the host-side wait (the stages' stream waits for the copy on the device).  The host buffer must stay unchanged
+ * until the commit's first stage has run; pinned memory (vgs_host_alloc / vgs_host_register) makes the copy asynchronous
+ * and about twice as fast, pageable memory works. */
+vgs_status vgs_stage_points(vgs_ctx* ctx, const float* xyz_host, int64_t n, int32_t stride_bytes);
+vgs_status vgs_commit_points(vgs_ctx* ctx);
+/* pinned host memory for the two calls above and for vgs_get_point_labels_async (hipHostMalloc / hipHostRegister) */
+vgs_status vgs_host_alloc(void** p, uint64_t bytes);
+vgs_status vgs_host_free(void* p);
+vgs_status vgs_host_register(void* p, uint64_t bytes);
+vgs_status vgs_host_unregister(void* p);
 
 /* ---- VGS stages, in the reference's call order (T:54-74) --------------------------------- */
 vgs_status vgs_voxelize(vgs_ctx* ctx);   /* addPointsFromInputCloud + getBoundingBox/setBoundingBox + setVoxelCenters + getVoxelNum (T:54-62, VS:146-189) */
@@ -138,13 +152,27 @@ vgs_status vgs_get_attributes(vgs_ctx* ctx, float* centroid, float* normal, floa
  * which: 0 adjacency (getOneVoxelAdjacency order, VS:268; used nodes only), 1 connect lists after the local cut,
  *        2 after crossValidation (VS:2111), 3 after closestCheck (VS:2181) */
 vgs_status vgs_get_lists(vgs_ctx* ctx, int32_t which, int64_t* offsets, int32_t* idx);
+/* voxels_adjacency_idx_[v][0] (VS:253): the number of neighbours of every node inside graph_size, itself included; 0 for a
+ * node that has no list (unused voxels, see `which` above) */
+vgs_status vgs_get_adjacency_counts(vgs_ctx* ctx, int32_t* n_all /* n_nodes */);
 vgs_status vgs_get_node_labels(vgs_ctx* ctx, int32_t* component_root /* V: smallest node id of its cluster */,
                                int32_t* kept_label /* V: index into kept clusters or -1 */);
 vgs_status vgs_get_point_labels(vgs_ctx* ctx, int32_t* labels /* N host; -1 = dropped */);
+/* starts the copy of the labels to `labels` (N int32, ideally pinned) on a copy stream and returns; the next run of the
+ * stages writes a second label buffer, so the copy overlaps it.  vgs_wait_point_labels blocks until `labels` is complete.
+ * One copy in flight per context: a second call waits for the first. */
+vgs_status vgs_get_point_labels_async(vgs_ctx* ctx, int32_t* labels);
+vgs_status vgs_wait_point_labels(vgs_ctx* ctx);
 vgs_status vgs_get_point_labels_device(vgs_ctx* ctx, const int32_t** labels_dev /* N, valid until next run */);
 /* getClusterIdx (VS:117): offsets (kept+1, int64) and point indices grouped by cluster (cluster order =
  * ascending smallest voxel id, as the reference; inside a cluster ascending voxel id then point index) */
 vgs_status vgs_get_clusters(vgs_ctx* ctx, int64_t* offsets, int32_t* point_idx);
+/* The same with a choice of the order inside a cluster.  VGS_ORDER_REFERENCE is the reference's own: nodes in the pre-order
+ * of recursionSearch over the final connect lists with the seed appended LAST (VS:2032-2053, 2064-2080; SS:2079-2103), the
+ * points of each node in ascending index (VS:981-999; SS:2109-2126) -- element for element what getClusterIdx() holds.
+ * (Output formatting: the walk runs on the host over the downloaded lists.) */
+enum { VGS_ORDER_VOXEL_ID = 0, VGS_ORDER_REFERENCE = 1 };
+vgs_status vgs_get_clusters_ordered(vgs_ctx* ctx, int32_t order, int64_t* offsets, int32_t* point_idx);
 
 /* ---- multi-GPU support (spatial tiles) -------------------------------------- */
 /* The reference is single-process; these entry points are what a tiled driver needs around the same stages.

@@ -115,6 +115,7 @@ class VoxelBasedSegmentation {
     if (!cloud_) throw std::runtime_error("addPointsFromInputCloud before setInputCloud");
     chk(vgs_set_points(ctx(), &cloud_->points[0].x, (int64_t)cloud_->points.size(), (int32_t)sizeof(PointT)), "vgs_set_points");
     chk(vgs_voxelize(ctx()), "vgs_voxelize");
+    adj_off_.clear(); adj_idx_.clear();
   }
   void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {
     double b[6];
@@ -130,9 +131,10 @@ class VoxelBasedSegmentation {
     if (!drawn_) return out;  // clusters_point_idx_ is filled by drawColorMapofPointsinClusters only (VS:1006)
     const int64_t k = count(VGS_N_KEPT);
     std::vector<int64_t> off((size_t)k + 1);
-    chk(vgs_get_clusters(ctx(), off.data(), nullptr), "vgs_get_clusters");
+    // element for element what the reference's clusters_point_idx_ holds: DFS order of the nodes, seed last
+    chk(vgs_get_clusters_ordered(ctx(), VGS_ORDER_REFERENCE, off.data(), nullptr), "vgs_get_clusters");
     std::vector<int32_t> idx((size_t)off[k] + 1);
-    chk(vgs_get_clusters(ctx(), off.data(), idx.data()), "vgs_get_clusters");
+    chk(vgs_get_clusters_ordered(ctx(), VGS_ORDER_REFERENCE, off.data(), idx.data()), "vgs_get_clusters");
     out.resize((size_t)k);
     for (int64_t i = 0; i < k; ++i) out[(size_t)i].assign(idx.begin() + off[i], idx.begin() + off[i + 1]);
     return out;
@@ -158,14 +160,20 @@ class VoxelBasedSegmentation {
     p_.graph_size = graph_size;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
     chk(vgs_adjacency(ctx()), "vgs_adjacency");
+    adj_off_.clear(); adj_idx_.clear();
   }
   std::vector<int> getOneVoxelAdjacency(int voxel_id) {                                  // VS:268
-    const int64_t v = count(VGS_N_VOXELS);
-    std::vector<int64_t> off((size_t)v + 1);
-    chk(vgs_get_lists(ctx(), 0, off.data(), nullptr), "vgs_get_lists");
-    std::vector<int32_t> idx((size_t)off[v] + 1);
-    chk(vgs_get_lists(ctx(), 0, off.data(), idx.data()), "vgs_get_lists");
-    return std::vector<int>(idx.begin() + off[voxel_id], idx.begin() + off[voxel_id + 1]);
+    // the reference keeps voxels_adjacency_idx_ in memory and a caller loops over the voxels: the lists are fetched once per
+    // findAllVoxelAdjacency, not once per call
+    if (adj_off_.empty()) {
+      const int64_t v = count(VGS_N_VOXELS);
+      adj_off_.assign((size_t)v + 1, 0);
+      chk(vgs_get_lists(ctx(), 0, adj_off_.data(), nullptr), "vgs_get_lists");
+      adj_idx_.assign((size_t)adj_off_[v] + 1, 0);
+      chk(vgs_get_lists(ctx(), 0, adj_off_.data(), adj_idx_.data()), "vgs_get_lists");
+    }
+    if (voxel_id < 0 || (size_t)voxel_id + 1 >= adj_off_.size()) throw std::out_of_range("getOneVoxelAdjacency: voxel id");
+    return std::vector<int>(adj_idx_.begin() + adj_off_[voxel_id], adj_idx_.begin() + adj_off_[voxel_id + 1]);
   }
   void segmentVoxelCloudWithGraphModel(float cut_thred, float sig_p, float sig_n, float sig_o, float sig_e, float sig_c,
                                        float sig_w) {                                    // VS:372
@@ -201,6 +209,8 @@ class VoxelBasedSegmentation {
   std::unique_ptr<vgs_ctx, vgs_detail::CtxDeleter> ctx_;
   PCXYZPtr cloud_;
   bool drawn_ = false;
+  std::vector<int64_t> adj_off_;   // getOneVoxelAdjacency's copy of the lists
+  std::vector<int32_t> adj_idx_;
 };
 
 template <typename PointT>
@@ -226,9 +236,10 @@ class SuperVoxelBasedSegmentation {
   std::vector<std::vector<int>> getClusterIdx() {                                        // SS:130 (no draw call needed, SS:2124)
     const int64_t k = count(VGS_N_KEPT);
     std::vector<int64_t> off((size_t)k + 1);
-    chk(vgs_get_clusters(ctx(), off.data(), nullptr), "vgs_get_clusters");
+    // element for element what the reference's clusters_point_idx_ holds: DFS order of the nodes, seed last
+    chk(vgs_get_clusters_ordered(ctx(), VGS_ORDER_REFERENCE, off.data(), nullptr), "vgs_get_clusters");
     std::vector<int32_t> idx((size_t)off[k] + 1);
-    chk(vgs_get_clusters(ctx(), off.data(), idx.data()), "vgs_get_clusters");
+    chk(vgs_get_clusters_ordered(ctx(), VGS_ORDER_REFERENCE, off.data(), idx.data()), "vgs_get_clusters");
     std::vector<std::vector<int>> out((size_t)k);
     for (int64_t i = 0; i < k; ++i) out[(size_t)i].assign(idx.begin() + off[i], idx.begin() + off[i + 1]);
     return out;

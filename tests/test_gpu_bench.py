@@ -1,0 +1,40 @@
+"""bench.py end to end on the GPU box at reduced sizes: the single-GPU line with its host-to-host leg, and the N > 1 branch
+(TiledSegmenter + process group) with two ranks sharing the one GPU over gloo (VGS_BENCH_BACKEND / VGS_BENCH_SINGLE_DEVICE:
+a 1-GPU box cannot run RCCL with two ranks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(gpu):
+    out = _run(["--points", "400000", "--steps", "3", "--warmup", "1"])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "points/s" and out["dtype"] == "f32"
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    h = out["host_to_host"]
+    assert h["labels_equal_device_resident_run"] is True and h["value"] > 0 and h["latency_ms_median"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["cpu_lean"]["value"] >= cb["value"]
+    assert out["stage_ms"]["labels"] > 0.0
+
+
+def test_two_ranks_on_one_gpu(gpu):
+    out = _run(["--gpus", "2", "--points", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+               env_extra={"VGS_BENCH_BACKEND": "gloo", "VGS_BENCH_SINGLE_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "2x1" in out["config"]["workload"]

@@ -84,12 +84,30 @@ def test_labels_identical(run):
     root, kept = eng.node_labels()
     np.testing.assert_array_equal(canonical_labels(root), canonical_labels(nc_ref))
     np.testing.assert_array_equal(eng.point_labels(), pl_ref)
-    # getClusterIdx: same clusters in the same order; inside a cluster the reference follows its DFS order
+    # getClusterIdx, default order of the engine (ascending voxel id inside a cluster): the same clusters in the same order
     go, gi = eng.clusters()
     ro, ri = ref.lists("clusters_points")
     assert len(go) == len(ro)
     for k in range(len(go) - 1):
         assert sorted(gi[go[k]:go[k + 1]].tolist()) == sorted(ri[ro[k]:ro[k + 1]].tolist())
+
+
+def test_cluster_index_lists_in_reference_order(run):
+    """getClusterIdx element for element: clusters in the order of their seeds, nodes in recursionSearch's DFS order with the
+    seed appended last (voxel_segmentation.h:2032-2053, 2064-2080), points per node ascending (VS:981-999).  No sorting on
+    either side.  The walk depends on the ORDER of the final connect lists, so that is compared first."""
+    eng, ref = run["eng"], run["ref"]
+    go, gi = eng.lists("connect_final")
+    ro, ri = ref.lists("connect_final")
+    np.testing.assert_array_equal(go, ro)
+    np.testing.assert_array_equal(gi, ri)
+    co, ci = eng.clusters("reference")
+    rco, rci = ref.lists("clusters_points")
+    np.testing.assert_array_equal(co, rco)
+    np.testing.assert_array_equal(ci, rci)
+    # and the class mirror returns exactly these lists
+    c0 = ci[co[0]:co[1]].tolist() if len(co) > 1 else []
+    assert len(c0) == len(set(c0))
 
 
 def test_partition_vs_refmath_faithful(run, oracle):

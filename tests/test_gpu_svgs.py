@@ -77,6 +77,20 @@ def test_labels_identical(run):
     assert c["clusters"] == ref.clusters_num and c["kept"] == ref.kept_clusters   # SVGS keeps every cluster (SS:2113)
 
 
+def test_cluster_index_lists_in_reference_order(run):
+    """getClusterIdx element for element (supervoxel_segmentation.h:2079-2126): DFS order of the supervoxels with the seed
+    last, each supervoxel's points in ascending index; no sorting on either side."""
+    eng, ref = run["eng"], run["ref"]
+    go, gi = eng.lists("connect_final")
+    ro, ri = ref.lists("connect_final")
+    np.testing.assert_array_equal(go, ro)
+    np.testing.assert_array_equal(gi, ri)
+    co, ci = eng.clusters("reference")
+    rco, rci = ref.lists("clusters_points")
+    np.testing.assert_array_equal(co, rco)
+    np.testing.assert_array_equal(ci, rci)
+
+
 def test_class_mirror(run, gpu):
     """segmentationSVGS (reference test:138-160) through the class mirror."""
     sv = gpu.SuperVoxelBasedSegmentation(0.05)

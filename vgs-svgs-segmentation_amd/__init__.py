@@ -7,4 +7,5 @@ the repo-root shim `vgs_svgs_segmentation_amd`.
 """
 from . import _lib, pcd, scenes  # noqa: F401
 from ._lib import VgsError, VgsParams, build  # noqa: F401
-from .api import Engine, SuperVoxelBasedSegmentation, VoxelBasedSegmentation, default_params, parse_task_file, segmentation_vgs  # noqa: F401
+from .api import (Engine, SuperVoxelBasedSegmentation, VoxelBasedSegmentation, default_params, parse_task_file, pinned_empty,  # noqa: F401
+                  segmentation_vgs)

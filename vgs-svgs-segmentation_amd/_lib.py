@@ -57,6 +57,12 @@ SYMBOLS = [
     ("vgs_last_error_string", C.c_char_p, [_P]),
     ("vgs_set_points", C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     ("vgs_set_points_device", C.c_int, [_P, _P, C.c_int64, C.c_int32]),
+    ("vgs_stage_points", C.c_int, [_P, _P, C.c_int64, C.c_int32]),
+    ("vgs_commit_points", C.c_int, [_P]),
+    ("vgs_host_alloc", C.c_int, [C.POINTER(_P), C.c_uint64]),
+    ("vgs_host_free", C.c_int, [_P]),
+    ("vgs_host_register", C.c_int, [_P, C.c_uint64]),
+    ("vgs_host_unregister", C.c_int, [_P]),
     ("vgs_voxelize", C.c_int, [_P]),
     ("vgs_features", C.c_int, [_P]),
     ("vgs_adjacency", C.c_int, [_P]),
@@ -76,10 +82,14 @@ SYMBOLS = [
     ("vgs_get_point_voxel", C.c_int, [_P, _P]),
     ("vgs_get_attributes", C.c_int, [_P, _P, _P, _P, _P]),
     ("vgs_get_lists", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("vgs_get_adjacency_counts", C.c_int, [_P, _P]),
     ("vgs_get_node_labels", C.c_int, [_P, _P, _P]),
     ("vgs_get_point_labels", C.c_int, [_P, _P]),
+    ("vgs_get_point_labels_async", C.c_int, [_P, _P]),
+    ("vgs_wait_point_labels", C.c_int, [_P]),
     ("vgs_get_point_labels_device", C.c_int, [_P, C.POINTER(_P)]),
     ("vgs_get_clusters", C.c_int, [_P, _P, _P]),
+    ("vgs_get_clusters_ordered", C.c_int, [_P, C.c_int32, _P, _P]),
     ("vgs_grid_state_init", C.c_int, [C.POINTER(VgsGridState)]),
     ("vgs_grid_advance", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_points_bbox", C.c_int, [_P, _P, C.POINTER(C.c_int64)]),

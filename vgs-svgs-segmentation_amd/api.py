@@ -42,6 +42,35 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class _Pinned:
+    """Owner of one hipHostMalloc block (freed when the last numpy view of it goes away)."""
+
+    def __init__(self, nbytes):
+        self._L = _lib.lib()
+        self.p = C.c_void_p()
+        st = self._L.vgs_host_alloc(C.byref(self.p), max(int(nbytes), 1))
+        if st != _lib.VGS_OK:
+            raise VgsError(st, f"vgs_host_alloc({nbytes})")
+
+    def __del__(self):
+        try:
+            if self.p.value:
+                self._L.vgs_host_free(self.p)
+                self.p = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in pinned host memory (vgs_host_alloc): the staging buffers of stage_points / point_labels_async."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    blk = _Pinned(n)
+    buf = (C.c_char * max(n, 1)).from_address(blk.p.value)
+    buf._owner = blk   # the ctypes array keeps the block alive, the numpy array keeps the ctypes array alive
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class Engine:
     def __init__(self, params: VgsParams):
         self._L = _lib.lib()
@@ -168,6 +197,12 @@ class Engine:
         self._ck(self._L.vgs_get_lists(self._h, w, _ptr(off), _ptr(idx)))
         return off, idx[:int(off[-1])]
 
+    def adjacency_counts(self):
+        """Neighbours inside graph_size per node, itself included (0 for unused voxels)."""
+        out = np.zeros(self.counts()["voxels"], dtype=np.int32)
+        self._ck(self._L.vgs_get_adjacency_counts(self._h, _ptr(out)))
+        return out
+
     def node_labels(self):
         V = self.counts()["voxels"]
         root = np.zeros(V, dtype=np.int32)
@@ -192,13 +227,40 @@ class Engine:
         self._ck(self._L.vgs_get_point_labels_device(self._h, C.byref(p)))
         return p.value
 
-    def clusters(self):
+    ORDERS = {"voxel_id": 0, "reference": 1}
+
+    def clusters(self, order="voxel_id"):
+        """getClusterIdx as (offsets, point indices).  order="reference": nodes in recursionSearch's DFS order with the seed
+        last, points per node ascending (voxel_segmentation.h:2032-2080, 981-999) -- the reference's own element order."""
         K = self.counts()["kept"]
+        o = self.ORDERS[order]
         off = np.zeros(K + 1, dtype=np.int64)
-        self._ck(self._L.vgs_get_clusters(self._h, _ptr(off), None))
+        self._ck(self._L.vgs_get_clusters_ordered(self._h, o, _ptr(off), None))
         idx = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
-        self._ck(self._L.vgs_get_clusters(self._h, _ptr(off), _ptr(idx)))
+        self._ck(self._L.vgs_get_clusters_ordered(self._h, o, _ptr(off), _ptr(idx)))
         return off, idx[:int(off[-1])]
+
+    # ---- a sequence of clouds: uploads of the next cloud and downloads of the last labels overlap the stages
+    def stage_points(self, xyz):
+        """Start the copy of the NEXT cloud (ideally a pinned array, see pinned_empty) and return at once."""
+        if xyz.dtype != np.float32 or not xyz.flags["C_CONTIGUOUS"] or xyz.ndim != 2 or xyz.shape[1] not in (3, 4):
+            raise ValueError("xyz must be a C-contiguous (N,3) or (N,4) float32 array")
+        self._staged = xyz
+        self._ck(self._L.vgs_stage_points(self._h, _ptr(xyz), xyz.shape[0], xyz.shape[1] * 4))
+
+    def commit_points(self):
+        self._ck(self._L.vgs_commit_points(self._h))
+        self._keep, self._staged = self._staged, None
+        self.n = self._keep.shape[0]
+
+    def point_labels_async(self, out):
+        if out.dtype != np.int32 or not out.flags["C_CONTIGUOUS"] or out.shape[0] < self.n:
+            raise ValueError("out must be a C-contiguous int32 array with one entry per point")
+        self._labels_out = out
+        self._ck(self._L.vgs_get_point_labels_async(self._h, _ptr(out)))
+
+    def wait_labels(self):
+        self._ck(self._L.vgs_wait_point_labels(self._h))
 
 
 class VoxelBasedSegmentation:
@@ -209,6 +271,7 @@ class VoxelBasedSegmentation:
         self._eng = Engine(self._p)
         self._cloud = None
         self._drawn = False
+        self._adj = None
 
     def _push(self):
         self._eng.set_params(self._p)
@@ -257,9 +320,12 @@ class VoxelBasedSegmentation:
         self._p.graph_size = float(graph_size)
         self._push()
         self._eng.adjacency()
+        self._adj = None
 
     def getOneVoxelAdjacency(self, voxel_id):                # VS:268
-        off, idx = self._eng.lists("adjacency")
+        if self._adj is None:    # fetched once per findAllVoxelAdjacency, not once per call
+            self._adj = self._eng.lists("adjacency")
+        off, idx = self._adj
         return idx[off[voxel_id]:off[voxel_id + 1]].tolist()
 
     def segmentVoxelCloudWithGraphModel(self, cut_thred, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w):  # VS:372
@@ -279,7 +345,7 @@ class VoxelBasedSegmentation:
     def getClusterIdx(self):                                 # VS:117
         if not self._drawn:
             return []   # clusters_point_idx_ is only filled by drawColorMapofPointsinClusters (VS:1006)
-        off, idx = self._eng.clusters()
+        off, idx = self._eng.clusters("reference")
         return [idx[off[k]:off[k + 1]].tolist() for k in range(len(off) - 1)]
 
     @property
@@ -351,7 +417,7 @@ class SuperVoxelBasedSegmentation:
         return self._eng.counts()["clusters"]
 
     def getClusterIdx(self):                                                          # SS:130
-        off, idx = self._eng.clusters()
+        off, idx = self._eng.clusters("reference")
         return [idx[off[k]:off[k + 1]].tolist() for k in range(len(off) - 1)]
 
     @property

@@ -442,7 +442,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
-  if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !getenv("VGS_NO_ADJMASKS")) {
+  if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !c->K.no_adjmasks) {
     // hot path: candidates from the brick occupancy masks; rows it cannot take go through the general kernel
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
     unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);

@@ -27,6 +27,26 @@ static vgs_status timed(vgs_ctx* c, int slot, F&& f) {
   return VGS_OK;
 }
 
+void vgs_read_env_knobs(vgs_ctx* c) {
+  VgsKnobs& k = c->K;
+  auto geti = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+  auto getf = [](const char* n, float d) { const char* v = getenv(n); return v ? (float)atof(v) : d; };
+  auto has = [](const char* n) { return getenv(n) != nullptr; };
+  k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
+  k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m);
+  k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
+  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS");
+  k.debug = has("VGS_DEBUG");
+}
+
+// The hand-over kernels of the local cut end inside the merge stage's timed region (vgs_localcut_finish measures by how much):
+// that tail belongs to the local cut in the reported stage times.
+static void vgs_charge_localcut_tail(vgs_ctx* c) {
+  const double t = (double)c->lc_tail.tail_ms;
+  if (t > 0.0 && t < c->times[VGS_T_MERGE]) { c->times[VGS_T_LOCALCUT] += t; c->times[VGS_T_MERGE] -= t; }
+  c->lc_tail.tail_ms = 0.f;
+}
+
 extern "C" {
 
 vgs_status vgs_params_default_vgs(vgs_params* p) {
@@ -118,12 +138,17 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
       hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
       hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_hi) != hipSuccess) {
     g_create_err = "vgs_create: hipSetDevice/hipStreamCreate failed";
-    delete c;
+    vgs_destroy(c);
     return VGS_E_HIP;
   }
   if (hipHostMalloc(&c->pin, 4096, hipHostMallocDefault) != hipSuccess) c->pin = nullptr;   // read-backs fall back to pageable copies
-  for (int i = 0; i < 14; ++i)
-    if (hipEventCreate(&c->ev[i]) != hipSuccess) { g_create_err = "vgs_create: hipEventCreate failed"; delete c; return VGS_E_HIP; }
+  bool ok = hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_d2h, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < 14; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  if (!ok) { g_create_err = "vgs_create: hipStreamCreate/hipEventCreate failed"; vgs_destroy(c); return VGS_E_HIP; }   // frees what exists
+  vgs_read_env_knobs(c);
   *out = c;
   return VGS_OK;
 }
@@ -136,7 +161,9 @@ void vgs_destroy(vgs_ctx* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   if (c->stream4) (void)hipStreamSynchronize(c->stream4);
-  c->owned_xyz.release(); c->grow_state.release();
+  if (c->s_h2d) (void)hipStreamSynchronize(c->s_h2d);
+  if (c->s_d2h) (void)hipStreamSynchronize(c->s_d2h);
+  c->xyz_buf[0].release(); c->xyz_buf[1].release(); c->pt_label_alt.release(); c->grow_state.release();
   c->code_a.release(); c->code_b.release(); c->perm_a.release(); c->perm_b.release(); c->sort_tmp.release();
   c->head_flag.release(); c->pt_vox.release(); c->vox_code.release(); c->vox_start.release();
   c->xs.release(); c->ys.release(); c->zs.release();
@@ -157,6 +184,10 @@ void vgs_destroy(vgs_ctx* c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
+  if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+  if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+  if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
+  if (c->ev_d2h) (void)hipEventDestroy(c->ev_d2h);
   delete c;
 }
 
@@ -202,12 +233,53 @@ vgs_status vgs_set_points(vgs_ctx* c, const float* xyz_host, int64_t n, int32_t 
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   vgs_status s = set_points_common(c, n, stride_bytes);
   if (s != VGS_OK) return s;
-  VGS_HIP_TRY(c, c->owned_xyz.ensure((size_t)n * c->stride_f + 4));
-  if (n > 0) VGS_HIP_TRY(c, hipMemcpyAsync(c->owned_xyz.p, xyz_host, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+  DevBuf<float>& buf = c->xyz_buf[c->xyz_cur];   // a staged cloud, if any, sits in the other one
+  VGS_HIP_TRY(c, buf.ensure((size_t)n * c->stride_f + 4));
+  if (n > 0) VGS_HIP_TRY(c, hipMemcpyAsync(buf.p, xyz_host, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->xyz = c->owned_xyz.p;
+  c->xyz = buf.p;
   return VGS_OK;
 }
+
+// ---- a sequence of clouds: the next upload and the last download overlap the stages of the current cloud --------------
+vgs_status vgs_stage_points(vgs_ctx* c, const float* xyz_host, int64_t n, int32_t stride_bytes) {
+  if (!c || (!xyz_host && n > 0)) return VGS_E_ARG;
+  if (n < 0 || (stride_bytes != 12 && stride_bytes != 16)) { c->err = "vgs_stage_points: n >= 0 and stride_bytes 12 or 16 required"; return VGS_E_ARG; }
+  if (n >= (int64_t)1 << 31) { c->err = "vgs_stage_points: more than 2^31-1 points"; return VGS_E_UNSUPPORTED; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  if (c->staged) VGS_HIP_TRY(c, hipEventSynchronize(c->ev_h2d));   // a staged cloud that was never committed is replaced
+  DevBuf<float>& buf = c->xyz_buf[1 - c->xyz_cur];
+  VGS_HIP_TRY(c, buf.ensure((size_t)n * (stride_bytes / 4) + 4));
+  if (n > 0) VGS_HIP_TRY(c, hipMemcpyAsync(buf.p, xyz_host, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->s_h2d));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev_h2d, c->s_h2d));
+  c->staged = true; c->staged_n = n; c->staged_stride = stride_bytes;
+  return VGS_OK;
+}
+
+vgs_status vgs_commit_points(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (!c->staged) { c->err = "vgs_commit_points: no staged cloud (vgs_stage_points first)"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_h2d, 0));   // the stages wait on the device, the host does not
+  vgs_status s = set_points_common(c, c->staged_n, c->staged_stride);
+  if (s != VGS_OK) return s;
+  c->xyz_cur = 1 - c->xyz_cur;
+  c->xyz = c->xyz_buf[c->xyz_cur].p;
+  c->staged = false;
+  return VGS_OK;
+}
+
+vgs_status vgs_host_alloc(void** p, uint64_t bytes) {
+  if (!p) return VGS_E_ARG;
+  *p = nullptr;
+  return hipHostMalloc(p, bytes > 0 ? (size_t)bytes : 1, hipHostMallocDefault) == hipSuccess ? VGS_OK : VGS_E_NOMEM;
+}
+vgs_status vgs_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? VGS_OK : VGS_E_HIP; }
+vgs_status vgs_host_register(void* p, uint64_t bytes) {
+  if (!p || bytes == 0) return VGS_E_ARG;
+  return hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? VGS_OK : VGS_E_HIP;
+}
+vgs_status vgs_host_unregister(void* p) { return (p && hipHostUnregister(p) == hipSuccess) ? VGS_OK : VGS_E_HIP; }
 
 vgs_status vgs_set_points_device(vgs_ctx* c, const float* xyz_dev, int64_t n, int32_t stride_bytes) {
   if (!c || (!xyz_dev && n > 0)) return VGS_E_ARG;
@@ -252,7 +324,7 @@ vgs_status vgs_segment(vgs_ctx* c) {
   vgs_status s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); });
   if (s != VGS_OK) return s;
   s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); });
-  if (s == VGS_OK) c->stage = ST_SEGMENTED;
+  if (s == VGS_OK) { c->stage = ST_SEGMENTED; vgs_charge_localcut_tail(c); }
   return s;
 }
 
@@ -320,7 +392,7 @@ vgs_status svgs_segment(vgs_ctx* c) {
   if ((s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_svgs_neighbours(c); })) != VGS_OK) return s;  // SS:1477-1521
   if ((s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); })) != VGS_OK) return s;          // SS:384-413
   if ((s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); })) != VGS_OK) return s;                // SS:416-420
-  c->stage = ST_SEGMENTED;
+  c->stage = ST_SEGMENTED; vgs_charge_localcut_tail(c);
   c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] +
                           c->times[VGS_T_MERGE];
   return VGS_OK;
@@ -431,10 +503,10 @@ vgs_status vgs_get_attributes(vgs_ctx* c, float* centroid, float* normal, float*
   return VGS_OK;
 }
 
-vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* idx) {
-  if (!c || !offsets || which < 0 || which > 3) return VGS_E_ARG;
-  const int need = which == 0 ? ST_ADJACENCY : ST_SEGMENTED;
-  if (c->stage < need) { c->err = "vgs_get_lists: stage not reached"; return VGS_E_STATE; }
+}  // extern "C"
+
+// the per-node lists of vgs_get_lists as host vectors (also the input of the reference-order cluster walk)
+static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::vector<int32_t>>& L) {
   const int64_t V = c->V, U = c->U;
   std::vector<uint32_t> used_ids((size_t)U), cnt((size_t)U);
   std::vector<uint64_t> keys;
@@ -469,7 +541,7 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
     }
   }
   // per-voxel lists; closestCheck appends (VS:2293-2294): i gets its target, the target gets i, in voxel order
-  std::vector<std::vector<int32_t>> L((size_t)V);
+  L.assign((size_t)V, {});
   for (int64_t u = 0; u < U; ++u) {
     const uint32_t i = used_ids[u];
     for (uint32_t k = 0; k < cnt[u]; ++k) {
@@ -480,6 +552,19 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
   if (which == 3 && !attach.empty())   // no used voxel: nothing was cut, nothing re-attached
     for (int64_t i = 0; i < V; ++i)
       if (attach[i] >= 0) { L[i].push_back(attach[i]); L[attach[i]].push_back((int32_t)i); }
+  return VGS_OK;
+}
+
+extern "C" {
+
+vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* idx) {
+  if (!c || !offsets || which < 0 || which > 3) return VGS_E_ARG;
+  const int need = which == 0 ? ST_ADJACENCY : ST_SEGMENTED;
+  if (c->stage < need) { c->err = "vgs_get_lists: stage not reached"; return VGS_E_STATE; }
+  const int64_t V = c->V;
+  std::vector<std::vector<int32_t>> L;
+  vgs_status sb = vgs_build_lists(c, which, L);
+  if (sb != VGS_OK) return sb;
   int64_t o = 0;
   for (int64_t v = 0; v < V; ++v) {
     offsets[v] = o;
@@ -487,6 +572,19 @@ vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* i
     o += (int64_t)L[v].size();
   }
   offsets[V] = o;
+  return VGS_OK;
+}
+
+vgs_status vgs_get_adjacency_counts(vgs_ctx* c, int32_t* n_all) {
+  if (!c || !n_all) return VGS_E_ARG;
+  if (c->stage < ST_ADJACENCY) { c->err = "vgs_get_adjacency_counts: adjacency first"; return VGS_E_STATE; }
+  for (int64_t v = 0; v < c->V; ++v) n_all[v] = 0;
+  if (c->U == 0) return VGS_OK;
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<uint32_t> ids((size_t)c->U), cnt((size_t)c->U);
+  VGS_HIP_TRY(c, hipMemcpy(ids.data(), c->used_ids.p, ids.size() * 4, hipMemcpyDeviceToHost));
+  VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_mused.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+  for (int64_t u = 0; u < c->U; ++u) n_all[ids[u]] = (int32_t)cnt[u];
   return VGS_OK;
 }
 
@@ -506,6 +604,25 @@ vgs_status vgs_get_point_labels(vgs_ctx* c, int32_t* labels) {
   return VGS_OK;
 }
 
+vgs_status vgs_get_point_labels_async(vgs_ctx* c, int32_t* labels) {
+  if (!c || !labels) return VGS_E_ARG;
+  if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_point_labels_async: segment first"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  if (c->d2h_open) { VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }   // one download in flight per context
+  if (c->N == 0) return VGS_OK;
+  // the stages have completed on the host's side (every stage ends with a wait), so the copy stream may start at once
+  VGS_HIP_TRY(c, hipMemcpyAsync(labels, c->pt_label.p, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->s_d2h));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev_d2h, c->s_d2h));
+  c->d2h_open = true; c->d2h_src = c->pt_label.p;
+  return VGS_OK;
+}
+
+vgs_status vgs_wait_point_labels(vgs_ctx* c) {
+  if (!c) return VGS_E_ARG;
+  if (c->d2h_open) { VGS_HIP_TRY(c, hipSetDevice(c->device)); VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }
+  return VGS_OK;
+}
+
 vgs_status vgs_get_point_labels_device(vgs_ctx* c, const int32_t** labels_dev) {
   if (!c || !labels_dev) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_point_labels_device: segment first"; return VGS_E_STATE; }
@@ -513,9 +630,11 @@ vgs_status vgs_get_point_labels_device(vgs_ctx* c, const int32_t** labels_dev) {
   return VGS_OK;
 }
 
-vgs_status vgs_get_clusters(vgs_ctx* c, int64_t* offsets, int32_t* point_idx) {
-  if (!c || !offsets) return VGS_E_ARG;
+vgs_status vgs_get_clusters_ordered(vgs_ctx* c, int32_t order, int64_t* offsets, int32_t* point_idx) {
+  if (!c || !offsets || (order != VGS_ORDER_VOXEL_ID && order != VGS_ORDER_REFERENCE)) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED) { c->err = "vgs_get_clusters: segment first (drawColorMapofPointsinClusters precedes getClusterIdx, VS:1006)"; return VGS_E_STATE; }
+  if (order == VGS_ORDER_REFERENCE && c->have_region) { c->err = "vgs_get_clusters: reference order needs the whole cloud in one context (not a tile)"; return VGS_E_STATE; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
   const int64_t K = c->counts[VGS_N_KEPT];
   std::vector<int64_t> cnt((size_t)K + 1, 0);
   std::vector<uint32_t> perm((size_t)c->Nf), pv((size_t)c->Nf);
@@ -528,12 +647,51 @@ vgs_status vgs_get_clusters(vgs_ctx* c, int64_t* offsets, int32_t* point_idx) {
   for (int64_t j = 0; j < c->Nf; ++j) { const int32_t l = vl[pv[j]]; if (l >= 0) cnt[l + 1]++; }
   for (int64_t k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
   for (int64_t k = 0; k <= K; ++k) offsets[k] = cnt[k];
-  if (point_idx) {
-    std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+  if (!point_idx) return VGS_OK;
+  std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+  if (order == VGS_ORDER_VOXEL_ID) {
     // sorted positions run over voxels in ascending id and points in ascending index inside a voxel
     for (int64_t j = 0; j < c->Nf; ++j) { const int32_t l = vl[pv[j]]; if (l >= 0) point_idx[cur[l]++] = (int32_t)perm[j]; }
+    return VGS_OK;
+  }
+  // Reference order (output formatting on the host, not the hot path): clusteringVoxels scans the nodes in ascending id and
+  // starts recursionSearch at every unclustered one -- a pre-order walk over the final connect lists in list order -- and
+  // appends the seed LAST (VS:2032-2053, 2064-2080; SS:2079-2103); a cluster's points are its nodes' point lists in that
+  // node order, each in ascending point index (VS:981-999, SS:2109-2126).  The kept clusters keep the order of their seeds,
+  // which is the order of the labels (ascending smallest node id).
+  std::vector<std::vector<int32_t>> L;
+  vgs_status sb = vgs_build_lists(c, 3, L);
+  if (sb != VGS_OK) return sb;
+  const int64_t V = c->V;
+  std::vector<uint32_t> vstart((size_t)V + 1, 0);
+  if (V > 0) VGS_HIP_TRY(c, hipMemcpy(vstart.data(), c->vox_start.p, ((size_t)V + 1) * 4, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> clustered((size_t)V, 0);
+  std::vector<std::pair<int32_t, size_t>> stack;   // (node whose list is being scanned, position): the recursion, unrolled
+  std::vector<int32_t> members;
+  for (int64_t i = 0; i < V; ++i) {
+    if (clustered[i]) continue;
+    clustered[i] = 1;
+    members.clear();
+    stack.clear();
+    stack.emplace_back((int32_t)i, 0);
+    while (!stack.empty()) {
+      auto& top = stack.back();
+      const std::vector<int32_t>& lst = L[top.first];
+      if (top.second >= lst.size()) { stack.pop_back(); continue; }
+      const int32_t v = lst[top.second++];
+      if (!clustered[v]) { members.push_back(v); clustered[v] = 1; stack.emplace_back(v, 0); }
+    }
+    members.push_back((int32_t)i);
+    const int32_t l = vl[i];
+    if (l < 0) continue;   // dropped by the size filter (VS:969)
+    for (int32_t v : members)
+      for (uint32_t j = vstart[v]; j < vstart[v + 1]; ++j) point_idx[cur[l]++] = (int32_t)perm[j];
   }
   return VGS_OK;
+}
+
+vgs_status vgs_get_clusters(vgs_ctx* c, int64_t* offsets, int32_t* point_idx) {
+  return vgs_get_clusters_ordered(c, VGS_ORDER_VOXEL_ID, offsets, point_idx);
 }
 
 // ---- multi-GPU ---------------------------------------------------------------

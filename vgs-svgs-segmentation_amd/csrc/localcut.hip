@@ -661,15 +661,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     vgs_status sn = vgs_stage_nearlists(c);
     if (sn != VGS_OK) return sn;
   }
-  const int a1_max = getenv("VGS_A1MAX") ? atoi(getenv("VGS_A1MAX")) : 4;
+  const int a1_max = c->K.a1_max;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
                      0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, a1_max, ids_a, ids_b, ids_c,
                      ids_d, ids_a1, d_nabc);
   unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
   VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
 #ifdef VGS_PROF
-  if (const char* oc = getenv("VGS_ONLY_CLASS")) {  // diagnostics: run a single class (results are incomplete)
-    for (int k = 0; k < LC_NCLASS; ++k) if (k != atoi(oc)) nabc[k] = 0;
+  if (c->K.only_class >= 0) {  // diagnostics: run a single class (results are incomplete)
+    for (int k = 0; k < LC_NCLASS; ++k) if (k != c->K.only_class) nabc[k] = 0;
   }
 #endif
   unsigned long long* cnt = (unsigned long long*)c->counters.p;
@@ -696,17 +696,17 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     LP.ctab = c->lc_ctab.p; LP.ctab_scale = c->lc_ctab_scale;
     WP.lc = LP;
   }
-  WP.shell0 = getenv("VGS_SHELL0") ? (float)atof(getenv("VGS_SHELL0")) : 8.0f;
+  WP.shell0 = c->K.shell0;
   WP.grow = 2.25f;
-  WP.cap_frac = getenv("VGS_CAPFRAC") ? (float)atof(getenv("VGS_CAPFRAC")) : 0.7f;
-  WP.dbg_stop = getenv("VGS_DBG_STOP") ? atoi(getenv("VGS_DBG_STOP")) : 0;
-  WP.max_rounds = getenv("VGS_ROUNDS") ? atoi(getenv("VGS_ROUNDS")) : 6;
-  WP.dbg_max_m = getenv("VGS_DBG_MAXM") ? atoi(getenv("VGS_DBG_MAXM")) : 0;
+  WP.cap_frac = c->K.cap_frac;
+  WP.dbg_stop = c->K.dbg_stop;
+  WP.max_rounds = c->K.max_rounds;
+  WP.dbg_max_m = c->K.dbg_max_m;
   VGS_HIP_TRY(c, c->lc_pending.ensure((size_t)U)); VGS_HIP_TRY(c, c->lc_defer.ensure((size_t)U));
   VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   WP.pending = c->lc_pending.p;
-  const bool dense = !getenv("VGS_NO_DENSE");   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
-  WP.near_min_own = getenv("VGS_NEARMINOWN") ? atoi(getenv("VGS_NEARMINOWN")) : 7;
+  const bool dense = !c->K.no_dense;   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
+  WP.near_min_own = c->K.near_min_own;
   WP.ho_bins = dense ? LW_HO_BINS : 1;
   WP.ho_stride = (int)U;
   {
@@ -722,7 +722,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   // general kernel: neighbour records in LDS up to SMALL_M, from L2 beyond.  With n_dev the list length is read on the
   // device (fixed grid of nw workgroups starting at list position `offset`); otherwise nw is the length.
-  auto launch_block = [&](const uint32_t* ids, unsigned int nw, bool mid, const unsigned int* n_dev = nullptr, unsigned int offset = 0) -> vgs_status {
+  auto launch_block = [&](hipStream_t strm, const uint32_t* ids, unsigned int nw, bool mid, const unsigned int* n_dev = nullptr, unsigned int offset = 0) -> vgs_status {
     if (nw == 0) return VGS_OK;
     const int arg_n = n_dev ? (int)offset : (int)nw;
     if (mid) {
@@ -730,13 +730,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       auto kern = k_localcut<SMALL_M, SMALL_CAP, false>;
       const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, strm, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                          c->node.p, LP, c->conn.p, cnt, c->evals.p);
     } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+      hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, strm, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                          c->node.p, LP, c->conn.p, cnt, c->evals.p);
     }
     return VGS_OK;
@@ -754,6 +754,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // The heavy classes (few, long-running wavefronts with a large LDS footprint) run on two side streams and are
   // launched BEFORE the bulk class: once the bulk class has filled every CU's LDS with its small workgroups a 35 KB
   // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).
+  // from here on the side streams carry work of this run: a failure below must make the next run wait for them
+  c->lc_tail.open = true; c->lc_tail.dense = dense; c->lc_tail.grid_f = 0; c->lc_tail.grid_g = GRID_G; c->lc_tail.tail_ms = 0.f;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[2], 0));
@@ -771,8 +773,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows both C and D
     }
-    hipStream_t main_stream = c->stream;
-    c->stream = c->stream2;  // launch_block uses c->stream
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf);
@@ -781,12 +781,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     vgs_status st = VGS_OK;
     const unsigned int ncd = nabc[2] + nabc[3];
     if (ncd > 0) {
-      if (!dense) st = launch_block(ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
+      if (!dense) st = launch_block(c->stream2, ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
       else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
         hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(ncd < 4 * GRID_G ? ncd : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
                            c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p);
     }
-    c->stream = main_stream;
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
@@ -815,16 +814,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
   {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
-    hipStream_t main_stream = c->stream;
-    c->stream = c->stream3;  // launch_block uses c->stream
     vgs_status st = VGS_OK;
     if (!dense) {
-      st = launch_block(ids_f, grid_f, true, d_nf, 0);
+      st = launch_block(c->stream3, ids_f, grid_f, true, d_nf, 0);
     } else if (grid_f > 0) {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p);
     }
-    c->stream = main_stream;
     if (st != VGS_OK) return st;
     VGS_HIP_TRY(c, hipEventRecord(c->ev[4], c->stream3));
   }
@@ -832,13 +828,14 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
   if (nabc[3] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[12], 0));
-  if (getenv("VGS_NO_OVERLAP")) {   // diagnostics: the merge stage starts behind the hand-over kernels
+  if (c->K.no_overlap) {   // diagnostics: the merge stage starts behind the hand-over kernels
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
-  c->lc_tail.open = true; c->lc_tail.grid_f = grid_f; c->lc_tail.grid_g = GRID_G;
+  c->lc_tail.grid_f = grid_f;
   for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));   // end of the stage's main-stream work (vgs_localcut_finish measures the tail behind it)
   c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
   c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
   VGS_HIP_TRY(c, hipGetLastError());
@@ -897,7 +894,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
                                (unsigned int)(hc[11] >> 32)};
   const unsigned int nf = nfg[0] + nfg[1];
   if (n_deferred) *n_deferred = (unsigned int)(hc[13] & 0xffffffffull);
-  const bool dense = !getenv("VGS_NO_DENSE");
+  const bool dense = c->lc_tail.dense;   // as the launch half of the stage saw it
   const unsigned int nf2 = (unsigned int)(hc[12] & 0xffffffffull), ng2 = (unsigned int)(hc[12] >> 32);   // sent on by the dense kernels
   {
     vgs_status st = VGS_OK;
@@ -928,7 +925,8 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   c->times[VGS_T_LOCALCUT_KERNEL] = kms;
   VGS_HIP_TRY(c, hipEventElapsedTime(&kms, c->ev[10], c->ev[11]));
   c->times[VGS_T_LOCALCUT_BULK] = kms;
-  if (getenv("VGS_DEBUG") && nfg[0] > 0) {
+  if (hipEventElapsedTime(&kms, c->ev[13], c->ev[7]) == hipSuccess && kms > 0.f) c->lc_tail.tail_ms = kms;
+  if (c->K.debug && nfg[0] > 0) {
     std::vector<uint32_t> idf(nfg[0]), ev((size_t)U), ac((size_t)U);
     {
       const unsigned int nb4[4] = {(unsigned int)(hc[14] & 0xffffffffull), (unsigned int)(hc[14] >> 32), (unsigned int)(hc[15] & 0xffffffffull), (unsigned int)(hc[15] >> 32)};
@@ -957,7 +955,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
       fprintf(stderr, "\n");
     }
   }
-  if (getenv("VGS_DEBUG")) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
+  if (c->K.debug) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
 #ifdef VGS_PROF
   {
     unsigned long long lp[2][16];

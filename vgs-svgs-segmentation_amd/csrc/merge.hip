@@ -16,6 +16,7 @@
 //     which the reference discovers clusters (VS:2064).
 #include <cstring>
 #include <string.h>
+#include <utility>
 
 #include <rocprim/rocprim.hpp>
 
@@ -380,6 +381,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   const int64_t V = c->V, U = c->U, N = c->N;
   c->bnd_unique = -1;  // tile protocol results belong to the previous segmentation
   c->counts[VGS_N_CLUSTERS] = 0; c->counts[VGS_N_KEPT] = 0; c->counts[VGS_N_ISOLATED] = 0; c->counts[VGS_N_REATTACHED] = 0;
+  // an asynchronous download (vgs_get_point_labels_async) may still read the last labels: this run writes the other buffer
+  if (c->d2h_open && c->d2h_src == c->pt_label.p) std::swap(c->pt_label, c->pt_label_alt);
   VGS_HIP_TRY(c, c->pt_label.ensure(N > 0 ? N : 1));
   if (V == 0) {
     if (N > 0) VGS_HIP_TRY(c, hipMemsetAsync(c->pt_label.p, 0xff, N * sizeof(int32_t), c->stream));
@@ -461,7 +464,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
-  // cluster filter + labels
+  // cluster filter + labels (VGS_T_LABELS: this tail of the stage, measured on its own; it is part of VGS_T_MERGE)
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));   // ev[2], ev[3]: free again once vgs_localcut_finish has run
   uint32_t* keep_flag = c->head_flag.p;  // >= N >= V entries, free after features
   VGS_HIP_TRY(c, c->head_flag.ensure(V + 1));
   keep_flag = c->head_flag.p;
@@ -476,10 +480,12 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
                      (unsigned int*)(mcnt + 3));
   hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
                      N, c->pt_label.p);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
   // one read-back: words 1-3 = re-attachments, roots, kept segments
   uint64_t hm[4] = {0, 0, 0, 0};
   VGS_READBACK(c, hm, mcnt, sizeof(hm));
+  { float lms = 0.f; if (hipEventElapsedTime(&lms, c->ev[2], c->ev[3]) == hipSuccess) c->times[VGS_T_LABELS] = lms; }
   const unsigned int n_roots = (unsigned int)hm[2];
   if (U > 0 && n_cand > 0) n_succ = (unsigned int)hm[1];
   c->counts[VGS_N_REATTACHED] = n_succ;

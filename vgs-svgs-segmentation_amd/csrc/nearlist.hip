@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
 // and the neighbourhood ball fits the consumer's offset map
 vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   c->nl_enabled = false;
-  if (c->P.method != 2 || !c->adj_pruned || !c->adj_have_gtab || c->U == 0 || getenv("VGS_NO_NEAR")) return VGS_OK;
+  if (c->P.method != 2 || !c->adj_pruned || !c->adj_have_gtab || c->U == 0 || c->K.no_near) return VGS_OK;
   const double rr = (double)c->P.graph_size / (double)c->P.voxel_size;
   // some offset reaches NL_BALL + 1 (adjacency.hip: lim2): the one-wavefront classes cannot use the lists then (their offset
   // map ends at NL_BALL), the multi-wavefront classes look partners up in a hash and still can

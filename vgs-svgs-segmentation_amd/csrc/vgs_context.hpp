@@ -72,8 +72,29 @@ struct Epoch {  // keys of points with index >= first use this box
 
 enum Stage { ST_NONE = 0, ST_POINTS = 1, ST_VOXELS = 2, ST_FEATURES = 3, ST_ADJACENCY = 4, ST_SEGMENTED = 5 };
 
+// Diagnostics / schedule-tuning knobs (none changes a result).  Read from the environment ONCE, when the context is created
+// (vgs_read_env_knobs): a stage never calls getenv, so a host that changes its environment between two calls cannot make the
+// two halves of a stage disagree.
+struct VgsKnobs {
+  int a1_max = 4;            // VGS_A1MAX: own near-list length up to which a class-A voxel goes first
+  float shell0 = 8.0f;       // VGS_SHELL0
+  float cap_frac = 0.7f;     // VGS_CAPFRAC
+  int dbg_stop = 0;          // VGS_DBG_STOP
+  int max_rounds = 6;        // VGS_ROUNDS
+  int dbg_max_m = 0;         // VGS_DBG_MAXM
+  int near_min_own = 7;      // VGS_NEARMINOWN
+  int fv_blocks = 512;       // VGS_FV_BLOCKS
+  int only_class = -1;       // VGS_ONLY_CLASS (-DVGS_PROF builds)
+  bool no_dense = false;     // VGS_NO_DENSE
+  bool no_overlap = false;   // VGS_NO_OVERLAP
+  bool no_near = false;      // VGS_NO_NEAR
+  bool no_adjmasks = false;  // VGS_NO_ADJMASKS
+  bool debug = false;        // VGS_DEBUG
+};
+
 struct vgs_ctx {
   vgs_params P;
+  VgsKnobs K;
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // side streams: the heavy local-cut classes overlap the light one
@@ -84,8 +105,18 @@ struct vgs_ctx {
   void* pin = nullptr;   // 4 KB of pinned host memory: small read-backs land here (a pageable destination makes the copy blocking and slower)
 
   // input
-  const float* xyz = nullptr;  // device pointer (owned_xyz or caller's)
-  DevBuf<float> owned_xyz;
+  const float* xyz = nullptr;  // device pointer (one of xyz_buf or the caller's)
+  // two input buffers: while the stages run on one cloud, vgs_stage_points copies the next one into the other on the
+  // upload stream (a sequence of clouds; the points are read by the voxelize stage only)
+  DevBuf<float> xyz_buf[2];
+  int xyz_cur = 0;
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // copy streams: uploads of the next cloud, downloads of the last labels
+  hipEvent_t ev_h2d = nullptr, ev_d2h = nullptr;
+  bool staged = false;         // a cloud is on its way into xyz_buf[1 - xyz_cur]
+  int64_t staged_n = 0;
+  int staged_stride = 12;
+  bool d2h_open = false;       // vgs_get_point_labels_async has a copy in flight ...
+  const int32_t* d2h_src = nullptr;   // ... out of this buffer
   int64_t N = 0;
   int stride_f = 3;
 
@@ -151,7 +182,7 @@ struct vgs_ctx {
   // touch: per used voxel "handed over, connect row not final yet", the rows put off, and what vgs_localcut_finish needs
   DevBuf<uint8_t> lc_pending;
   DevBuf<uint32_t> lc_defer;
-  struct { bool open = false; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; } lc_tail;
+  struct { bool open = false; bool dense = true; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
   int64_t lc_diag[8] = {0};   // vgs_get_schedule_counters
   DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
   float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;
@@ -162,7 +193,8 @@ struct vgs_ctx {
   DevBuf<uint32_t> parent;
   DevBuf<uint32_t> csz, kept_rank;
   DevBuf<int32_t> vox_label;
-  DevBuf<int32_t> pt_label;
+  DevBuf<int32_t> pt_label;      // labels of the current cloud
+  DevBuf<int32_t> pt_label_alt;  // the buffer the next run writes while an asynchronous download still reads pt_label
   DevBuf<uint64_t> counters;   // device-side counters (pairs, flags)
   DevBuf<uint32_t> work_ids;   // scratch index lists
 
@@ -222,6 +254,8 @@ static inline vgs_status vgs_readback(vgs_ctx* c, void* dst, const void* src_dev
   return VGS_OK;
 }
 #define VGS_READBACK(ctx, dst, src, bytes) do { vgs_status _s = vgs_readback((ctx), (dst), (src), (bytes)); if (_s != VGS_OK) return _s; } while (0)
+
+void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only
 
 // stage implementations (one .hip file each)
 vgs_status vgs_stage_voxelize(vgs_ctx* c);

@@ -271,7 +271,7 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   const int pinned = (c->grid_pinned && record_epochs) ? 1 : 0;
   // few enough threads that the scan moves through the cloud front to back (a growth step is found within the first
   // trip or two: the points come in random order), enough to keep the HBM pipes full on the one scan that reads everything
-  const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, getenv("VGS_FV_BLOCKS") ? atoi(getenv("VGS_FV_BLOCKS")) : 512));
+  const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, (int64_t)c->K.fv_blocks));
   for (int batch = 0; batch < 64; ++batch) {
     // a scene grows its box about log2(extent / voxel) times; pairs queued after the last growth return at once
     for (int k = 0; k < 8; ++k) {

@@ -224,6 +224,10 @@ class TiledSegmenter:
         # of them may come back -1 (seen with generated tiles whose objects reach over the border; tools/fuzz_tiles.py
         # partitions by region).  n_outside says how many there are.
         self.n_outside = int(((x < lo[0]) | (x >= hi[0]) | (y < lo[1]) | (y >= hi[1])).sum())
+        if self.n_outside > 0:
+            import warnings
+            warnings.warn(f"rank {self.rank}: {self.n_outside} of {xyz_host.shape[0]} points lie outside this rank's region; a few of "
+                          "them may come back unlabelled (-1): partition the cloud by tile_regions() before loading", RuntimeWarning)
         near = (x < lo[0] + h) | (x >= hi[0] - h) | (y < lo[1] + h) | (y >= hi[1] - h)
         strips = all_gather_varlen(self.dist, np.ascontiguousarray(xyz_host[near]).reshape(-1), self.coll_device)
         extra = []
