@@ -149,12 +149,26 @@ vgs_status vgs_get_point_voxel(vgs_ctx* ctx, int32_t* voxel_of_point /* N, -1 = 
 /* per-node attributes (voxels for VGS, supervoxels for SVGS): centroid 3*V, normal 3*V, eigen 8*V, used V */
 vgs_status vgs_get_attributes(vgs_ctx* ctx, float* centroid, float* normal, float* eigen8, uint8_t* used);
 /* ragged lists, two-call protocol: pass idx == NULL to get offsets (n_nodes+1, int64) and the total first.
- * which: 0 adjacency (getOneVoxelAdjacency order, VS:268; used nodes only), 1 connect lists after the local cut,
+ * which: 0 adjacency (getOneVoxelAdjacency order, VS:268; every voxel, used or not, with every neighbour, as findAllVoxelAdjacency
+ *        builds them VS:236-263 -- computed on request, the hot path keeps only what the cuts read), 1 connect lists after the local cut,
  *        2 after crossValidation (VS:2111), 3 after closestCheck (VS:2181) */
 vgs_status vgs_get_lists(vgs_ctx* ctx, int32_t which, int64_t* offsets, int32_t* idx);
+/* Element order of the connect lists (which >= 1) and of getClusterIdx.  VGS_ORDER_VOXEL_ID: members in the order of the
+ * adjacency row / ascending voxel id -- what the hot path keeps (a flag per adjacency slot).  VGS_ORDER_REFERENCE: the
+ * reference's own order: cutGraphSegmentation returns its vertex list in merge-history order (every merge appends the absorbed
+ * segment's vertices, VS:1986-1998, 2003-2026), crossValidation filters it in place, closestCheck appends (VS:2293-2294).
+ * Computed on request by replaying the scan inside every list that was found (csrc/cutorder.hip); ties as the oracle's lean
+ * flavour (the reference's std::sort of both orientations of a pair leaves them unspecified). */
+enum { VGS_ORDER_VOXEL_ID = 0, VGS_ORDER_REFERENCE = 1 };
+vgs_status vgs_get_lists_ordered(vgs_ctx* ctx, int32_t which, int32_t order, int64_t* offsets, int32_t* idx);
 /* voxels_adjacency_idx_[v][0] (VS:253): the number of neighbours of every node inside graph_size, itself included; 0 for a
  * node that has no list (unused voxels, see `which` above) */
 vgs_status vgs_get_adjacency_counts(vgs_ctx* ctx, int32_t* n_all /* n_nodes */);
+/* The affinity matrix buildAdjacencyGraph fills for one node (VS:1796-1910; SS twin): weights[a * n + b] =
+ * distanceWeight(measuringDistance(ids[a], ids[b])), ids = the node's stored adjacency row (the used neighbours when unused
+ * voxels are inert, every neighbour otherwise), ids[0] = the node itself.  Two-call protocol: ids == NULL returns n (0 for a
+ * node without a local graph).  Diagnostics / parity tests: the hot path never materialises this matrix. */
+vgs_status vgs_get_local_weights(vgs_ctx* ctx, int32_t node_id, int32_t* n, int32_t* ids, float* weights);
 vgs_status vgs_get_node_labels(vgs_ctx* ctx, int32_t* component_root /* V: smallest node id of its cluster */,
                                int32_t* kept_label /* V: index into kept clusters or -1 */);
 vgs_status vgs_get_point_labels(vgs_ctx* ctx, int32_t* labels /* N host; -1 = dropped */);
@@ -171,7 +185,6 @@ vgs_status vgs_get_clusters(vgs_ctx* ctx, int64_t* offsets, int32_t* point_idx);
  * of recursionSearch over the final connect lists with the seed appended LAST (VS:2032-2053, 2064-2080; SS:2079-2103), the
  * points of each node in ascending index (VS:981-999; SS:2109-2126) -- element for element what getClusterIdx() holds.
  * (Output formatting: the walk runs on the host over the downloaded lists.) */
-enum { VGS_ORDER_VOXEL_ID = 0, VGS_ORDER_REFERENCE = 1 };
 vgs_status vgs_get_clusters_ordered(vgs_ctx* ctx, int32_t order, int64_t* offsets, int32_t* point_idx);
 
 /* ---- multi-GPU support (spatial tiles) -------------------------------------- */

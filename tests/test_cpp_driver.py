@@ -72,7 +72,7 @@ def test_task_file_front_end(gpu, tmp_path, method):
         assert svox == c["supervoxels"] and svox > 0
     else:
         assert voxels == c["voxels"]
-    off, idx = eng.clusters()
+    off, idx = eng.clusters("reference")   # the drivers save getClusterIdx(): the reference's own element order
     assert labelled == len(idx)
     # the output name gets a .pcd ending (test:78 / test:163); points are listed cluster by cluster, one colour each
     name = "Town_Test_VGS.pcd" if method == 2 else "Town_Test_SVGS.pcd"

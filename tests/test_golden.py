@@ -9,7 +9,9 @@ import pytest
 
 from helpers import canonical_labels, partition_agreement
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+_ALL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD = [p for p in _ALL if not os.path.basename(p).startswith("svgs_")]       # method 2 (VGS)
+GOLD_SVGS = [p for p in _ALL if os.path.basename(p).startswith("svgs_")]      # method 3 (SVGS from a supervoxel labelling)
 
 
 def _params(g):
@@ -74,4 +76,71 @@ def test_gpu_reproduces_golden(gpu, path):
     # P2 against the RefMath labels
     assert partition_agreement(eng.point_labels(), g["point_label_ref"]) >= 0.995
     off, _ = eng.lists("adjacency")
-    np.testing.assert_array_equal(np.diff(off).astype(np.int32)[used], g["adj_len"][used])
+    np.testing.assert_array_equal(np.diff(off).astype(np.int32), g["adj_len"])   # every voxel, used or not (VS:236-263)
+
+
+# ---- SVGS (method 3): supervoxel labelling -> attributes -> neighbours -> local cuts -> merge (SS:279-421) ----------------
+@pytest.mark.parametrize("path", GOLD_SVGS, ids=[os.path.basename(p)[:-4] for p in GOLD_SVGS])
+def test_oracle_reproduces_svgs_golden(oracle, path):
+    g = np.load(path)
+    for math, tag in ((0, "ref"), (1, "dev")):
+        r = oracle.run_svgs_from_labels(g["xyz"], g["sv_label"], int(g["max_label"]), oracle.svgs_params(math=math, flavour=1, **_params(g)))
+        off, idx = r.lists("sv_points")
+        np.testing.assert_array_equal(off, g["sv_start"])
+        np.testing.assert_array_equal(idx, g["sv_point_idx"])
+        nd = r.nodes()
+        np.testing.assert_array_equal(nd["centroid"].view(np.uint32), g[f"centroid_{tag}"].view(np.uint32))
+        aoff, _ = r.lists("adjacency")
+        np.testing.assert_array_equal(np.diff(aoff).astype(np.int32), g["adj_len"])
+        if math == 1:
+            np.testing.assert_array_equal(nd["normal"].view(np.uint32), g["normal_dev"].view(np.uint32))
+            np.testing.assert_array_equal(nd["eigen"].view(np.uint32), g["eigen_dev"].view(np.uint32))
+            np.testing.assert_array_equal(r.labels()[0], g["point_label_dev"])
+            assert [r.clusters_num, r.kept_clusters] == g["clusters_dev"].tolist()
+        else:
+            np.testing.assert_allclose(nd["eigen"], g["eigen_ref"], atol=1e-5)
+            assert partition_agreement(r.labels()[0], g["point_label_ref"]) > 0.999
+    # the two data flows of the oracle agree on the partition in the reference's arithmetic
+    assert partition_agreement(g["point_label_ref"], g["point_label_ref_faithful"]) > 0.995
+    if "vccs" in os.path.basename(path):   # the labelling itself is the oracle's VCCS restatement of this repo's stage
+        lab, mx = oracle.vccs(g["xyz"], oracle.svgs_params(**_params(g)))
+        np.testing.assert_array_equal(lab, g["sv_label"])
+        assert mx == int(g["max_label"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD_SVGS, ids=[os.path.basename(p)[:-4] for p in GOLD_SVGS])
+def test_gpu_reproduces_svgs_golden(gpu, path):
+    g = np.load(path)
+    p = gpu.default_params(3, **_params(g))
+    eng = gpu.Engine(p)
+    eng.set_points(g["xyz"])
+    eng.set_supervoxel_labels(g["sv_label"], int(g["max_label"]))
+    eng.svgs_segment()
+    t = eng.voxel_table()
+    np.testing.assert_array_equal(t["start"], g["sv_start"].astype(np.int32))
+    np.testing.assert_array_equal(t["point_idx"], g["sv_point_idx"])
+    a = eng.attributes()
+    for k in ("centroid", "normal", "eigen"):       # bit-exact against the DevMath vectors
+        np.testing.assert_array_equal(a[k].view(np.uint32), g[f"{k}_dev"].view(np.uint32))
+    np.testing.assert_array_equal(eng.point_labels(), g["point_label_dev"])
+    root, _ = eng.node_labels()
+    np.testing.assert_array_equal(canonical_labels(root), canonical_labels(g["node_cluster_dev"]))
+    c = eng.counts()
+    assert [c["clusters"], c["kept"]] == g["clusters_dev"].tolist()
+    off, _ = eng.lists("adjacency")
+    np.testing.assert_array_equal(np.diff(off).astype(np.int32), g["adj_len"])
+    # P1 against the RefMath vectors, P2 against the RefMath labels of both data flows (lean, faithful)
+    np.testing.assert_allclose(a["centroid"], g["centroid_ref"], atol=1e-4)
+    cosang = (a["normal"] * g["normal_ref"]).sum(1)
+    assert (np.arccos(np.clip(cosang, -1, 1)) < 1e-3).mean() > 0.999
+    assert np.nanmax(np.abs(a["eigen"] - g["eigen_ref"])) < 2e-3
+    assert partition_agreement(eng.point_labels(), g["point_label_ref"]) >= 0.995
+    assert partition_agreement(eng.point_labels(), g["point_label_ref_faithful"]) >= 0.995
+    if "vccs" in os.path.basename(path):             # the engine's own supervoxel stage gives this labelling
+        e2 = gpu.Engine(p)
+        e2.set_points(g["xyz"])
+        e2.supervoxels()
+        lab, mx = e2.supervoxel_labels()
+        np.testing.assert_array_equal(lab, g["sv_label"])
+        assert mx == int(g["max_label"])

@@ -25,6 +25,8 @@ CASES = [
     ("plane_r10", lambda v: v.scenes.pc_scene(40_000), dict(voxel_size=0.05, graph_size=0.5), lambda a, bc, d: bc > 1000),
     ("slab_r10", lambda v: _slab(60_000, 0.85, 0.11, 7), dict(voxel_size=0.05, graph_size=0.5), lambda a, bc, d: d > 100),
     ("slab_r6", lambda v: _slab(120_000, 2.0, 0.25, 8), dict(voxel_size=0.08, graph_size=0.5), lambda a, bc, d: bc > 300),
+    # BASELINE config 2's own parameters (voxel 0.05 m, graph 0.5 m) on its scene at more than 100 k points
+    ("c2_110k", lambda v: v.scenes.pc_scene(110_000), dict(voxel_size=0.05, graph_size=0.5), lambda a, bc, d: bc > 4000),
 ]
 
 

@@ -61,8 +61,9 @@ def test_adjacency_exact_order(run):
     go, gi = eng.lists("adjacency")
     ro, ri = ref.lists("adjacency")
     gl, rl = ragged_lists(go, gi), ragged_lists(ro, ri)
-    for v in np.nonzero(used)[0]:
+    for v in range(len(rl)):   # every voxel has a list, used or not (findAllVoxelAdjacency, VS:236-263)
         assert gl[v] == rl[v], f"voxel {v}: adjacency differs"
+    assert (~used).any() and all(len(rl[v]) > 0 for v in np.nonzero(~used)[0][:50])
     assert eng.counts()["adj"] == sum(len(rl[v]) for v in np.nonzero(used)[0])
 
 
@@ -97,10 +98,11 @@ def test_cluster_index_lists_in_reference_order(run):
     seed appended last (voxel_segmentation.h:2032-2053, 2064-2080), points per node ascending (VS:981-999).  No sorting on
     either side.  The walk depends on the ORDER of the final connect lists, so that is compared first."""
     eng, ref = run["eng"], run["ref"]
-    go, gi = eng.lists("connect_final")
-    ro, ri = ref.lists("connect_final")
-    np.testing.assert_array_equal(go, ro)
-    np.testing.assert_array_equal(gi, ri)
+    for which in ("connect_cut", "connect_cross", "connect_final"):   # merge-history order of the local cut, kept by the later steps
+        go, gi = eng.lists(which, "reference")
+        ro, ri = ref.lists(which)
+        np.testing.assert_array_equal(go, ro)
+        np.testing.assert_array_equal(gi, ri)
     co, ci = eng.clusters("reference")
     rco, rci = ref.lists("clusters_points")
     np.testing.assert_array_equal(co, rco)
@@ -113,12 +115,47 @@ def test_cluster_index_lists_in_reference_order(run):
 def test_partition_vs_refmath_faithful(run, oracle):
     """P2: against the oracle in the reference's own arithmetic (libm, promotions) and data flow
     (n x n matrix, std::sort): >= 99.5 % of points in matching segments."""
-    if run["name"] != "town":
-        pytest.skip("faithful flavour is slow; one scene is enough")
     ref = oracle.run_vgs(run["xyz"], oracle_params(oracle, run["p"], math=0, flavour=0))
     pl_ref, _ = ref.labels()
     agree = partition_agreement(run["eng"].point_labels(), pl_ref)
     assert agree >= 0.995, agree
+
+
+def test_pair_weights_vs_refmath(run, oracle):
+    """SURVEY 8c P1, directly: the affinity matrices buildAdjacencyGraph fills (voxel_segmentation.h:1796-1910) for a
+    spread of voxels, HIP (all-float DevMath) against the oracle's RefMath weight (libm, the C++ promotions of the
+    reference's expressions) on the SAME node attributes -- |dw| <= 1e-5, NaN where the reference has NaN.  This leg shares
+    no arithmetic with the device (csrc/vgs_math.h is not involved on the oracle side)."""
+    eng = run["eng"]
+    a = eng.attributes()
+    used = np.nonzero(a["used"])[0]
+    rp = oracle_params(oracle, run["p"], math=0, flavour=0)
+    rng = np.random.default_rng(3)
+
+    def n16(v):
+        x = np.zeros(16, dtype=np.float32)
+        x[0:3], x[3:6], x[6:14] = a["centroid"][v], a["normal"][v], a["eigen"][v]
+        x[14], x[15] = (8.0, 1.0) if a["used"][v] else (1.0, 0.0)   # number of eigen features the node carries (oracle Node::nf), used flag
+        return x
+
+    worst, n_pairs, n_nan = 0.0, 0, 0
+    for v in rng.choice(used, size=min(12, used.size), replace=False):
+        ids, W = eng.local_weights(int(v))
+        assert ids.size > 0 and ids[0] == v                  # radiusSearch returns the voxel itself first
+        sel = rng.choice(ids.size, size=min(24, ids.size), replace=False)
+        nodes = {int(k): n16(int(ids[k])) for k in sel}
+        for i in sel:
+            for j in sel:
+                w_ref = oracle.pair_weight(nodes[int(i)], nodes[int(j)], rp)
+                w_gpu = float(W[i, j])
+                if w_ref != w_ref or w_gpu != w_gpu:
+                    assert (w_ref != w_ref) == (w_gpu != w_gpu), (int(ids[i]), int(ids[j]), w_gpu, w_ref)
+                    n_nan += 1
+                    continue
+                worst = max(worst, abs(w_gpu - w_ref))
+                n_pairs += 1
+    assert n_pairs > 1000
+    assert worst <= 1e-5, worst
 
 
 def test_deterministic(run, gpu):

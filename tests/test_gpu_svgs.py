@@ -81,10 +81,11 @@ def test_cluster_index_lists_in_reference_order(run):
     """getClusterIdx element for element (supervoxel_segmentation.h:2079-2126): DFS order of the supervoxels with the seed
     last, each supervoxel's points in ascending index; no sorting on either side."""
     eng, ref = run["eng"], run["ref"]
-    go, gi = eng.lists("connect_final")
-    ro, ri = ref.lists("connect_final")
-    np.testing.assert_array_equal(go, ro)
-    np.testing.assert_array_equal(gi, ri)
+    for which in ("connect_cut", "connect_cross", "connect_final"):   # merge-history order of the local cut, kept by the later steps
+        go, gi = eng.lists(which, "reference")
+        ro, ri = ref.lists(which)
+        np.testing.assert_array_equal(go, ro)
+        np.testing.assert_array_equal(gi, ri)
     co, ci = eng.clusters("reference")
     rco, rci = ref.lists("clusters_points")
     np.testing.assert_array_equal(co, rco)

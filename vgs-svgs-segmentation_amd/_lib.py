@@ -82,7 +82,9 @@ SYMBOLS = [
     ("vgs_get_point_voxel", C.c_int, [_P, _P]),
     ("vgs_get_attributes", C.c_int, [_P, _P, _P, _P, _P]),
     ("vgs_get_lists", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("vgs_get_lists_ordered", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     ("vgs_get_adjacency_counts", C.c_int, [_P, _P]),
+    ("vgs_get_local_weights", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P]),
     ("vgs_get_node_labels", C.c_int, [_P, _P, _P]),
     ("vgs_get_point_labels", C.c_int, [_P, _P]),
     ("vgs_get_point_labels_async", C.c_int, [_P, _P]),

@@ -188,13 +188,15 @@ class Engine:
 
     LISTS = {"adjacency": 0, "connect_cut": 1, "connect_cross": 2, "connect_final": 3}
 
-    def lists(self, which):
+    def lists(self, which, order="voxel_id"):
+        """Ragged lists as (offsets, ids).  order="reference": the connect lists element for element as the reference holds them
+        (merge-history order of the local cut, csrc/cutorder.hip); "voxel_id": members in adjacency-row order (the hot path's)."""
         V = self.counts()["voxels"]
         off = np.zeros(V + 1, dtype=np.int64)
-        w = self.LISTS[which]
-        self._ck(self._L.vgs_get_lists(self._h, w, _ptr(off), None))
+        w, o = self.LISTS[which], self.ORDERS[order]
+        self._ck(self._L.vgs_get_lists_ordered(self._h, w, o, _ptr(off), None))
         idx = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
-        self._ck(self._L.vgs_get_lists(self._h, w, _ptr(off), _ptr(idx)))
+        self._ck(self._L.vgs_get_lists_ordered(self._h, w, o, _ptr(off), _ptr(idx)))
         return off, idx[:int(off[-1])]
 
     def adjacency_counts(self):
@@ -202,6 +204,16 @@ class Engine:
         out = np.zeros(self.counts()["voxels"], dtype=np.int32)
         self._ck(self._L.vgs_get_adjacency_counts(self._h, _ptr(out)))
         return out
+
+    def local_weights(self, node_id):
+        """(ids, W): the n x n affinity matrix of node_id's local graph over its stored adjacency row (W[a, b]: ids[a] first)."""
+        n = C.c_int32(0)
+        self._ck(self._L.vgs_get_local_weights(self._h, int(node_id), C.byref(n), None, None))
+        ids = np.zeros(max(n.value, 1), dtype=np.int32)
+        W = np.zeros((max(n.value, 1), max(n.value, 1)), dtype=np.float32)
+        if n.value:
+            self._ck(self._L.vgs_get_local_weights(self._h, int(node_id), C.byref(n), _ptr(ids), _ptr(W)))
+        return ids[:n.value], W[:n.value, :n.value]
 
     def node_labels(self):
         V = self.counts()["voxels"]

@@ -428,8 +428,11 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
 }
 
 // full = true: every neighbour (the reference's lists); false: used neighbours only (hot path)
-vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2) {
-  const int64_t U = c->U;
+// ids / n_ids (optional): the rows to build instead of the used voxels' (any voxel ids; row k belongs to ids[k])
+vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2, const uint32_t* ids,
+                             int64_t n_ids) {
+  const int64_t U = ids ? n_ids : c->U;
+  const uint32_t* row_ids = ids ? ids : c->used_ids.p;
   const float res_f = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
   uint16_t* gt = nullptr;   // group tables only for the rows the pipeline keeps
@@ -438,7 +441,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     gt = c->adj_gtab.p;
   }
 #define LAUNCH_ADJ(CAPV, FULLV, GRID, REDO, NREDO, REDO_OUT)                                                                 \
-  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(GRID), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,            \
+  hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(GRID), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,            \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
                      c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
@@ -448,7 +451,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
     VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
 #define LAUNCH_ADJM(NBV)                                                                                                          \
-    hipLaunchKernelGGL((k_adjacency_masks<240, NBV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, c->used_ids.p, U,  \
+    hipLaunchKernelGGL((k_adjacency_masks<240, NBV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,  \
                        (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
                        out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p)
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);

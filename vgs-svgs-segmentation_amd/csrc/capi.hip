@@ -1,6 +1,7 @@
 // capi.hip -- the C-ABI of include/vgs.h: parameter surface, context lifetime, stage drivers with the
 // reference's call-order contract turned into status codes, result getters (two-call size queries,
 // caller-allocated outputs).  Host code only; kernels live in the stage files.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -506,8 +507,41 @@ vgs_status vgs_get_attributes(vgs_ctx* c, float* centroid, float* normal, float*
 }  // extern "C"
 
 // the per-node lists of vgs_get_lists as host vectors (also the input of the reference-order cluster walk)
-static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::vector<int32_t>>& L) {
+// ordered = true (which >= 1): every list in the reference's own element order, the merge history of the local cut
+// (cutorder.hip); false: the members in the order of the adjacency row
+static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::vector<int32_t>>& L, bool ordered = false) {
   const int64_t V = c->V, U = c->U;
+  if (which == 0 && c->P.method == 2 && U > 0) {
+    // findAllVoxelAdjacency builds a list for EVERY voxel, used or not, with every neighbour (VS:236-263).  The hot path
+    // keeps rows for the used voxels only (and only their used neighbours when unused ones are inert), so the full lists
+    // are built here on request: the general kernel over all voxel ids, a chunk of rows at a time.
+    VGS_HIP_TRY(c, hipSetDevice(c->device));
+    L.assign((size_t)V, {});
+    const int64_t chunk = std::min<int64_t>(V, 65536);
+    DevBuf<uint64_t> fk; DevBuf<uint32_t> fc, fn, fid;
+    VGS_HIP_TRY(c, fk.ensure((size_t)chunk * c->adj_stride)); VGS_HIP_TRY(c, fc.ensure(chunk)); VGS_HIP_TRY(c, fn.ensure(chunk)); VGS_HIP_TRY(c, fid.ensure(chunk));
+    std::vector<uint32_t> ids((size_t)chunk), cnt((size_t)chunk);
+    std::vector<uint64_t> keys((size_t)chunk * c->adj_stride);
+    vgs_status st = VGS_OK;
+    for (int64_t v0 = 0; v0 < V && st == VGS_OK; v0 += chunk) {
+      const int64_t m = std::min(chunk, V - v0);
+      for (int64_t k = 0; k < m; ++k) ids[(size_t)k] = (uint32_t)(v0 + k);
+      if (hipMemcpy(fid.p, ids.data(), (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess) { st = VGS_E_HIP; break; }
+      st = vgs_run_adjacency(c, true, fk.p, fc.p, fn.p, c->adj_r2, fid.p, m);
+      if (st == VGS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = VGS_E_HIP;
+      if (st == VGS_OK && (hipMemcpy(cnt.data(), fc.p, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(keys.data(), fk.p, (size_t)m * c->adj_stride * 8, hipMemcpyDeviceToHost) != hipSuccess)) st = VGS_E_HIP;
+      if (st != VGS_OK) break;
+      for (int64_t k = 0; k < m; ++k) {
+        std::vector<int32_t>& l = L[(size_t)(v0 + k)];
+        l.resize(cnt[(size_t)k]);
+        for (uint32_t q = 0; q < cnt[(size_t)k]; ++q) l[q] = (int32_t)(uint32_t)keys[(size_t)k * c->adj_stride + q];
+      }
+    }
+    fk.release(); fc.release(); fn.release(); fid.release();
+    if (st == VGS_E_HIP) c->err = "vgs_get_lists: full adjacency pass failed";
+    return st;
+  }
   std::vector<uint32_t> used_ids((size_t)U), cnt((size_t)U);
   std::vector<uint64_t> keys;
   std::vector<uint8_t> flag;
@@ -516,20 +550,8 @@ static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::ve
     VGS_HIP_TRY(c, hipSetDevice(c->device));
     VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     keys.resize((size_t)U * c->adj_stride);
-    if (which == 0 && c->adj_pruned && c->P.method == 2) {
-      // getOneVoxelAdjacency wants every neighbour: the hot-path rows keep the used ones only, so run the FULL pass
-      DevBuf<uint64_t> fk; DevBuf<uint32_t> fc, fn;
-      VGS_HIP_TRY(c, fk.ensure(keys.size())); VGS_HIP_TRY(c, fc.ensure(U)); VGS_HIP_TRY(c, fn.ensure(U));
-      vgs_status st = vgs_run_adjacency(c, true, fk.p, fc.p, fn.p, c->adj_r2);
-      if (st == VGS_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = VGS_E_HIP;
-      if (st == VGS_OK && (hipMemcpy(cnt.data(), fc.p, (size_t)U * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                           hipMemcpy(keys.data(), fk.p, keys.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)) st = VGS_E_HIP;
-      fk.release(); fc.release(); fn.release();
-      if (st != VGS_OK) { if (st == VGS_E_HIP) c->err = "vgs_get_lists: full adjacency pass failed"; return st; }
-    } else {
-      VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-      VGS_HIP_TRY(c, hipMemcpy(keys.data(), c->adj_key.p, keys.size() * 8, hipMemcpyDeviceToHost));
-    }
+    VGS_HIP_TRY(c, hipMemcpy(cnt.data(), c->adj_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    VGS_HIP_TRY(c, hipMemcpy(keys.data(), c->adj_key.p, keys.size() * 8, hipMemcpyDeviceToHost));
     if (which >= 1) {
       flag.resize((size_t)U * c->adj_stride);
       const uint8_t* src = c->conn.p + (which >= 2 ? (size_t)U * c->adj_stride : 0);
@@ -542,6 +564,19 @@ static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::ve
   }
   // per-voxel lists; closestCheck appends (VS:2293-2294): i gets its target, the target gets i, in voxel order
   L.assign((size_t)V, {});
+  if (ordered && which >= 1 && U > 0) {
+    std::vector<uint16_t> ord;
+    std::vector<uint32_t> kk;
+    vgs_status so = vgs_cut_order(c, ord, kk);
+    if (so != VGS_OK) return so;
+    for (int64_t u = 0; u < U; ++u) {
+      const uint32_t i = used_ids[u];
+      for (uint32_t r = 0; r < kk[u]; ++r) {
+        const size_t s = (size_t)u * c->adj_stride + ord[(size_t)u * c->adj_stride + r];
+        if (which == 1 || flag[s]) L[i].push_back((int32_t)(uint32_t)keys[s]);   // crossValidation filters in list order (VS:2119-2152)
+      }
+    }
+  } else
   for (int64_t u = 0; u < U; ++u) {
     const uint32_t i = used_ids[u];
     for (uint32_t k = 0; k < cnt[u]; ++k) {
@@ -558,12 +593,16 @@ static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::ve
 extern "C" {
 
 vgs_status vgs_get_lists(vgs_ctx* c, int32_t which, int64_t* offsets, int32_t* idx) {
-  if (!c || !offsets || which < 0 || which > 3) return VGS_E_ARG;
+  return vgs_get_lists_ordered(c, which, VGS_ORDER_VOXEL_ID, offsets, idx);
+}
+
+vgs_status vgs_get_lists_ordered(vgs_ctx* c, int32_t which, int32_t order, int64_t* offsets, int32_t* idx) {
+  if (!c || !offsets || which < 0 || which > 3 || (order != VGS_ORDER_VOXEL_ID && order != VGS_ORDER_REFERENCE)) return VGS_E_ARG;
   const int need = which == 0 ? ST_ADJACENCY : ST_SEGMENTED;
   if (c->stage < need) { c->err = "vgs_get_lists: stage not reached"; return VGS_E_STATE; }
   const int64_t V = c->V;
   std::vector<std::vector<int32_t>> L;
-  vgs_status sb = vgs_build_lists(c, which, L);
+  vgs_status sb = vgs_build_lists(c, which, L, order == VGS_ORDER_REFERENCE);
   if (sb != VGS_OK) return sb;
   int64_t o = 0;
   for (int64_t v = 0; v < V; ++v) {
@@ -660,7 +699,7 @@ vgs_status vgs_get_clusters_ordered(vgs_ctx* c, int32_t order, int64_t* offsets,
   // node order, each in ascending point index (VS:981-999, SS:2109-2126).  The kept clusters keep the order of their seeds,
   // which is the order of the labels (ascending smallest node id).
   std::vector<std::vector<int32_t>> L;
-  vgs_status sb = vgs_build_lists(c, 3, L);
+  vgs_status sb = vgs_build_lists(c, 3, L, true);
   if (sb != VGS_OK) return sb;
   const int64_t V = c->V;
   std::vector<uint32_t> vstart((size_t)V + 1, 0);

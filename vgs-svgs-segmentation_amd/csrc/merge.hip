@@ -377,6 +377,43 @@ static VgsWeightParams make_weight_params_m(const vgs_params& p) {
   return W;
 }
 
+// ------------------------------------------------------------------ diagnostics: the affinity matrix of one local graph
+// W[a * n + b] = distanceWeight(measuringDistance(row[a], row[b])) with row[a] as the FIRST argument (VS:1796-1910): the
+// n x n matrix buildAdjacencyGraph fills for node i, over the entries of the stored adjacency row.
+__global__ void k_local_weights(const uint64_t* __restrict__ row, int n, const NodeRec* __restrict__ node, VgsWeightParams W,
+                                int32_t* __restrict__ ids, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) ids[t] = (int32_t)(uint32_t)row[t];
+  if (t >= (int64_t)n * n) return;
+  const int a = (int)(t / n), b = (int)(t % n);
+  out[t] = vm_pair_weight(node[(uint32_t)row[a]], node[(uint32_t)row[b]], W);
+}
+
+extern "C" vgs_status vgs_get_local_weights(vgs_ctx* c, int32_t node_id, int32_t* n_out, int32_t* ids, float* weights) {
+  if (!c || !n_out) return VGS_E_ARG;
+  if (c->stage < ST_ADJACENCY) { c->err = "vgs_get_local_weights: adjacency first"; return VGS_E_STATE; }
+  if (node_id < 0 || node_id >= c->V) { c->err = "vgs_get_local_weights: node id out of range"; return VGS_E_ARG; }
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t u = 0xffffffffu;
+  VGS_HIP_TRY(c, hipMemcpy(&u, c->used_rank.p + node_id, 4, hipMemcpyDeviceToHost));
+  if (u == 0xffffffffu) { *n_out = 0; return VGS_OK; }   // an unused voxel has no local graph (VS:384)
+  uint32_t n = 0;
+  VGS_HIP_TRY(c, hipMemcpy(&n, c->adj_cnt.p + u, 4, hipMemcpyDeviceToHost));
+  *n_out = (int32_t)n;
+  if (!ids || !weights || n == 0) return VGS_OK;
+  DevBuf<float> d_w; DevBuf<int32_t> d_ids;
+  VGS_HIP_TRY(c, d_w.ensure((size_t)n * n)); VGS_HIP_TRY(c, d_ids.ensure(n));
+  const int64_t total = (int64_t)n * n;
+  hipLaunchKernelGGL(k_local_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->adj_key.p + (size_t)u * c->adj_stride, (int)n,
+                     c->node.p, make_weight_params_m(c->P), d_ids.p, d_w.p);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(weights, d_w.p, (size_t)total * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ids, d_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+  d_w.release(); d_ids.release();
+  if (e != hipSuccess) { c->err = std::string("vgs_get_local_weights: ") + hipGetErrorString(e); return VGS_E_HIP; }
+  return VGS_OK;
+}
+
 vgs_status vgs_stage_merge(vgs_ctx* c) {
   const int64_t V = c->V, U = c->U, N = c->N;
   c->bnd_unique = -1;  // tile protocol results belong to the previous segmentation

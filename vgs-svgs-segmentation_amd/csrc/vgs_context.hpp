@@ -255,13 +255,15 @@ static inline vgs_status vgs_readback(vgs_ctx* c, void* dst, const void* src_dev
 }
 #define VGS_READBACK(ctx, dst, src, bytes) do { vgs_status _s = vgs_readback((ctx), (dst), (src), (bytes)); if (_s != VGS_OK) return _s; } while (0)
 
+vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host);   // cutorder.hip
 void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only
 
 // stage implementations (one .hip file each)
 vgs_status vgs_stage_voxelize(vgs_ctx* c);
 vgs_status vgs_stage_features(vgs_ctx* c);
 vgs_status vgs_stage_adjacency(vgs_ctx* c);
-vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2);
+vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2, const uint32_t* ids = nullptr,
+                             int64_t n_ids = 0);
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_nearlists(vgs_ctx* c);   // part of the local-cut stage
 vgs_status vgs_stage_localcut(vgs_ctx* c);   // launches everything; its hand-over kernels may still run when it returns
