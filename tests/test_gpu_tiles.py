@@ -251,7 +251,7 @@ def test_tile_grids_match_single_engine(gpu, tiles, n_per):
     assert m.mean() > 0.85
     a, b = canonical_labels(tiled[m]), canonical_labels(ref[m])
     assert np.array_equal(a, b), f"{int((a != b).sum())} of {int(m.sum())} points differ outside closestCheck"
-    # four-owner corners: the used voxels whose cube contains an inner corner of the layout hold points of several ranks,
+    # four-owner corners: the voxels whose cube contains an inner corner of the layout hold points of three or four ranks,
     # and every one of those points has the single engine's label
     cen = eng.voxel_centers()
     xs = [(i - tx / 2.0) * pitch for i in range(1, tx)]
@@ -259,14 +259,14 @@ def test_tile_grids_match_single_engine(gpu, tiles, n_per):
     n_corner = 0
     for cx in xs:
         for cy in ys:
-            near = np.nonzero(used & (np.abs(cen[:, 0] - cx) <= 0.0501) & (np.abs(cen[:, 1] - cy) <= 0.0501))[0]
-            for vtx in near:
+            near = np.nonzero((np.abs(cen[:, 0] - cx) <= 0.0501) & (np.abs(cen[:, 1] - cy) <= 0.0501))[0]
+            for vtx in near:   # used or not: an unused voxel's points are dropped by every rank alike
                 sel = pv == vtx
                 owners = set(rank_of_point[sel].tolist())
-                if len(owners) >= 2:   # where the corner cuts the cube decides whether two, three or four ranks hold points of it
+                if len(owners) >= 3:
                     n_corner += 1
                     lt, lr = tiled[sel], ref[sel]
                     assert lt.min() == lt.max() and (lt[0] >= 0) == (lr[0] >= 0), (vtx, lt[:4], lr[:4])
                     if lr[0] >= 0:   # the whole segment of that voxel is the single engine's segment
                         np.testing.assert_array_equal((tiled == lt[0])[m], (ref == lr[0])[m])
-    assert n_corner >= 1, "scene precondition: no used voxel with points of several ranks at a tile corner"
+    assert n_corner >= 1, "scene precondition: no voxel with points of three or more ranks at a tile corner"

@@ -1,0 +1,56 @@
+"""The native tiled driver (include/vgs_tiles.h: C++ host code, RCCL collectives) on the GPU box.
+  * emulated ranks (threads of examples/vgs_tiles_run meeting in shared memory, one GPU): the labels of every rank equal the
+    labels of the Python twin (TiledSegmenter over the in-process FakeDist) element for element, for 2x1 and 2x2 layouts;
+  * the RCCL path with the communicator of a one-rank world (what a 1-GPU box can run): ncclCommInitRank, ncclAllGather and
+    ncclBroadcast are the calls a multi-GPU run makes, and the labels equal a plain engine's."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_tiles import _run_tiled
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vgs-svgs-segmentation_amd", "csrc")
+EXE = os.path.join(ROOT, "examples", "vgs_tiles_run")
+
+
+def _native(tmp_path, parts, mode, tiles, pitch, env=None):
+    subprocess.check_call(["make", "-C", CSRC, "-s", "example"])
+    prefix = str(tmp_path / "t")
+    for r, p in enumerate(parts):
+        np.ascontiguousarray(p, dtype=np.float32).tofile(f"{prefix}.{r}.f32")
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.check_output([EXE, mode, f"{tiles[0]}x{tiles[1]}", "--pitch", repr(float(pitch)), "--voxel", "0.1", prefix], text=True, env=e)
+    world, kept, n0, nrec = (int(x) for x in out.strip().splitlines()[-1].split())   # RCCL may print a banner first
+    labels = [np.fromfile(f"{prefix}.{r}.labels.i32", dtype=np.int32) for r in range(len(parts))]
+    return world, kept, labels, nrec
+
+
+@pytest.mark.parametrize("tiles,n_per", [((2, 1), 150_000), ((2, 2), 120_000)], ids=["2x1", "2x2"])
+def test_native_driver_equals_the_python_twin(gpu, tmp_path, tiles, n_per):
+    world = tiles[0] * tiles[1]
+    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
+    parts = [gpu.scenes.tiled_urban_scene(n_per * world, tiles=tiles, tile_index=r) for r in range(world)]
+    w, kept, labels, nrec = _native(tmp_path, parts, "--emulate", tiles, pitch)
+    assert w == world and nrec > 0
+    out = _run_tiled(gpu, parts, dict(voxel_size=0.1), pitch, world=world, tiles=tiles)
+    assert kept == out[0][1]
+    for r in range(world):
+        np.testing.assert_array_equal(labels[r], out[r][0])
+    # a segment that crosses a border carries one label on both sides
+    assert set(labels[0][labels[0] >= 0].tolist()) & set(labels[1][labels[1] >= 0].tolist())
+
+
+def test_native_driver_over_rccl_one_rank(gpu, tmp_path):
+    xyz = gpu.scenes.urban_scene(200_000)
+    env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"}
+    w, kept, labels, nrec = _native(tmp_path, [xyz], "--rccl", (1, 1), 1000.0, env=env)
+    eng = gpu.Engine(gpu.default_params(2, voxel_size=0.1))
+    eng.set_points(xyz)
+    eng.run()
+    assert w == 1 and kept == eng.counts()["kept"]
+    np.testing.assert_array_equal(labels[0], eng.point_labels())

@@ -31,11 +31,15 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                   uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
                                                   const int32_t* __restrict__ nvals, const uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo,
-                                                  uint32_t* __restrict__ redo_out) {
+                                                  uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
+  // adj_off != null: the packed lattice offset (dx+16) | (dy+16) << 5 | (dz+16) << 10 of every stored entry goes to a row of
+  // its own (the local cut reads it instead of gathering the neighbours' records for their lattice coordinates); a row that
+  // is not in band gets 0xffff in its first slot: its order comes from a sort that does not carry the offsets
   // redo != null: second pass over the rows that did not fit the first pass's list (their number is read on the device);
   // redo_out != null: first pass, rows with more than CAP survivors are appended there instead of being written
   __shared__ uint64_t lst[CAP];
   __shared__ uint8_t gl[CAP];    // integer squared length of each survivor's lattice offset (the table is sorted by it)
+  __shared__ uint16_t loff[CAP]; // its packed lattice offset
   __shared__ float ctab[3][32];  // voxel centres along each axis for key offsets -R..R (double arithmetic once per wavefront, not per offset)
   const int lane = threadIdx.x;
   auto do_row = [&](const int64_t u) {
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
     uint64_t key64 = 0;
     bool is_used = false;
     int norm = 0;
+    uint32_t poff = 0;
     if (o < n_off) {
       const int32_t pk = offsets[o];
       const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
             keep = true;
             key64 = ((uint64_t)vm_bits(d2) << 32) | (uint32_t)t;
             norm = dx * dx + dy * dy + dz * dz;
+            poff = (uint32_t)(dx + 16) | ((uint32_t)(dy + 16) << 5) | ((uint32_t)(dz + 16) << 10);
             in_band = in_band && (fabsf(d2 - (float)norm * res2) < 0.49f * res2) && (norm < 256);
           }
         }
@@ -82,11 +88,12 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
     const unsigned long long mall = __ballot(keep);
     const bool store = FULL ? keep : (keep && is_used);
     const unsigned long long m = __ballot(store);
-    if (store) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); if (pos < CAP) { lst[pos] = key64; gl[pos] = (uint8_t)norm; } }
+    if (store) { const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)); if (pos < CAP) { lst[pos] = key64; gl[pos] = (uint8_t)norm; loff[pos] = (uint16_t)poff; } }
     cnt += __popcll(m);
     mused += __popcll(mall);
   }
   uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
   __syncthreads();
   if (cnt > CAP) {  // dense volumetric neighbourhood: the pass with the full-size list takes this row
     if (lane == 0 && redo_out) redo_out[atomicAdd(n_redo, 1u)] = (uint32_t)u;
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
       for (int q = p - 1; q >= 0 && gl[q] == g; --q) { first = q; rank += lst[q] < key ? 1 : 0; }
       for (int q = p + 1; q < cnt && gl[q] == g; ++q) rank += lst[q] < key ? 1 : 0;
       row[first + rank] = key;
+      if (orow) orow[first + rank] = loff[p];
     }
     if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
     if (gtab) {
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
     return;
   }
   if (gtab) for (int r = lane; r <= ngroups; r += 64) gtab[(int64_t)u * gstride + r] = 0xffffu;  // no group table for this row
+  if (orow && lane == 0) orow[0] = 0xffffu;   // no offsets either
   // general case (coordinates so large that the rounding of the centres rivals the lattice step): bitonic sort
   // ascending on the next power of two >= cnt
   int np = 64;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
                                                         int adj_stride, uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                         uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
                                                         const int32_t* __restrict__ nvals, unsigned int* __restrict__ n_redo,
-                                                        uint32_t* __restrict__ redo_out) {
+                                                        uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
   constexpr int NB3 = NB * NB * NB, Bh = NB / 2, CAPC = 64 * ADJM_TRIPS;
   static_assert(NB3 <= ADJM_BRICKS, "two bricks per lane");
   __shared__ uint64_t s_occ[ADJM_BRICKS];
@@ -180,6 +189,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   __shared__ uint16_t s_cand[CAPC];     // used << 13 | brick slot << 6 | bit
   __shared__ uint64_t lst[CAP];
   __shared__ uint8_t gl[CAP];
+  __shared__ uint16_t loff[CAP];   // packed lattice offset of every survivor (see k_adjacency)
   __shared__ uint32_t s_hist[128], s_cur[128];   // two 16-bit counters per word: integer length l lives in word l >> 1
   __shared__ float ctab[3][32];
   const int lane = threadIdx.x;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   int nstore = 0, mused = 0;
   bool in_band = true;
   uint64_t rkey[ADJM_TRIPS];
-  int rnorm[ADJM_TRIPS];   // -1 = nothing to store
+  int rnorm[ADJM_TRIPS];   // -1 = nothing to store; bits 8.. hold the packed lattice offset
 #pragma unroll
   for (int tr = 0; tr < ADJM_TRIPS; ++tr) {
     rnorm[tr] = -1; rkey[tr] = 0;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
           in_band = in_band && (fabsf(d2 - (float)norm * res2) < 0.49f * res2) && (norm < 256);
           if (is_used) {
             rkey[tr] = ((uint64_t)vm_bits(d2) << 32) | t;
-            rnorm[tr] = norm & 255;
+            rnorm[tr] = (norm & 255) | (int)(((uint32_t)(dx + 16) | ((uint32_t)(dy + 16) << 5) | ((uint32_t)(dz + 16) << 10)) << 8);
             atomicAdd(&s_hist[(norm & 255) >> 1], 1u << (16 * (norm & 1)));
           }
         }
@@ -308,15 +318,16 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
 #pragma unroll
   for (int tr = 0; tr < ADJM_TRIPS; ++tr) {
     if (rnorm[tr] >= 0) {
-      const int g = rnorm[tr];
+      const int g = rnorm[tr] & 255;
       const uint32_t old = atomicAdd(&s_cur[g >> 1], 1u << (16 * (g & 1)));
       const uint32_t pos = (old >> (16 * (g & 1))) & 0xffffu;
-      lst[pos] = rkey[tr]; gl[pos] = (uint8_t)g;
+      lst[pos] = rkey[tr]; gl[pos] = (uint8_t)g; loff[pos] = (uint16_t)(rnorm[tr] >> 8);
     }
   }
   __syncthreads();
   // ---- final slot inside the group (the order inside a group is open: equal lengths, keys differ in rounding and id) ----
   uint64_t* row = adj_key + (int64_t)u * adj_stride;
+  uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
   const int cnt = nstore;
   for (int p = lane; p < cnt; p += 64) {
     const uint64_t key = lst[p];
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
     int rank = 0;
     for (int q = first; q < last; ++q) rank += lst[q] < key ? 1 : 0;
     row[first + rank] = key;
+    if (orow) orow[first + rank] = loff[p];
   }
   if (lane == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)mused; }
   if (gtab) {
@@ -436,14 +448,20 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   const float res_f = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
   uint16_t* gt = nullptr;   // group tables only for the rows the pipeline keeps
+  uint16_t* off = nullptr;  // the entries' lattice offsets likewise (voxel lattice only: the local cut of method 2 reads them)
   if (out_key == c->adj_key.p && c->adj_have_gtab) {
     VGS_HIP_TRY(c, c->adj_gtab.ensure((size_t)U * c->adj_gstride));
     gt = c->adj_gtab.p;
   }
+  if (out_key == c->adj_key.p && c->P.method == 2 && c->adj_R <= 15) {
+    VGS_HIP_TRY(c, c->adj_off.ensure((size_t)U * c->adj_stride));
+    off = c->adj_off.p;
+  }
+  c->adj_have_off = (out_key == c->adj_key.p) ? (off != nullptr) : c->adj_have_off;
 #define LAUNCH_ADJ(CAPV, FULLV, GRID, REDO, NREDO, REDO_OUT)                                                                 \
   hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(GRID), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,            \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
-                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT)
+                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT, off)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
   if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !c->K.no_adjmasks) {
     // hot path: candidates from the brick occupancy masks; rows it cannot take go through the general kernel
@@ -453,7 +471,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 #define LAUNCH_ADJM(NBV)                                                                                                          \
     hipLaunchKernelGGL((k_adjacency_masks<240, NBV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,  \
                        (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
-                       out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p)
+                       out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p, off)
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
 #undef LAUNCH_ADJM
     // rows it passed on (more candidates than its list): the general kernel, a fixed grid striding over the device-side list

@@ -9,13 +9,23 @@
 #include <string>
 #include <vector>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "vgs_context.hpp"
 
 static thread_local std::string g_create_err;
 
+static const char* const VGS_STAGE_NAMES[VGS_T_COUNT] = {"vgs:voxelize", "vgs:features", "vgs:adjacency", "vgs:localcut", "vgs:merge", "vgs:labels",
+                                                         "vgs:total", "vgs:localcut_kernel", "vgs:supervoxels", "vgs:localcut_bulk", "", ""};
+struct RoctxRange {   // a stage = one roctx range (rocprofv3 --marker-trace shows the stages on the host timeline)
+  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+  ~RoctxRange() { roctxRangePop(); }
+};
+
 // time a stage with HIP events on the context's stream
 template <typename F>
 static vgs_status timed(vgs_ctx* c, int slot, F&& f) {
+  RoctxRange range(VGS_STAGE_NAMES[slot]);
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   vgs_status s = f();
@@ -169,14 +179,14 @@ void vgs_destroy(vgs_ctx* c) {
   c->head_flag.release(); c->pt_vox.release(); c->vox_code.release(); c->vox_start.release();
   c->xs.release(); c->ys.release(); c->zs.release();
   c->node.release(); c->used_ids.release(); c->used_rank.release();
-  c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_cnt.release(); c->adj_mused.release();
+  c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_off.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->nl_cnt.release(); c->nl_slot.release(); c->nl_dw.release(); c->lc_ctab.release();
   c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
   c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_label.release();
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
-  c->owned.release(); c->straddle.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
+  c->owned.release(); c->straddle.release(); c->mixsrc.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
   c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   if (c->pin) (void)hipHostFree(c->pin);
@@ -226,6 +236,7 @@ static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes)
   for (int i = 0; i < VGS_T_COUNT; ++i) c->times[i] = 0;
   // a supervoxel labelling belongs to the cloud it was made for (SS:279-331 rebuilds it per createSupervoxels call)
   c->sv_have_labels = false; c->sv_labels_external = false; c->sv_max_label = 0; c->sv_label_n = -1;
+  c->n_own = -1;   // tiles: vgs_set_own_point_count follows the cloud
   return VGS_OK;
 }
 

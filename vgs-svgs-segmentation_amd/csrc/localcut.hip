@@ -769,13 +769,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev[2], 0));
       hipLaunchKernelGGL((k_localcut_wave<WAVE_D, LCAP_D, NW_D>), dim3(((nabc[3] + 7) / 8) * 8), dim3(64 * NW_D), 0, c->stream4, (const uint32_t*)nullptr, 0,
                          ids_d, (int)nabc[3], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
-                         ids_g, d_ng, c->evals.p, dbg_buf);
+                         ids_g, d_ng, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
       VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows both C and D
     }
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
-                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf);
+                         c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
     VGS_HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));   // class C done (its hand-overs follow)
     // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
     vgs_status st = VGS_OK;
@@ -792,7 +792,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // classes A and B have the same LDS footprint, so their workgroups interleave freely; B (heavier) goes first
   if (nabc[1] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
-                       ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf);
+                       ids_b, (int)nabc[1], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[8], c->stream3));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[10], c->stream));
   // class A1 (the voxels the lazy schedule is likely to work on for long, or give up on) is the launch's first list: the
@@ -801,7 +801,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // a 1024-edge list for A1: 40 % fewer hand-overs, but the step gets slower.)
   if (nabc[0] + nabc[4] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
-                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf);
+                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
   // trip before the launch); the host checks the length afterwards (vgs_localcut_finish).  The kernel runs on the side

@@ -50,6 +50,12 @@
 #ifndef LW_TRIP
 #define LW_TRIP 3
 #endif
+// bucket sort of the bulk class's edge lists (round-3 experiment, off: exact -- the parity tests pass with it -- but slower
+// than the bitonic network it replaces, 4.7 against 4.2 ms in the same build: fewer instructions, yet its LDS atomics, the scan
+// and the rank loops are chains of dependent LDS round trips, and this kernel is bound by exactly those at 24 wavefronts per CU)
+#ifndef LW_BUCKET_SORT
+#define LW_BUCKET_SORT 0
+#endif
 // groups of four vertices whose near-pair list entries are requested together (first shells)
 #ifndef LW_NEAR_GROUPS
 #define LW_NEAR_GROUPS 2
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
                                                       int adj_stride, const NodeRec* __restrict__ node, LwParams P,
                                                       uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                       uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
-                                                      uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out) {
+                                                      uint32_t* __restrict__ evals_out, uint32_t* __restrict__ dbg_out,
+                                                      const uint16_t* __restrict__ adj_off) {
   constexpr bool SMALL = MAXM <= 255;  // indices and segment sizes fit a byte
   typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;   // vertex / segment index, segment size
   // pair id = (a << PSH) | b with a < b
@@ -200,24 +207,27 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     return;
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
-  const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);  // cut / size, looked up across lanes
+  // cut / size, looked up across lanes.  (A table in LDS instead -- one read where the cross-lane lookup costs two ds_bpermute -- was
+  // measured in round 3: its 384 bytes take the workgroup from 6368 to 6752 bytes of LDS, 22 instead of 24 wavefronts per CU, and
+  // the launch went from 3.9 to 4.2 ms.  The kernel follows its occupancy, not its instruction count.)
+  const float cut_tab0 = cut / (float)(lane + 1), cut_tab1 = cut / (float)(lane + 65);
   bool near_ok = false;   // wave-uniform: the first shell can be read from the near-pair lists
   bool cen_ready = true;  // centroids are staged
-  uint32_t pad0 = 0;
+  // The lattice offset of every vertex from the voxel comes with the adjacency row (adj_off, written by the adjacency stage):
+  // one coalesced 2-byte read per vertex instead of a gather of the neighbours' records.  orow[0] = 0xffff: this row has none.
+  const uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
   if constexpr (NEAR) {
-    near_ok = P.near.enabled != 0 && P.near.direct != 0;
+    near_ok = P.near.enabled != 0 && P.near.direct != 0 && orow != nullptr;
     if (near_ok) {
       for (int k = lane; k < NMAP_BYTES / 4; k += 64) nmap4[k] = 0xffffffffu;
-      pad0 = node[(uint32_t)row[0]].pad;   // vertex 0 is the voxel itself
       wave_sync();
     }
   }
   if constexpr (NEARH) {
-    near_ok = P.near.enabled != 0;
+    near_ok = P.near.enabled != 0 && orow != nullptr;
     if (near_ok) {
       for (int k = (int)threadIdx.x; k < HCAP; k += 64 * NW) htab[k] = 0u;
       if (threadIdx.x == 0) { sh_i[SH_NEARBAD] = 0; sh_i[SH_NEARSUM] = 0; }
-      pad0 = node[(uint32_t)row[0]].pad;
       blk_sync();
     }
   }
@@ -239,25 +249,23 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     seg[c] = (idx_t)c; rep[c] = (idx_t)c; ssz[c] = 1; thr[c] = thr0; alist[c] = (idx_t)c; claim[c] = 0xffffffffu;
     if constexpr (NEAR) {
       if (near_ok) {
-        const uint32_t pd = node[t].pad;
-        const int ox = nl_diff10(pd & 1023u, pad0 & 1023u) + NL_BALL, oy = nl_diff10((pd >> 10) & 1023u, (pad0 >> 10) & 1023u) + NL_BALL,
-                  oz = nl_diff10((pd >> 20) & 1023u, (pad0 >> 20) & 1023u) + NL_BALL;
-        const bool inb = (unsigned)ox < (unsigned)NMAP_DIM && (unsigned)oy < (unsigned)NMAP_DIM && (unsigned)oz < (unsigned)NMAP_DIM;
+        const uint32_t pk = orow[c];
+        const int ox = (int)(pk & 31u) - 16 + NL_BALL, oy = (int)((pk >> 5) & 31u) - 16 + NL_BALL, oz = (int)((pk >> 10) & 31u) - 16 + NL_BALL;
+        const bool inb = pk != 0xffffu && (unsigned)ox < (unsigned)NMAP_DIM && (unsigned)oy < (unsigned)NMAP_DIM && (unsigned)oz < (unsigned)NMAP_DIM;
         if (inb) {
           nlat[c] = (uint16_t)(ox | (oy << 4) | (oz << 8));
           nmap[(oz * NMAP_DIM + oy) * NMAP_DIM + ox] = (uint8_t)c;
         }
-        near_bad = near_bad || !inb || P.near.cnt[t] == NL_NONE;
+        // a vertex without a list of its own (NL_NONE) shows when its list is first read: entry 0 holds a NaN distance (near_enum)
+        near_bad = near_bad || !inb;
       }
     }
     if constexpr (NEARH) {
       if (near_ok) {
-        const uint32_t pd = node[t].pad;
-        const int ox = nl_diff10(pd & 1023u, pad0 & 1023u) + 16, oy = nl_diff10((pd >> 10) & 1023u, (pad0 >> 10) & 1023u) + 16,
-                  oz = nl_diff10((pd >> 20) & 1023u, (pad0 >> 20) & 1023u) + 16;
-        const bool inb = (unsigned)ox < 32u && (unsigned)oy < 32u && (unsigned)oz < 32u;   // always: balls end at 15 voxels
+        const uint32_t pk = orow[c];
+        const bool inb = pk != 0xffffu;   // balls end at 15 voxels: every offset fits 5 bits per axis
         if (inb) {
-          const uint32_t key15 = (uint32_t)ox | ((uint32_t)oy << 5) | ((uint32_t)oz << 10);
+          const uint32_t key15 = pk;
           hlat[c] = (uint16_t)key15;
           uint32_t h = h_slot(key15);
           while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
@@ -302,7 +310,103 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
   // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
   // real one that never move, so cnt need not be a power of two and nothing is padded.
+  // One-wavefront classes, lists of more than 128 keys: a bucket sort.  The bitonic network costs 45 passes over 512 keys
+  // (800 VALU + 760 SALU instructions per voxel on URB10M, a fifth of the kernel); the weights of a shell lie in a narrow band,
+  // so the keys go into 128 buckets by weight (monotone float map of [wmin, wmax], descending), an LDS histogram gives every
+  // bucket its slice of the list, and a key's place inside its bucket (a handful of keys) is the number of larger keys there.
+  // Keys are unique (pair ids differ); dropped entries (0) keep their arrival order in the last bucket.  Returns false when the
+  // keys do not spread (one weight, or a bucket with more than 48 keys): the network below sorts those lists.
+  constexpr int BS_K = (LCAP + 63) / 64;
+  auto bucket_sort = [&](int cnt) -> bool {
+    uint64_t kk[BS_K];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < BS_K; ++j) {
+      const int e = lane + 64 * j;
+      kk[j] = e < cnt ? lk[e] : ~0ull;    // ~0: no key
+      const uint32_t wb = (uint32_t)(kk[j] >> 32);
+      if (e < cnt && kk[j] != 0ull) { lo = wb < lo ? wb : lo; hi = wb > hi ? wb : hi; }
+    }
+    // claim[] is free between merges (all ones): words 0..63 hold two 16-bit bucket counters each, 64 and 65 the band
+    if (lane < 2) claim[64 + lane] = lane == 0 ? 0xffffffffu : 0u;
+    claim[lane] = 0u;
+    wave_sync();
+    if (lo != 0xffffffffu) { atomicMin(&claim[64], lo); atomicMax(&claim[65], hi); }
+    wave_sync();
+    const float wmin = vm_from_bits(claim[64]), wmax = vm_from_bits(claim[65]);
+    const bool spread = wmax > wmin;   // weights are non-negative floats: bit order = value order
+    const float scale = 126.99f / (wmax - wmin);
+    uint32_t bk[BS_K];                    // bucket | arrival index << 8
+#pragma unroll
+    for (int j = 0; j < BS_K; ++j) {
+      bk[j] = 0;
+      if (kk[j] != ~0ull && spread) {
+        int b = 127;                      // dropped entries: behind every real key
+        if (kk[j] != 0ull) { b = 126 - (int)((vm_from_bits((uint32_t)(kk[j] >> 32)) - wmin) * scale); b = b < 0 ? 0 : (b > 126 ? 126 : b); }
+        const uint32_t old = atomicAdd(&claim[b >> 1], 1u << (16 * (b & 1)));
+        bk[j] = (uint32_t)b | (((old >> (16 * (b & 1))) & 0xffffu) << 8);
+      }
+    }
+    wave_sync();
+    const uint32_t cw = claim[lane];
+    const uint32_t c0 = cw & 0xffffu, c1 = cw >> 16;
+    const bool crowded = (c0 > 48u && lane != 63) || (c1 > 48u && lane != 63) || (lane == 63 && c0 > 48u);   // bucket 127 holds the dropped entries: any number
+    if (!spread || __ballot(crowded) != 0ull) {
+      wave_sync();
+      claim[lane] = 0xffffffffu; if (lane < 2) claim[64 + lane] = 0xffffffffu;
+      wave_sync();
+      return false;
+    }
+    uint32_t inc = c0 + c1;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += v; }
+    const uint32_t s0 = inc - (c0 + c1), s1 = s0 + c0;
+    wave_sync();
+    claim[lane] = s0 | (s1 << 16);        // bucket starts; the end of bucket b is the start of b + 1 (cnt behind the last)
+    wave_sync();
+    // place inside the bucket: bk[j] becomes start | length << 9 | rank << 15 (starts < 512, buckets hold at most 48 keys)
+    uint32_t maxlen = 0;
+#pragma unroll
+    for (int j = 0; j < BS_K; ++j)
+      if (kk[j] != ~0ull) {
+        const int b = (int)(bk[j] & 255u);
+        const uint32_t st = (claim[b >> 1] >> (16 * (b & 1))) & 0xffffu;
+        const uint32_t en = b == 127 ? (uint32_t)cnt : ((claim[(b + 1) >> 1] >> (16 * ((b + 1) & 1))) & 0xffffu);
+        const uint32_t arrival = bk[j] >> 8;
+        lk[st + arrival] = kk[j];         // grouped by bucket, arrival order inside
+        // dropped entries (bucket 127) stay where they arrived: length 0, rank = arrival does not fit 6 bits, so they keep a flag
+        if (b == 127) bk[j] = (st + arrival) | (1u << 31);
+        else { bk[j] = st | ((en - st) << 9); maxlen = (en - st) > maxlen ? (en - st) : maxlen; }
+      }
+    wave_sync();
+    // the rank loops of a lane's keys run side by side: one trip reads one bucket mate for every key (independent LDS reads)
+    for (uint32_t q = 0; __ballot(q < maxlen) != 0ull; ++q) {
+#pragma unroll
+      for (int j0 = 0; j0 < BS_K; j0 += 4) {
+        uint64_t mate[4];
+#pragma unroll
+        for (int j = j0; j < j0 + 4 && j < BS_K; ++j) {   // unconditional reads (clamped address): issued together
+          const uint32_t a = (bk[j] & 511u) + q;
+          mate[j - j0] = lk[a < (uint32_t)LCAP ? a : (uint32_t)LCAP - 1u];
+        }
+#pragma unroll
+        for (int j = j0; j < j0 + 4 && j < BS_K; ++j) {
+          const uint32_t len = (bk[j] >> 9) & 63u;
+          const bool counts = kk[j] != ~0ull && !(bk[j] >> 31) && q < len && mate[j - j0] > kk[j];
+          bk[j] += counts ? (1u << 15) : 0u;
+        }
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < BS_K; ++j)
+      if (kk[j] != ~0ull) lk[(bk[j] >> 31) ? (bk[j] & 0x7fffffffu) : ((bk[j] & 511u) + (bk[j] >> 15))] = kk[j];
+    claim[lane] = 0xffffffffu; if (lane < 2) claim[64 + lane] = 0xffffffffu;
+    wave_sync();
+    return true;
+  };
   auto sort_section = [&](int cnt) {   // all wavefronts of the workgroup
+    if constexpr (LW_BUCKET_SORT != 0 && NW == 1 && MAXM == 96) { if (cnt > 128 && bucket_sort(cnt)) return; }   // the bulk class (class B: the extra registers spill)
     int np = 64;
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {
@@ -486,6 +590,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       return inside;
     };
     const int j = lane & 15;
+    bool none = false;   // a vertex whose voxel has no list: NaN distance in entry 0 (nearlist.hip)
     // LW_NEAR_GROUPS groups of four vertices per trip: their list entries are requested together (the ids come out of
     // registers, so the only memory round trip of a trip is the entries themselves)
     for (int base = 0; base < m; base += 4 * LW_NEAR_GROUPS) {
@@ -499,6 +604,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         const size_t o = (size_t)vertex_id(va) * NL_S + (size_t)j;
         e[g] = make_float2(0.f, 0.f); sl[g] = 0;
         if (act[g]) { e[g] = P.near.dw[o]; sl[g] = P.near.slot[o]; }
+        none = none || (e[g].x != e[g].x);
       }
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(base + 4 * g + (lane >> 4), act[g], e[g], sl[g]);
@@ -519,6 +625,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         }
       }
     }
+    if (__ballot(none) != 0ull) return -1;   // the general enumeration takes this neighbourhood
     return count;
   };
 
@@ -791,7 +898,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int Pact = use_minor ? n_min * n_act : n_act * (n_act - 1) / 2;   // (upper bound of) candidate pairs
       // once every pair between the still-active vertices fits in the list there is no point in further shells
       const bool final_round = !(cut_hi < P.d2_all) || (merges > 0 && Pact <= free_slots);
-      const bool near_round = (NEAR || NEARH) && near_ok && !final_round && !(cut_hi > P.near.d2max);   // a shell inside the lists' reach
+      bool near_round = (NEAR || NEARH) && near_ok && !final_round && !(cut_hi > P.near.d2max);   // a shell inside the lists' reach
       int count;
       if constexpr (NEARH && NW > 1) {
         if (near_round) count = run_near(n_list, cut_lo, cut_hi, merges > 0, act_level);
@@ -800,10 +907,13 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
         }
       } else if constexpr (NEAR) {
+        count = 0;
         if (near_round) {
           count = near_enum(n_list, cut_lo, cut_hi, merges > 0, act_level);
-        } else {
-          if (!cen_ready) { stage_centroids(); cen_ready = true; wave_sync(); }   // the offset map is not needed any more
+          if (count < 0) { near_ok = false; near_round = false; }   // some vertex has no list: no shell of this voxel comes from the lists
+        }
+        if (!near_round) {
+          if (!cen_ready) { wave_sync(); stage_centroids(); cen_ready = true; wave_sync(); }   // the offset map is not needed any more
           count = run_enum(n_list, n_act, n_min, big, use_minor, final_round, merges > 0, Pact, cut_lo, cut_hi);
         }
       } else {

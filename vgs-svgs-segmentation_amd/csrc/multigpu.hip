@@ -12,8 +12,17 @@
 
 #include "vgs_context.hpp"
 
+// per voxel: does it hold points this rank loaded itself (mix[v]) / points that came with another rank's strip (mix[V + v])?
+__global__ void k_point_sources(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, int64_t nf, int64_t n_own, int64_t V,
+                                uint8_t* __restrict__ mix) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t v = pt_vox[j];
+  if (v != 0xffffffffu) mix[((int64_t)perm[j] < n_own ? 0 : V) + v] = 1;   // every writer stores the same value
+}
+
 __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float res_f, float min_x, float min_y, double lo_x, double lo_y,
-                        double hi_x, double hi_y, uint8_t* __restrict__ owned, uint8_t* __restrict__ straddle) {
+                        double hi_x, double hi_y, uint8_t* __restrict__ owned, uint8_t* __restrict__ straddle, const uint8_t* __restrict__ mix) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t code = vox_code[v];
@@ -23,15 +32,27 @@ __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float 
   owned[v] = (cx >= lo_x && cx < hi_x && cy >= lo_y && cy < hi_y) ? 1 : 0;
   // the voxel's cube reaches over a border of the region: points on both sides (loaded by different ranks) fall into it
   const double h = 0.5001 * (double)res_f;
-  straddle[v] = (fabs(cx - lo_x) < h || fabs(cx - hi_x) < h || fabs(cy - lo_y) < h || fabs(cy - hi_y) < h) ? 1 : 0;
+  bool st = fabs(cx - lo_x) < h || fabs(cx - hi_x) < h || fabs(cy - lo_y) < h || fabs(cy - hi_y) < h;
+  // ... or the ranks were handed points beyond their regions (objects that reach over a tile's edge): an owned voxel with points
+  // another rank loaded, a halo voxel with points this rank loaded.  Both ranks see that (the holder sends such points in its
+  // strip) and both publish the voxel, so the holder learns the label of its points from the owner's record.
+  if (mix) st = st || (owned[v] ? mix[V + v] != 0 : mix[v] != 0);
+  straddle[v] = st ? 1 : 0;
 }
 
 vgs_status vgs_compute_owned(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->owned.ensure(c->V > 0 ? c->V : 1));
   VGS_HIP_TRY(c, c->straddle.ensure(c->V > 0 ? c->V : 1));
   if (c->V == 0) return VGS_OK;
+  const uint8_t* mix = nullptr;
+  if (c->n_own >= 0 && c->Nf > 0) {
+    VGS_HIP_TRY(c, c->mixsrc.ensure(2 * (size_t)c->V));
+    VGS_HIP_TRY(c, hipMemsetAsync(c->mixsrc.p, 0, 2 * (size_t)c->V, c->stream));
+    hipLaunchKernelGGL(k_point_sources, dim3((unsigned)((c->Nf + 255) / 256)), dim3(256), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->Nf, c->n_own, c->V, c->mixsrc.p);
+    mix = c->mixsrc.p;
+  }
   hipLaunchKernelGGL(k_owned, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, c->V, c->P.voxel_size,
-                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p, c->straddle.p);
+                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p, c->straddle.p, mix);
   VGS_HIP_TRY(c, hipGetLastError());
   return VGS_OK;
 }
@@ -293,6 +314,13 @@ vgs_status vgs_set_owned_region(vgs_ctx* c, const double* lo, const double* hi) 
   if (!c || !lo || !hi) return VGS_E_ARG;
   c->own_lo[0] = lo[0]; c->own_lo[1] = lo[1]; c->own_hi[0] = hi[0]; c->own_hi[1] = hi[1];
   c->have_region = true;
+  if (c->stage > ST_ADJACENCY) c->stage = ST_ADJACENCY;
+  return VGS_OK;
+}
+
+vgs_status vgs_set_own_point_count(vgs_ctx* c, int64_t n_own) {
+  if (!c || n_own < -1) return VGS_E_ARG;
+  c->n_own = n_own;
   if (c->stage > ST_ADJACENCY) c->stage = ST_ADJACENCY;
   return VGS_OK;
 }

@@ -141,7 +141,12 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
       const int gg = g_first + x / NL_S, j = x % NL_S;
       const int kept = s_kept[gg];
       if (kept >= 0 && kept <= NL_S && j >= kept) out_dw[(size_t)s_vid[gg] * NL_S + (size_t)j] = make_float2(__builtin_huge_valf(), 0.0f);
-      if (j == 0) out_cnt[s_vid[gg]] = (kept < 0 || kept > NL_S || !((cube_ok >> gg) & 1ull)) ? (uint8_t)NL_NONE : (uint8_t)kept;
+      if (j == 0) {
+        const bool none = kept < 0 || kept > NL_S || !((cube_ok >> gg) & 1ull);
+        out_cnt[s_vid[gg]] = none ? (uint8_t)NL_NONE : (uint8_t)kept;
+        // a reader that does not look at the count (the one-wavefront classes of the cut) finds "no list" as a NaN distance in entry 0
+        if (none) out_dw[(size_t)s_vid[gg] * NL_S] = make_float2(vm_nan(), 0.0f);
+      }
     }
     __syncthreads();
   }

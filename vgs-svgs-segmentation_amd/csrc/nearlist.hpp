@@ -34,7 +34,8 @@ struct NearLists {
   const uint8_t* cnt;    // [V]        number of entries, NL_NONE = no list
   const uint16_t* slot;  // [V * NL_S] lattice offset of b from a: (dx+2) | (dy+2) << 4 | (dz+2) << 8
   const float2* dw;      // [V * NL_S] (squared centroid distance, vm_pair_weight(a, b)), ascending distance; unused entries
-                         //            hold (+inf, 0), so a reader needs no count: "d2 < shell radius" ends the list
+                         //            hold (+inf, 0), so a reader needs no count: "d2 < shell radius" ends the list; a voxel
+                         //            without a list (NL_NONE) has a NaN distance in entry 0
   float d2max;           // lists are complete for shells up to this squared centroid distance
   int enabled;           // the lists exist
   int direct;            // the search ball fits the one-wavefront classes' direct offset map (NL_BALL)

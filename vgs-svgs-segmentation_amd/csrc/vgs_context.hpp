@@ -163,6 +163,8 @@ struct vgs_ctx {
   int adj_R = 0;   // largest |offset| per axis of the ball table
   int adj_stride = 0;
   DevBuf<uint64_t> adj_key;
+  DevBuf<uint16_t> adj_off;   // per row entry: packed lattice offset from the row's voxel, (dx+16) | (dy+16) << 5 | (dz+16) << 10; row[0] = 0xffff: none
+  bool adj_have_off = false;
   DevBuf<uint32_t> adj_cnt, adj_mused;  // per used voxel: stored row length, number of ALL neighbours
   bool adj_pruned = false;              // rows hold used neighbours only
   float adj_r2 = 0.f;
@@ -222,6 +224,8 @@ struct vgs_ctx {
   bool have_region = false;
   double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
   DevBuf<uint8_t> owned;        // per voxel: 1 = centre inside this rank's region
+  int64_t n_own = -1;           // points [0, n_own) of the cloud were loaded by this rank itself, the rest came with other ranks' strips (-1: not told)
+  DevBuf<uint8_t> mixsrc;       // per voxel: holds own-loaded points / holds points from other ranks' strips
   DevBuf<uint8_t> straddle;     // per voxel: 1 = its cube crosses the border of the region (it may hold points of two ranks)
   DevBuf<uint64_t> bnd_code;    // boundary records
   DevBuf<int32_t> bnd_root;

@@ -218,16 +218,11 @@ class TiledSegmenter:
         lo, hi = self.regions[self.rank]
         h = self.halo
         x, y = xyz_host[:, 0].astype(np.float64), xyz_host[:, 1].astype(np.float64)
-        # A rank is expected to load the points of ITS region.  Points it holds beyond the border still reach the owner of that
-        # ground through the strips below and take part in the owner's voxels, but their labels are read from this rank's
-        # halo computation, which knows a segment's global label only if the segment touches one of its own voxels: a few
-        # of them may come back -1 (seen with generated tiles whose objects reach over the border; tools/fuzz_tiles.py
-        # partitions by region).  n_outside says how many there are.
+        # Points a rank holds beyond its border (generated tiles whose objects reach over the edge) reach the owner of that ground
+        # through the strips below and take part in the owner's voxels.  Their labels are read from this rank's halo computation;
+        # the voxels that hold them are published as boundary voxels by this rank and by their owner (vgs_set_own_point_count),
+        # so the halo voxel's local root carries the owner's label.  n_outside says how many such points there are.
         self.n_outside = int(((x < lo[0]) | (x >= hi[0]) | (y < lo[1]) | (y >= hi[1])).sum())
-        if self.n_outside > 0:
-            import warnings
-            warnings.warn(f"rank {self.rank}: {self.n_outside} of {xyz_host.shape[0]} points lie outside this rank's region; a few of "
-                          "them may come back unlabelled (-1): partition the cloud by tile_regions() before loading", RuntimeWarning)
         near = (x < lo[0] + h) | (x >= hi[0] - h) | (y < lo[1] + h) | (y >= hi[1] - h)
         strips = all_gather_varlen(self.dist, np.ascontiguousarray(xyz_host[near]).reshape(-1), self.coll_device)
         extra = []
@@ -248,6 +243,7 @@ class TiledSegmenter:
         self._keep = local
         self.engine.set_points_device(local.data_ptr(), local.shape[0], 12, keep=local)
         self.engine._ck(self.engine._L.vgs_set_owned_region(self.engine._h, _ptr(lo), _ptr(hi)))
+        self.engine._ck(self.engine._L.vgs_set_own_point_count(self.engine._h, int(self.n_own)))
 
     def _chain_grid(self):
         """The shared grid: what inserting the ranks' clouds one after the other does to the octree box.
