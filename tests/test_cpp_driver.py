@@ -115,6 +115,39 @@ def test_debug_meshes(gpu, tmp_path):
     assert hc["vertex"] == 8 * int((kept >= 0).sum())
     hn = header(tmp_path / "dbg_normals.ply")
     assert hn == {"vertex": 2 * int(used.sum()), "edge": int(used.sum())}
+    # geometry and colours, not only counts: parse the ASCII PLY bodies
+    def body(path, h):
+        with open(path) as f:
+            lines = f.read().split("end_header\n", 1)[1].splitlines()
+        nv = h["vertex"]
+        verts = np.array([ln.split() for ln in lines[:nv]], dtype=np.float64)
+        rest = [np.array(ln.split(), dtype=np.int64) for ln in lines[nv:]]
+        return verts[:, :3], verts[:, 3:6].astype(np.int64), rest
+
+    cen = eng.voxel_centers().astype(np.float64)
+    a = eng.attributes()
+    # drawColorMapofVoxels (VS:510-652): one box per used voxel in leaf order, corners = centre +- half a voxel, one colour per box
+    xyz_v, rgb_v, faces_v = body(tmp_path / "dbg_voxels.ply", hv)
+    boxes = xyz_v.reshape(-1, 8, 3)
+    np.testing.assert_allclose(boxes.mean(axis=1), cen[used], atol=2e-6)
+    np.testing.assert_allclose(np.abs(boxes - cen[used][:, None, :]), 0.075, atol=2e-6)        # voxel size 0.15
+    assert (rgb_v.reshape(-1, 8, 3) == rgb_v.reshape(-1, 8, 3)[:, :1, :]).all()
+    assert all(f[0] == 4 and f[1:].min() >= 8 * (k // 6) and f[1:].max() < 8 * (k // 6 + 1) for k, f in enumerate(faces_v))   # six quads on their own box
+    assert len({tuple(c) for c in rgb_v[::8].tolist()}) > 0.9 * min(int(used.sum()), 4096)    # boxes are coloured individually
+    # drawColorMapofClusteredVoxels (VS:654): the voxels of the kept clusters, every cluster in one colour
+    xyz_c, rgb_c, _ = body(tmp_path / "dbg_clustered_voxels.ply", hc)
+    sel = kept >= 0
+    np.testing.assert_allclose(xyz_c.reshape(-1, 8, 3).mean(axis=1), cen[sel], atol=2e-6)
+    col_of = {}
+    for k, c in zip(kept[sel].tolist(), rgb_c[::8].tolist()):
+        assert col_of.setdefault(k, tuple(c)) == tuple(c)
+    assert len(set(col_of.values())) == len(col_of)
+    # drawNormofVoxels (VS:1016-1104): a segment from the centroid along the normal, one voxel size long
+    xyz_n, _, edges = body(tmp_path / "dbg_normals.ply", hn)
+    seg = xyz_n.reshape(-1, 2, 3)
+    np.testing.assert_allclose(seg[:, 0, :], a["centroid"][used].astype(np.float64), atol=2e-6)
+    np.testing.assert_allclose(seg[:, 1, :] - seg[:, 0, :], 0.15 * a["normal"][used].astype(np.float64), atol=2e-6)
+    assert all(e.tolist() == [2 * k, 2 * k + 1] for k, e in enumerate(edges))
     # the PLY reader of point_clouds_io.hpp takes the vertices of these files back
     subprocess.check_call([os.path.join(ROOT, "examples", "pcd_tool"), "convert", str(tmp_path / "dbg_voxels.ply"), str(tmp_path / "v.pcd"), "binary"])
     f, _ = gpu.pcd.read_pcd(tmp_path / "v.pcd")

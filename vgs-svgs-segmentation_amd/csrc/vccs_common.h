@@ -77,4 +77,47 @@ VGS_HD void vccs_state_from_sums(const long long* sums, unsigned int count, floa
   else { n[0] = 0.f; n[1] = 0.f; n[2] = 0.f; }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// vccs_mode 1 ("PCL order"): pcl::SupervoxelClustering's own steps restated (PCL 1.8.1, recalled from upstream; unpinned --
+// see vccs.hip).  Arithmetic shared with the oracle (refcpu_vccs.cpp: vccs_pcl_supervoxels) so that both agree bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+// computeMeanAndCovarianceMatrix's single-pass accumulator (float, as PCL's Scalar): sums of x*x, x*y, x*z, y*y, y*z, z*z,
+// x, y, z over a multiset of voxel centroids
+struct VccsAccu { float a[9]; float n; };
+VGS_HD void vccs_accu_zero(VccsAccu* A) { for (int k = 0; k < 9; ++k) A->a[k] = 0.f; A->n = 0.f; }
+VGS_HD void vccs_accu_point(VccsAccu* A, const float* p) {
+  A->a[0] = A->a[0] + p[0] * p[0]; A->a[1] = A->a[1] + p[0] * p[1]; A->a[2] = A->a[2] + p[0] * p[2];
+  A->a[3] = A->a[3] + p[1] * p[1]; A->a[4] = A->a[4] + p[1] * p[2]; A->a[5] = A->a[5] + p[2] * p[2];
+  A->a[6] = A->a[6] + p[0]; A->a[7] = A->a[7] + p[1]; A->a[8] = A->a[8] + p[2];
+  A->n = A->n + 1.0f;
+}
+VGS_HD void vccs_accu_add(VccsAccu* A, const VccsAccu* B) { for (int k = 0; k < 9; ++k) A->a[k] = A->a[k] + B->a[k]; A->n = A->n + B->n; }
+// computePointNormal + flipNormalTowardsViewpoint(0, 0, 0) + normalize: cov = E[pp^T] - mean mean^T, smallest-eigenvalue
+// direction; fewer than three indices give no normal (PCL sets NaN; zero here: a zero normal gives the largest normal distance)
+VGS_HD void vccs_accu_normal(const VccsAccu* A, const float* self, float* n) {
+  n[0] = 0.f; n[1] = 0.f; n[2] = 0.f;
+  if (A->n < 3.0f) return;
+  float m[9];
+  for (int k = 0; k < 9; ++k) m[k] = A->a[k] / A->n;
+  float C[9];
+  C[0] = m[0] - m[6] * m[6]; C[1] = m[1] - m[6] * m[7]; C[2] = m[2] - m[6] * m[8];
+  C[4] = m[3] - m[7] * m[7]; C[5] = m[4] - m[7] * m[8]; C[8] = m[5] - m[8] * m[8];
+  C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+  float evecs[9], evals[3];
+  vm_eigen33(C, evecs, evals);
+  float nx = evecs[0], ny = evecs[3], nz = evecs[6];
+  if ((nx * (0.f - self[0]) + ny * (0.f - self[1])) + nz * (0.f - self[2]) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+  const float len = vm_sqrt((nx * nx + ny * ny) + nz * nz);
+  if (len > 0.f) { n[0] = nx / len; n[1] = ny / len; n[2] = nz / len; }
+}
+// the 27 cells of a leaf's neighbour list in PCL's computeNeighbors order (dx outermost, the leaf itself included)
+VGS_HD void vccs_offset27(int o, int* dx, int* dy, int* dz) { *dx = o / 9 - 1; *dy = (o / 3) % 3 - 1; *dz = o % 3 - 1; }
+// index of offset (dx, dy, dz) != 0 in the 26-neighbour table of vccs_offset (dz outermost, centre skipped)
+VGS_HD int vccs_index26(int dx, int dy, int dz) { const int k = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1); return k < 13 ? k : k - 1; }
+// selectInitialSupervoxelSeeds: a seed needs more than this many voxels within half a seed size
+VGS_HD float vccs_seed_min_points(float seed, float res) {
+  const float r = 0.5f * seed;
+  return 0.05f * (r * r) * 3.1415926536f / (res * res);
+}
+
 #endif
