@@ -43,6 +43,9 @@ typedef struct {
   float color_impt, spatial_impt, normal_impt; /* SVGS sig_a, sig_b, sig_c(2nd) lines 46,48,50 */
   int32_t q7_count_as_index; /* 1 = reproduce closestCheck reading the neighbour count as a voxel id (VS:2243) */
   int32_t device;        /* HIP device ordinal */
+  int32_t vccs_mode;     /* svgs_supervoxels: 0 = synchronous rounds (every voxel decides from the state at the start of a round),
+                          * 1 = pcl::SupervoxelClustering's own order: supervoxels take their turns one after the other in label
+                          * order, 2-ring normals, seed rejection (csrc/vccs.hip; unpinned against PCL either way) */
 } vgs_params;
 
 typedef struct vgs_ctx vgs_ctx;

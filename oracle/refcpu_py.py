@@ -64,6 +64,8 @@ def lib():
         L.ref_voxelize.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
         L.ref_vccs.restype = C.c_int
         L.ref_vccs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
+        L.ref_vccs_pcl.restype = C.c_int
+        L.ref_vccs_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_free.argtypes = [C.c_void_p]
         L.ref_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_vgs_bbox.argtypes = [C.c_void_p, C.c_void_p]
@@ -181,6 +183,14 @@ def vccs(xyz, params):
     xyz = _xyz(xyz)
     lab = np.zeros(xyz.shape[0], dtype=np.int32)
     mx = lib().ref_vccs(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
+    return lab, int(mx)
+
+
+def vccs_pcl(xyz, params):
+    """Supervoxel labels of the PCL-order restatement (vccs_mode 1: sequential owners, 2-ring normals, seed rejection)."""
+    xyz = _xyz(xyz)
+    lab = np.zeros(xyz.shape[0], dtype=np.int32)
+    mx = lib().ref_vccs_pcl(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
     return lab, int(mx)
 
 

@@ -268,18 +268,22 @@ void vccs_pcl_supervoxels(const float* xyz, int64_t n, int stride, const Params&
   };
   auto expand_all = [&]() {
     std::vector<std::vector<int>> leaves((size_t)K);
+    std::vector<char> taken((size_t)V);
     for (int i = 1; i < depth; ++i) {
       for (int k = 0; k < K; ++k) leaves[k].clear();
       for (int v = 0; v < V; ++v) if (owner[v] >= 0) leaves[owner[v]].push_back(v);   // ascending voxel id = idx_ order
+      std::fill(taken.begin(), taken.end(), 0);
       for (int k = 0; k < K; ++k) {
         if (!alive[k]) continue;
         for (int leaf : leaves[k]) {
-          if (owner[leaf] != k) continue;            // stolen earlier in this round: no longer in leaves_
+          // taken by an earlier supervoxel of this round: erased from leaves_; a voxel this supervoxel wins (back) joins
+          // leaves_ only after its turn (new_owned), so it is not expanded from in this round either
+          if (taken[leaf]) continue;
           for (int o = 0; o < 27; ++o) {
             const int nb = n27[(size_t)27 * leaf + o];
             if (nb < 0 || owner[nb] == k) continue;
             const float d = vccs_distance(&cen[3 * nb], &nrm[3 * nb], &sc[3 * k], &sn[3 * k], w_s_over_seed, w_n);
-            if (d < dist[nb]) { dist[nb] = d; owner[nb] = k; }   // joins leaves_ only after this supervoxel's turn
+            if (d < dist[nb]) { dist[nb] = d; owner[nb] = k; taken[nb] = 1; }
           }
         }
       }

@@ -80,3 +80,53 @@ def test_end_to_end_matches_oracle_pipeline(run, oracle):
     np.testing.assert_array_equal(run["eng"].point_labels(), pl)
     c = run["eng"].counts()
     assert c["clusters"] == ref.clusters_num
+
+
+# ---- vccs_mode 1: pcl::SupervoxelClustering's own order (sequential owners, 2-ring normals, seed rejection) -----------------
+@pytest.fixture(scope="module", params=[("urban", 200_000), ("pc", 120_000), ("town", 150_000)], ids=["urban", "pc", "town"])
+def run_pcl(request, gpu, oracle):
+    name, n = request.param
+    xyz = {"urban": gpu.scenes.urban_scene, "pc": gpu.scenes.pc_scene, "town": gpu.scenes.town_scene}[name](n)
+    p = gpu.default_params(3, vccs_mode=1)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    labels, max_label = eng.supervoxel_labels()
+    return dict(eng=eng, xyz=xyz, labels=labels, max_label=max_label, p=p)
+
+
+def test_pcl_order_labels_match_the_sequential_restatement(run_pcl, oracle):
+    """The GPU resolves PCL's sequential owner order with a fixed point over 'live' leaves; the oracle simply takes the
+    supervoxels' turns one after the other (refcpu_vccs.cpp: vccs_pcl_supervoxels).  Same labels, point for point."""
+    ref_labels, ref_max = oracle.vccs_pcl(run_pcl["xyz"], oracle_params(oracle, run_pcl["p"]))
+    assert run_pcl["max_label"] == ref_max
+    np.testing.assert_array_equal(run_pcl["labels"], ref_labels)
+    assert (run_pcl["labels"] == 0).mean() < 0.02
+    # the two modes are different algorithms: they must not agree by accident of falling through to the same code
+    sync_labels, _ = oracle.vccs(run_pcl["xyz"], oracle_params(oracle, run_pcl["p"]))
+    assert (sync_labels != ref_labels).mean() > 0.05
+
+
+def test_pcl_order_end_to_end(run_pcl, oracle):
+    ref = oracle.run_svgs_from_labels(run_pcl["xyz"], run_pcl["labels"], run_pcl["max_label"], oracle_params(oracle, run_pcl["p"]))
+    pl, _ = ref.labels()
+    np.testing.assert_array_equal(run_pcl["eng"].point_labels(), pl)
+
+
+def test_pcl_order_switch_rolls_the_labels_back(gpu):
+    """vccs_mode is one of the VCCS parameters: changing it invalidates supervoxel labels made by the other mode."""
+    xyz = gpu.scenes.urban_scene(60_000)
+    p = gpu.default_params(3)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    a, _ = eng.supervoxel_labels()
+    p.vccs_mode = 1
+    eng.set_params(p)
+    eng.run()
+    b, _ = eng.supervoxel_labels()
+    assert (a != b).any()
+    e2 = gpu.Engine(gpu.default_params(3, vccs_mode=1))
+    e2.set_points(xyz)
+    e2.run()
+    np.testing.assert_array_equal(b, e2.supervoxel_labels()[0])

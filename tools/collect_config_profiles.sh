@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profiles
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-for cfg in c2 c4; do
+for cfg in c2 c4 c4p; do
   python3 $R/tools/run_config.py $cfg 0 5 > $out/${tag}_${cfg}_line.json 2> $out/${tag}_${cfg}_stderr.txt
   rm -rf /tmp/kt_$cfg
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$cfg -o kt -- python3 $R/tools/run_config.py $cfg 0 5 > /dev/null 2>&1

@@ -5,12 +5,12 @@
 #   3. --pmc SQ instruction mix           -> per-kernel averages per launch
 # and <tag>_traffic.json = HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE, both reported in KB).
 # Output: gpurun_out/profiles/ (copy into profiles/ to commit).  usage: tools/collect_profiles.sh r01
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profiles
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-cmd="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cmd="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-to-host"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $cmd > $out/${tag}_bench_stdout.txt 2>&1
 cp $out/kt/kt_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do

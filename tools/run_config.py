@@ -14,6 +14,8 @@ elif cfg == "c3":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(2, voxel_size=0.1), "URB10M: urban scene, VGS, voxel 0.1 m, graph 0.5 m"
 elif cfg == "c4":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3), "URB10M: urban scene, SVGS (Task_File_SVGS.txt: voxel 0.05 m, seed 0.25 m, graph 0.5 m)"
+elif cfg == "c4p":
+    xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3, vccs_mode=1), "URB10M: urban scene, SVGS, supervoxels in PCL's own order (vccs_mode 1)"
 elif cfg == "c1":
     xyz, p, name = v.scenes.town_scene(n or 500_000), v.default_params(2), "TOWN stand-in: VGS, Task_File_VGS.txt defaults"
 else:
@@ -23,7 +25,7 @@ eng.set_points(xyz)
 ms, acc = [], {}
 for it in range(steps + 1):
     t = time.perf_counter()
-    if cfg == "c4":
+    if cfg in ("c4", "c4p"):
         eng.supervoxels()   # run() keeps supervoxel labels once they exist: createSupervoxels is part of every step
     eng.run()
     dt = (time.perf_counter() - t) * 1e3

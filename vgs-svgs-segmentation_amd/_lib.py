@@ -31,7 +31,7 @@ class VgsParams(C.Structure):
         ("sig_w", C.c_float), ("cut_thred", C.c_float),
         ("points_min", C.c_int32), ("adjacency_min", C.c_int32), ("voxels_min", C.c_int32),
         ("seed_size", C.c_float), ("color_impt", C.c_float), ("spatial_impt", C.c_float), ("normal_impt", C.c_float),
-        ("q7_count_as_index", C.c_int32), ("device", C.c_int32),
+        ("q7_count_as_index", C.c_int32), ("device", C.c_int32), ("vccs_mode", C.c_int32),
     ]
 
 

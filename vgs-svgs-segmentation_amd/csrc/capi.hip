@@ -183,7 +183,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->nl_cnt.release(); c->nl_slot.release(); c->nl_dw.release(); c->lc_ctab.release();
   c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
   c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_label.release();
-  c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release();
+  c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release(); c->vc_accu.release(); c->vc_live.release(); c->vc_alive.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
   c->owned.release(); c->straddle.release(); c->mixsrc.release(); c->bnd_code.release(); c->bnd_root.release(); c->root_label.release();
@@ -215,7 +215,7 @@ vgs_status vgs_set_params(vgs_ctx* c, const vgs_params* p) {
   if (p->graph_size != o.graph_size) keep = ST_FEATURES;
   if (p->points_min != o.points_min) keep = ST_VOXELS;
   if (p->voxel_size != o.voxel_size || p->seed_size != o.seed_size || p->color_impt != o.color_impt ||
-      p->spatial_impt != o.spatial_impt || p->normal_impt != o.normal_impt)
+      p->spatial_impt != o.spatial_impt || p->normal_impt != o.normal_impt || p->vccs_mode != o.vccs_mode)
     keep = ST_POINTS;
   if (c->stage > keep) c->stage = keep;
   // labels from svgs_supervoxels depend on voxel_size / seed_size / the three importances; a caller's own labelling does not

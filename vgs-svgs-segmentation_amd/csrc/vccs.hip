@@ -266,6 +266,333 @@ __global__ void k_vccs_point_labels(const uint32_t* __restrict__ perm, const uin
   out[perm[j]] = (v == 0xffffffffu || label[v] < 0) ? 0 : label[v] + 1;  // getLabeledCloud: 0 = unassigned (SS:303)
 }
 
+// ================================================================ vccs_mode 1: PCL's own order
+// pcl::SupervoxelClustering (1.8.1) step by step, restated from recollection (PCL is not available here: parity with it stays
+// unpinned; oracle/refcpu_vccs.cpp: vccs_pcl_supervoxels is the sequential CPU statement these kernels equal label for label):
+//   * normals from the 2-ring of voxel centroids (indices = [v] + for every neighbour t: [t] + the neighbours of t, the leaf
+//     itself being its own neighbour) through computePointNormal's single-pass covariance, flipped towards (0,0,0);
+//   * seeds: the voxel nearest to the centre of every occupied seed_res cell, cells in ascending Morton order
+//     (getOccupiedVoxelCenters), rejected unless more than 0.05 (seed/2)^2 pi / res^2 voxels lie within seed/2;
+//   * expansion, (int)(1.8 seed / res) - 1 rounds: the supervoxels take their turns ONE AFTER THE OTHER in label order, each
+//     offering its current centroid to the 27-neighbourhood of the leaves it still owns at its turn; a voxel goes to an offer
+//     strictly below its recorded distance, and recorded distances persist.  Sequential semantics, parallel execution: a leaf
+//     is expanded from at its owner S's turn iff no supervoxel with a smaller label took it earlier in the round ("live"), and
+//     whether T < S takes it depends only on the leaves of T that are live -- a recursion on smaller labels.  The live flags
+//     are therefore iterated to their fixed point (a few sweeps), then every voxel folds the offers of the supervoxels that
+//     touch it through live leaves in label order.  The result is exactly the sequential one (tests: equal to the oracle);
+//   * centroids from all leaves after every round (integer fixed-point sums), supervoxels without voxels removed for good;
+//   * refineSupervoxels(5): re-seed at the member voxel nearest to the centroid, reset every voxel, expand again.
+// Divergences from PCL that remain: the lattice is the class's own octree's (PCL's adjacency octree anchors at the
+// cloud's minimum corner) and the seed grid hangs on it; re-seeding searches the supervoxel's own voxels (PCL: kd-tree over all);
+// refineNormals is skipped; FLANN's tie order is replaced by (distance, voxel id); centroid sums are fixed point.
+__device__ __forceinline__ int vccs_nbr27(const int32_t* __restrict__ nbr, int64_t V, int64_t v, int o) {
+  int dx, dy, dz;
+  vccs_offset27(o, &dx, &dy, &dz);
+  if (dx == 0 && dy == 0 && dz == 0) return (int)v;
+  return nbr[(int64_t)vccs_index26(dx, dy, dz) * V + v];
+}
+
+__global__ void k_pcl_accu1(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, VccsAccu* __restrict__ A1) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= V) return;
+  VccsAccu A;
+  vccs_accu_zero(&A);
+  for (int o = 0; o < 27; ++o) { const int u = vccs_nbr27(nbr, V, t, o); if (u >= 0) vccs_accu_point(&A, &cen[3 * (int64_t)u]); }
+  A1[t] = A;
+}
+
+__global__ void k_pcl_normals(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, const VccsAccu* __restrict__ A1,
+                              float* __restrict__ nrm) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  VccsAccu A;
+  vccs_accu_zero(&A);
+  vccs_accu_point(&A, &cen[3 * v]);
+  for (int o = 0; o < 27; ++o) {
+    const int t = vccs_nbr27(nbr, V, v, o);
+    if (t < 0) continue;
+    vccs_accu_point(&A, &cen[3 * (int64_t)t]);
+    const VccsAccu B = A1[t];
+    vccs_accu_add(&A, &B);
+  }
+  float n[3];
+  vccs_accu_normal(&A, &cen[3 * v], n);
+  nrm[3 * v] = n[0]; nrm[3 * v + 1] = n[1]; nrm[3 * v + 2] = n[2];
+}
+
+// seed cells in Morton order: sort key = Morton code of the cell's integer coordinates
+__global__ void k_pcl_cell_codes(const float* __restrict__ cen, int64_t V, float min_x, float min_y, float min_z, float seed,
+                                 uint64_t* __restrict__ code, uint32_t* __restrict__ id) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint64_t cell = vccs_seed_cell(cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], min_x, min_y, min_z, seed);
+  code[v] = vm_morton((uint32_t)((cell >> 42) & 0x1fffff), (uint32_t)((cell >> 21) & 0x1fffff), (uint32_t)(cell & 0x1fffff));
+  id[v] = (uint32_t)v;
+}
+
+__global__ void k_pcl_pick_seeds(const uint64_t* __restrict__ mcode, const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ scan,
+                                 int64_t V, const float* __restrict__ cen, float min_x, float min_y, float min_z, float seed,
+                                 unsigned long long* __restrict__ seed_key) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V) return;
+  const uint32_t v = sorted_id[j];
+  const uint32_t cellrank = scan[j] - 1u;
+  const uint64_t m = mcode[j];
+  const uint64_t cell = ((uint64_t)vm_compact21(m >> 2) << 42) | ((uint64_t)vm_compact21(m >> 1) << 21) | (uint64_t)vm_compact21(m);
+  const float d2 = vccs_cell_center_d2(cell, cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], min_x, min_y, min_z, seed);
+  atomicMin(&seed_key[cellrank], ((unsigned long long)vm_bits(d2) << 32) | (unsigned long long)v);
+}
+
+// selectInitialSupervoxelSeeds: a seed voxel stays if more than min_points voxel centroids lie within seed / 2 of its own
+__global__ void k_pcl_seed_filter(const unsigned long long* __restrict__ seed_key, int K0, const uint64_t* __restrict__ vox_code, int depth,
+                                  const Brick* __restrict__ bricks, uint32_t hbits, const float* __restrict__ cen, float rad2, int R,
+                                  float min_points, uint32_t* __restrict__ keep) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K0) return;
+  const uint32_t s = (uint32_t)seed_key[k];
+  const uint64_t code = vox_code[s];
+  const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
+  const uint32_t lim = 1u << depth;
+  int num = 0;
+  for (int dz = -R; dz <= R; ++dz)
+    for (int dy = -R; dy <= R; ++dy)
+      for (int dx = -R; dx <= R; ++dx) {
+        const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;
+        if (!(nx < lim && ny < lim && nz < lim)) continue;
+        bool unused_flag;
+        const int u = brick_find(bricks, hbits, nx, ny, nz, &unused_flag);
+        if (u < 0) continue;
+        const float ex = cen[3 * (int64_t)u] - cen[3 * (int64_t)s], ey = cen[3 * (int64_t)u + 1] - cen[3 * (int64_t)s + 1], ez = cen[3 * (int64_t)u + 2] - cen[3 * (int64_t)s + 2];
+        if ((ex * ex + ey * ey) + ez * ez < rad2) ++num;
+      }
+  keep[k] = ((float)num > min_points) ? 1u : 0u;
+}
+
+__global__ void k_pcl_compact_seeds(const unsigned long long* __restrict__ seed_key, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keep_scan_excl,
+                                    int K0, uint32_t* __restrict__ seeds) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K0 && keep[k]) seeds[keep_scan_excl[k]] = (uint32_t)seed_key[k];
+}
+
+__global__ void k_pcl_reset(int64_t V, int32_t* __restrict__ owner, float* __restrict__ dist) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) { owner[v] = -1; dist[v] = 3.4028235e38f; }
+}
+
+// addLeaf of the seeds: the recorded distance of the seed voxel stays at its initial maximum
+__global__ void k_pcl_plant_first(const uint32_t* __restrict__ seeds, int K, const float* __restrict__ cen, const float* __restrict__ nrm,
+                                  int32_t* __restrict__ owner, VccsState* __restrict__ st, uint8_t* __restrict__ alive) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const uint32_t s = seeds[k];
+  owner[s] = k;
+  alive[k] = 1;
+  for (int a = 0; a < 3; ++a) { st[k].c[a] = cen[3 * (int64_t)s + a]; st[k].n[a] = nrm[3 * (int64_t)s + a]; }
+}
+
+// re-seeding: the supervoxel keeps its centroid; its new only leaf is the member voxel that was nearest to it
+__global__ void k_pcl_plant_again(const unsigned long long* __restrict__ seed_key, int K, const uint8_t* __restrict__ alive, int32_t* __restrict__ owner) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K || !alive[k] || seed_key[k] == ~0ull) return;
+  owner[(uint32_t)seed_key[k]] = k;
+}
+
+// The offers a voxel gets in one round, folded in label order: the supervoxels < limit that touch it through a live leaf of
+// its 27-neighbourhood (itself included).  Returns the owner after the fold; *d_out its recorded distance.
+__device__ __forceinline__ int vccs_pcl_fold(int64_t V, int64_t v, const int32_t* __restrict__ nbr, const int32_t* __restrict__ owner0,
+                                             const float* __restrict__ dist0, const uint8_t* __restrict__ live, const float* __restrict__ cen,
+                                             const float* __restrict__ nrm, const VccsState* __restrict__ st, float w_s_over_seed, float w_n, int limit,
+                                             float* d_out) {
+  int lab[27];
+  int nl = 0;
+  for (int o = 0; o < 27; ++o) {
+    const int l = vccs_nbr27(nbr, V, v, o);
+    if (l < 0) continue;
+    const int s = owner0[l];
+    if (s < 0 || s >= limit || !live[l]) continue;
+    int pos = nl;
+    bool dup = false;
+    for (int q = 0; q < nl; ++q) if (lab[q] == s) { dup = true; break; }
+    if (dup) continue;
+    while (pos > 0 && lab[pos - 1] > s) { lab[pos] = lab[pos - 1]; --pos; }   // insertion: ascending labels
+    lab[pos] = s;
+    ++nl;
+  }
+  int cur = owner0[v];
+  float cd = dist0[v];
+  const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
+  const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
+  for (int q = 0; q < nl; ++q) {
+    const int s = lab[q];
+    if (s == cur) continue;
+    const float d = vccs_distance(c, n, st[s].c, st[s].n, w_s_over_seed, w_n);
+    if (d < cd) { cd = d; cur = s; }
+  }
+  *d_out = cd;
+  return cur;
+}
+
+// one sweep of the live flags: a leaf of S is live iff the offers of the supervoxels before S leave it with S
+__global__ void k_pcl_live(int64_t V, const int32_t* __restrict__ nbr, const int32_t* __restrict__ owner0, const float* __restrict__ dist0,
+                           const uint8_t* __restrict__ live_in, const float* __restrict__ cen, const float* __restrict__ nrm,
+                           const VccsState* __restrict__ st, float w_s_over_seed, float w_n, uint8_t* __restrict__ live_out,
+                           unsigned int* __restrict__ changed) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int s = owner0[v];
+  uint8_t l = 0;
+  if (s >= 0) {
+    float d;
+    l = vccs_pcl_fold(V, v, nbr, owner0, dist0, live_in, cen, nrm, st, w_s_over_seed, w_n, s, &d) == s ? 1 : 0;
+  }
+  live_out[v] = l;
+  if (l != live_in[v]) atomicOr(changed, 1u);
+}
+
+__global__ void k_pcl_live_init(int64_t V, const int32_t* __restrict__ owner, uint8_t* __restrict__ live) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) live[v] = owner[v] >= 0 ? 1 : 0;
+}
+
+__global__ void k_pcl_claim(int64_t V, const int32_t* __restrict__ nbr, const int32_t* __restrict__ owner0, const float* __restrict__ dist0,
+                            const uint8_t* __restrict__ live, const float* __restrict__ cen, const float* __restrict__ nrm,
+                            const VccsState* __restrict__ st, float w_s_over_seed, float w_n, int32_t* __restrict__ owner1, float* __restrict__ dist1) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float d;
+  owner1[v] = vccs_pcl_fold(V, v, nbr, owner0, dist0, live, cen, nrm, st, w_s_over_seed, w_n, 0x7fffffff, &d);
+  dist1[v] = d;
+}
+
+__global__ void k_pcl_update(int K, const long long* __restrict__ sums, const unsigned int* __restrict__ count, VccsState* __restrict__ st,
+                             uint8_t* __restrict__ alive) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K || !alive[k]) return;
+  if (count[k] == 0) { alive[k] = 0; return; }   // removed for good
+  vccs_state_from_sums(&sums[6 * k], count[k], st[k].c, st[k].n);
+}
+
+__global__ void k_pcl_max_label(int K, const uint8_t* __restrict__ alive, unsigned int* __restrict__ out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K && alive[k]) atomicMax(out, (unsigned int)(k + 1));
+}
+
+static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
+  const int64_t V = c->V, N = c->N;
+  const int TB = 256;
+  const unsigned nbV = (unsigned)((V + TB - 1) / TB);
+  DevBuf<float>& cen = c->vc_cen; DevBuf<float>& nrm = c->vc_nrm; DevBuf<float>& dist = c->vc_dist;
+  VGS_HIP_TRY(c, cen.ensure(3 * V)); VGS_HIP_TRY(c, nrm.ensure(3 * V)); VGS_HIP_TRY(c, dist.ensure(2 * V));
+  VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
+  static_assert(sizeof(VccsAccu) == 40, "VccsAccu");
+  VGS_HIP_TRY(c, c->vc_accu.ensure(10 * (size_t)V)); VGS_HIP_TRY(c, c->vc_live.ensure(2 * (size_t)V));
+  VGS_HIP_TRY(c, c->counters.ensure(64));
+  hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
+  { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
+  // the 26-neighbour table (its 1-ring normals are overwritten by the 2-ring ones)
+  hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                     c->vc_nbr.p, nrm.p);
+  hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p);
+  hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p);
+  // ---- seeds ----
+  const float seed = c->P.seed_size, res = c->P.voxel_size;
+  const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
+  VGS_HIP_TRY(c, c->cell_code_a.ensure(V)); VGS_HIP_TRY(c, c->cell_code_b.ensure(V));
+  VGS_HIP_TRY(c, c->cell_id_a.ensure(V)); VGS_HIP_TRY(c, c->cell_id_b.ensure(V));
+  VGS_HIP_TRY(c, c->head_flag.ensure(V + 1)); VGS_HIP_TRY(c, c->perm_a.ensure(V + 1));
+  hipLaunchKernelGGL(k_pcl_cell_codes, dim3(nbV), dim3(TB), 0, c->stream, cen.p, V, mnx, mny, mnz, seed, c->cell_code_a.p, c->cell_id_a.p);
+  size_t sort_bytes = 0, scan_bytes = 0, scan2_bytes = 0;
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, c->cell_code_a.p, c->cell_code_b.p, c->cell_id_a.p, c->cell_id_b.p, (size_t)V, 0, 63, c->stream));
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+  VGS_HIP_TRY(c, rocprim::exclusive_scan(nullptr, scan2_bytes, c->head_flag.p, c->perm_a.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+  VGS_HIP_TRY(c, c->sort_tmp.ensure(std::max(sort_bytes, std::max(scan_bytes, scan2_bytes))));
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs(c->sort_tmp.p, sort_bytes, c->cell_code_a.p, c->cell_code_b.p, c->cell_id_a.p, c->cell_id_b.p, (size_t)V, 0, 63, c->stream));
+  hipLaunchKernelGGL(k_vccs_heads, dim3(nbV), dim3(TB), 0, c->stream, c->cell_code_b.p, V, c->head_flag.p);
+  uint32_t* scan = c->perm_a.p;
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+  uint32_t K0u = 0;
+  VGS_HIP_TRY(c, hipMemcpyAsync(&K0u, scan + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int K0 = (int)K0u;
+  const unsigned nbK0 = (unsigned)((K0 + TB - 1) / TB);
+  VGS_HIP_TRY(c, c->vc_seedkey.ensure(K0));
+  unsigned long long* seed_key = (unsigned long long*)c->vc_seedkey.p;
+  hipLaunchKernelGGL(k_vccs_fill_u64, dim3(nbK0), dim3(TB), 0, c->stream, seed_key, (int64_t)K0, ~0ull);
+  hipLaunchKernelGGL(k_pcl_pick_seeds, dim3(nbV), dim3(TB), 0, c->stream, c->cell_code_b.p, c->cell_id_b.p, scan, V, cen.p, mnx, mny, mnz, seed, seed_key);
+  // rejection + compaction (the scan buffers are free again: keep flags in head_flag, their exclusive scan in perm_a, seeds in cell_id_a)
+  const float rad = 0.5f * seed;
+  hipLaunchKernelGGL(k_pcl_seed_filter, dim3(nbK0), dim3(TB), 0, c->stream, seed_key, K0, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                     rad * rad, (int)(rad / res) + 1, vccs_seed_min_points(seed, res), c->head_flag.p);
+  VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, scan2_bytes, c->head_flag.p, c->perm_a.p, 0u, (size_t)K0, rocprim::plus<uint32_t>(), c->stream));
+  uint32_t tail[2] = {0, 0};
+  VGS_HIP_TRY(c, hipMemcpyAsync(&tail[0], c->perm_a.p + (K0 - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipMemcpyAsync(&tail[1], c->head_flag.p + (K0 - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int K = (int)(tail[0] + tail[1]);
+  c->sv_max_label = 0;
+  c->counts[VGS_N_SUPERVOXELS] = K;
+  if (K == 0) {
+    VGS_HIP_TRY(c, hipMemsetAsync(c->sv_label.p, 0, (size_t)N * 4, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sv_have_labels = true;
+    return VGS_OK;
+  }
+  uint32_t* seeds = c->cell_id_a.p;
+  hipLaunchKernelGGL(k_pcl_compact_seeds, dim3(nbK0), dim3(TB), 0, c->stream, seed_key, c->head_flag.p, c->perm_a.p, K0, seeds);
+  const unsigned nbK = (unsigned)((K + TB - 1) / TB);
+  VGS_HIP_TRY(c, c->vc_sums.ensure(6 * (size_t)K)); VGS_HIP_TRY(c, c->vc_count.ensure(K)); VGS_HIP_TRY(c, c->vc_state.ensure(6 * (size_t)K));
+  VGS_HIP_TRY(c, c->vc_alive.ensure(K)); VGS_HIP_TRY(c, c->vc_seedkey.ensure(std::max(K, K0)));
+  seed_key = (unsigned long long*)c->vc_seedkey.p;
+  VccsState* state = (VccsState*)c->vc_state.p;
+  // ---- extract + refineSupervoxels(5) ----
+  const int depth = (int)(1.8f * seed / res);
+  const float w_s_over_seed = c->P.spatial_impt / seed, w_n = c->P.normal_impt;
+  int32_t* own[2] = {c->vc_label.p, c->vc_label.p + V};
+  float* dst[2] = {dist.p, dist.p + V};
+  uint8_t* live[2] = {c->vc_live.p, c->vc_live.p + V};
+  unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);
+  int cur = 0;
+  hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
+  hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
+  for (int pass = 0; pass < 6; ++pass) {
+    if (pass > 0) {
+      hipLaunchKernelGGL(k_vccs_fill_u64, dim3(nbK), dim3(TB), 0, c->stream, seed_key, (int64_t)K, ~0ull);
+      hipLaunchKernelGGL(k_vccs_reseed, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, state, seed_key);
+      hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
+      hipLaunchKernelGGL(k_pcl_plant_again, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, c->vc_alive.p, own[cur]);
+    }
+    for (int it = 1; it < depth; ++it) {
+      int lc = 0;
+      hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
+      for (int sweep = 0; sweep < 4096; ++sweep) {   // fixed point of the live flags: the recursion is on smaller labels, so it ends
+        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
+                           live[lc ^ 1], d_changed);
+        lc ^= 1;
+        unsigned int ch = 0;
+        VGS_READBACK(c, &ch, d_changed, 4);
+        if (!ch) break;
+      }
+      hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
+                         own[cur ^ 1], dst[cur ^ 1]);
+      cur ^= 1;
+      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * sizeof(long long), c->stream));
+      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
+      hipLaunchKernelGGL(k_vccs_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+      hipLaunchKernelGGL(k_pcl_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state, c->vc_alive.p);
+    }
+  }
+  hipLaunchKernelGGL(k_vccs_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, own[cur], N, c->sv_label.p);
+  VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_pcl_max_label, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_alive.p, d_changed);
+  unsigned int mx = 0;
+  VGS_READBACK(c, &mx, d_changed, 4);
+  VGS_HIP_TRY(c, hipGetLastError());
+  c->sv_max_label = (int32_t)mx;   // getMaxLabel(): the largest label still in use
+  c->sv_have_labels = true;
+  return VGS_OK;
+}
+
 // ---------------------------------------------------------------- driver
 vgs_status vgs_stage_vccs(vgs_ctx* c) {
   // the class's own octree at voxel_resolution_ (SS:85, test:138-142) provides the VCCS voxels
@@ -275,6 +602,7 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->sv_label.ensure(N > 0 ? N : 1));
   c->sv_max_label = 0;
   if (V == 0) { if (N > 0) VGS_HIP_TRY(c, hipMemsetAsync(c->sv_label.p, 0, N * 4, c->stream)); c->sv_have_labels = true; return VGS_OK; }
+  if (c->P.vccs_mode == 1) return vgs_stage_vccs_pcl(c);
   const int TB = 256;
   const unsigned nbV = (unsigned)((V + TB - 1) / TB);
   static_assert(sizeof(VccsState) == 24, "VccsState");

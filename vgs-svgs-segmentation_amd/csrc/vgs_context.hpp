@@ -219,6 +219,8 @@ struct vgs_ctx {
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
   DevBuf<uint32_t> vc_count;
+  DevBuf<float> vc_accu;        // vccs_mode 1: 1-ring covariance accumulators (10 floats per voxel)
+  DevBuf<uint8_t> vc_live, vc_alive;   // vccs_mode 1: leaf is expanded from at its owner's turn (two sweeps' worth); supervoxel still exists
 
   // multi-GPU
   bool have_region = false;
