@@ -305,12 +305,52 @@ def main():
             eng2.wait_labels()
             lat.append((time.perf_counter() - ts) * 1e3)
         lat = sorted(lat[1:])
+        eng2.close()
+        # the same sequence dealt to TWO contexts (one host thread each, their own streams and staging buffers): the latency-bound
+        # tail of one cloud's step (hand-over kernels, crossValidation, union-find) runs beside the bulk of the other cloud's
+        import threading
+        eng3 = v.Engine(p)
+        hl3 = [v.pinned_empty((xyz.shape[0],), np.int32) for _ in range(2)]
+
+        def seq_on(e, bufs, k_steps):
+            if k_steps <= 0:
+                return
+            e.stage_points(hx)
+            for k in range(k_steps):
+                e.commit_points()
+                if k + 1 < k_steps:
+                    e.stage_points(hx)
+                e.run()
+                e.point_labels_async(bufs[k & 1])
+            e.wait_labels()
+
+        def two_contexts(k_steps):
+            ka, kb = (k_steps + 1) // 2, k_steps // 2
+            bar = threading.Barrier(3)
+            th = [threading.Thread(target=lambda e=e, b=b, k=k: (bar.wait(), seq_on(e, b, k))) for e, b, k in ((eng2, hl, ka), (eng3, hl3, kb))]
+            for t in th:
+                t.start()
+            bar.wait()
+            t_start = time.perf_counter()
+            for t in th:
+                t.join()
+            return time.perf_counter() - t_start
+
+        eng2 = v.Engine(p)                      # (the first one was closed above)
+        two_contexts(2)
+        torch.cuda.synchronize(dev)
+        k2 = max(args.steps, 2)
+        two_elapsed = two_contexts(k2)
+        two_same = bool(np.array_equal(hl3[((k2 // 2) - 1) & 1], labels_dev)) if k2 // 2 > 0 else True
+        eng2.close(); eng3.close()
         h2h = {"value": n_per * args.steps / h2h_elapsed, "unit": "points/s", "ms_per_step": h2h_elapsed / args.steps * 1e3,
+               "two_contexts": {"value": n_per * k2 / two_elapsed, "unit": "points/s", "ms_per_step": two_elapsed / k2 * 1e3, "steps": k2,
+                                "labels_equal_device_resident_run": two_same,
+                                "mode": "the same host-to-host sequence dealt to two contexts (two host threads, own streams): two clouds in flight"},
                "steps": args.steps, "mode": "sequence of clouds: pinned host xyz in -> pinned host labels out, cloud k+1's H2D and cloud k-1's D2H "
                                             "beside cloud k's stages (the first upload and the last download are inside the timed region)",
                "latency_ms_median": lat[len(lat) // 2], "latency_note": "one cloud, nothing overlapped: set_points + run + labels to host, median of 5 after 1",
                "labels_equal_device_resident_run": same}
-        eng2.close()
 
     if rank == 0:
         c = runner.counts()

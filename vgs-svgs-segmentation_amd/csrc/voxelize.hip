@@ -187,8 +187,11 @@ __global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* 
 
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
 // The epochs are read where the growth left them (GrowState on the device): no table goes through the host.
+// KeyT: uint32_t when the valid bit + 3 * depth bits fit 32 (scenes up to 1024 voxels across: the 10 M-point bench scene has
+// depth 10) -- the radix sort then moves 8 instead of 12 bytes per point and pass -- uint64_t otherwise.
+template <typename KeyT>
 __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const GrowState* __restrict__ gs,
-                             double res, int code_bits, uint64_t* __restrict__ code, uint32_t* __restrict__ perm) {
+                             double res, int code_bits, KeyT* __restrict__ code, uint32_t* __restrict__ perm) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = xyz + i * stride_f;
@@ -204,33 +207,36 @@ __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_
     uint32_t kz = vm_axis_key(z, ep.min[2], res) + (uint32_t)(gs->shift[2] - ep.shift[2]);
     c = (1ull << code_bits) | vm_morton(kx, ky, kz);
   }
-  code[i] = c;
+  code[i] = (KeyT)c;
   perm[i] = (uint32_t)i;
 }
 
 // run heads in the sorted code array (invalid codes == 0 sit at the tail of the descending order)
-__global__ void k_heads(const uint64_t* __restrict__ code, int64_t n, uint32_t* __restrict__ head) {
+template <typename KeyT>
+__global__ void k_heads(const KeyT* __restrict__ code, int64_t n, uint32_t* __restrict__ head) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
-    uint64_t c = code[j];
+    KeyT c = code[j];
     head[j] = (c != 0 && (j == 0 || code[j - 1] != c)) ? 1u : 0u;
   }
 }
 
 // number of valid (non-zero) codes = index of the first zero in the descending array
-__global__ void k_count_valid(const uint64_t* __restrict__ code, int64_t n, unsigned long long* __restrict__ n_valid) {
+template <typename KeyT>
+__global__ void k_count_valid(const KeyT* __restrict__ code, int64_t n, unsigned long long* __restrict__ n_valid) {
   int64_t lo = 0, hi = n;
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (code[mid] != 0) lo = mid + 1; else hi = mid; }
   *n_valid = (unsigned long long)lo;
 }
 __global__ void k_copy_last(const uint32_t* __restrict__ scan, int64_t n, unsigned long long* __restrict__ out) { *out = (unsigned long long)scan[n - 1]; }
 
-__global__ void k_voxel_table(const uint64_t* __restrict__ code, const uint32_t* __restrict__ head,
+template <typename KeyT>
+__global__ void k_voxel_table(const KeyT* __restrict__ code, const uint32_t* __restrict__ head,
                               const uint32_t* __restrict__ scan, int64_t n, uint64_t mask, uint32_t* __restrict__ pt_vox,
                               uint64_t* __restrict__ vox_code, uint32_t* __restrict__ vox_start) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  uint64_t c = code[j];
+  uint64_t c = (uint64_t)code[j];
   if (c == 0) { pt_vox[j] = 0xffffffffu; return; }
   uint32_t v = scan[j] - 1u;
   pt_vox[j] = v;
@@ -297,6 +303,49 @@ static vgs_status grow_box(vgs_ctx* c) {
   return vgs_grow_box_from(c, c->box, true);
 }
 
+// codes -> stable descending sort -> run heads -> voxel table (KeyT as k_make_codes)
+template <typename KeyT>
+static vgs_status voxelize_sorted_table(vgs_ctx* c) {
+  const int64_t N = c->N;
+  const int TB = 256;
+  const unsigned nb = (unsigned)((N + TB - 1) / TB);
+  KeyT* code_a = (KeyT*)c->code_a.p;   // the 64-bit buffers hold either key width
+  KeyT* code_b = (KeyT*)c->code_b.p;
+  hipLaunchKernelGGL((k_make_codes<KeyT>), dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, (const GrowState*)c->grow_state.p, c->box.res,
+                     c->code_bits, code_a, c->perm_a.p);
+
+  // stable LSD radix sort, descending code (= PCL LeafNodeIterator order: children visited 7 -> 0),
+  // ascending point index inside a leaf (stability)
+  size_t tmp_bytes = 0;
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, code_a, code_b, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
+                                                (unsigned)(c->code_bits + 1), c->stream));
+  size_t scan_bytes = 0;
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->perm_a.p, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
+  VGS_HIP_TRY(c, c->sort_tmp.ensure(std::max(tmp_bytes, scan_bytes)));
+  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->sort_tmp.p, tmp_bytes, code_a, code_b, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
+                                                (unsigned)(c->code_bits + 1), c->stream));
+  // sorted: code_b, perm_b
+  unsigned long long* d_cnt = (unsigned long long*)c->counters.p;
+  VGS_HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL((k_heads<KeyT>), dim3(nb), dim3(TB), 0, c->stream, code_b, N, c->head_flag.p);
+  hipLaunchKernelGGL((k_count_valid<KeyT>), dim3(1), dim3(1), 0, c->stream, code_b, N, d_cnt);
+  uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
+  VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
+  hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
+  unsigned long long h2[2] = {0, 0};
+  VGS_READBACK(c, h2, d_cnt, sizeof(h2));
+  const unsigned long long nf = h2[0];
+  const uint32_t v_total = (uint32_t)h2[1];
+  c->Nf = (int64_t)nf;
+  c->V = (int64_t)v_total;
+  VGS_HIP_TRY(c, c->vox_code.ensure(c->V + 1)); VGS_HIP_TRY(c, c->vox_start.ensure(c->V + 1));
+  const uint64_t mask = (c->code_bits >= 64) ? ~0ull : ((1ull << c->code_bits) - 1ull);
+  hipLaunchKernelGGL((k_voxel_table<KeyT>), dim3(nb), dim3(TB), 0, c->stream, code_b, c->head_flag.p, scan, N, mask, c->pt_vox.p,
+                     c->vox_code.p, c->vox_start.p);
+  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->vox_start.p + c->V, (uint32_t)c->Nf);
+  return VGS_OK;
+}
+
 vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   const int64_t N = c->N;
   c->V = 0; c->Nf = 0; c->U = 0;
@@ -313,39 +362,8 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->perm_a.ensure(N)); VGS_HIP_TRY(c, c->perm_b.ensure(N));
   VGS_HIP_TRY(c, c->head_flag.ensure(N)); VGS_HIP_TRY(c, c->pt_vox.ensure(N));
   const int TB = 256;
-  const unsigned nb = (unsigned)((N + TB - 1) / TB);
-  hipLaunchKernelGGL(k_make_codes, dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, (const GrowState*)c->grow_state.p, c->box.res,
-                     c->code_bits, c->code_a.p, c->perm_a.p);
-
-  // stable LSD radix sort, descending code (= PCL LeafNodeIterator order: children visited 7 -> 0),
-  // ascending point index inside a leaf (stability)
-  size_t tmp_bytes = 0;
-  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, c->code_a.p, c->code_b.p, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
-                                                (unsigned)(c->code_bits + 1), c->stream));
-  size_t scan_bytes = 0;
-  VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes, c->head_flag.p, c->perm_a.p, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
-  VGS_HIP_TRY(c, c->sort_tmp.ensure(std::max(tmp_bytes, scan_bytes)));
-  VGS_HIP_TRY(c, rocprim::radix_sort_pairs_desc(c->sort_tmp.p, tmp_bytes, c->code_a.p, c->code_b.p, c->perm_a.p, c->perm_b.p, (size_t)N, 0,
-                                                (unsigned)(c->code_bits + 1), c->stream));
-  // sorted: code_b, perm_b
-  unsigned long long* d_cnt = (unsigned long long*)c->counters.p;
-  VGS_HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_heads, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, N, c->head_flag.p);
-  hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, c->stream, c->code_b.p, N, d_cnt);
-  uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
-  VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
-  hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
-  unsigned long long h2[2] = {0, 0};
-  VGS_READBACK(c, h2, d_cnt, sizeof(h2));
-  const unsigned long long nf = h2[0];
-  const uint32_t v_total = (uint32_t)h2[1];
-  c->Nf = (int64_t)nf;
-  c->V = (int64_t)v_total;
-  VGS_HIP_TRY(c, c->vox_code.ensure(c->V + 1)); VGS_HIP_TRY(c, c->vox_start.ensure(c->V + 1));
-  const uint64_t mask = (c->code_bits >= 64) ? ~0ull : ((1ull << c->code_bits) - 1ull);
-  hipLaunchKernelGGL(k_voxel_table, dim3(nb), dim3(TB), 0, c->stream, c->code_b.p, c->head_flag.p, scan, N, mask, c->pt_vox.p,
-                     c->vox_code.p, c->vox_start.p);
-  hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->vox_start.p + c->V, (uint32_t)c->Nf);
+  st = (c->code_bits + 1 <= 32) ? voxelize_sorted_table<uint32_t>(c) : voxelize_sorted_table<uint64_t>(c);
+  if (st != VGS_OK) return st;
   VGS_HIP_TRY(c, c->xs.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->ys.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->zs.ensure(c->Nf + 1));
   if (c->Nf > 0) {
     const unsigned nbf = (unsigned)((c->Nf + TB - 1) / TB);
