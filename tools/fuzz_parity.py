@@ -94,6 +94,21 @@ while time.time() < t_end:
     if not np.array_equal(e.point_labels(), ref.labels()[0]):
         ok = False
         print("MISMATCH labels", kind, n, seed, kw, flush=True)
+    # element order (round 3): connect lists in merge-history order, getClusterIdx in the reference's DFS order; full adjacency lists
+    if ok and runs % 2 == 0:
+        for which in ("connect_cut", "connect_final"):
+            off, idx = e.lists(which, "reference"); roff, ridx = ref.lists(which)
+            if not (np.array_equal(off, roff) and np.array_equal(idx, ridx)):
+                ok = False
+                print("MISMATCH order", which, kind, n, seed, kw, flush=True)
+        co, ci = e.clusters("reference"); rco, rci = ref.lists("clusters_points")
+        if not (np.array_equal(co, rco) and np.array_equal(ci, rci)):
+            ok = False
+            print("MISMATCH cluster order", kind, n, seed, kw, flush=True)
+        ao, ai = e.lists("adjacency"); rao, rai = ref.lists("adjacency")
+        if not (np.array_equal(ao, rao) and np.array_equal(ai, rai)):
+            ok = False
+            print("MISMATCH adjacency (all voxels)", kind, n, seed, kw, flush=True)
     sc = e.schedule_counters()
     runs += 1; bad += 0 if ok else 1
     print(f"run {runs} {kind} n={n} used={e.counts()['used']} handed={sc['handed_over']}/{sc['handed_over_large']} banded={sc['banded']} sent_on={sc['dense_sent_on']} {'ok' if ok else 'BAD'}", flush=True)

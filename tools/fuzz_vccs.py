@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the supervoxel stage (csrc/vccs.hip) and the SVGS pipeline behind it against the oracle:
-random scenes, voxel / seed sizes, importances.  usage: fuzz_vccs.py [seconds] [seed]"""
+random scenes, voxel / seed sizes, importances.  usage: fuzz_vccs.py [seconds] [seed] [vccs_mode]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "oracle"))
@@ -10,6 +10,7 @@ import refcpu_py as oracle
 from helpers import oracle_params
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 1: supervoxels in PCL's own order (vccs_mode 1) against the sequential restatement
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 runs = bad = 0
@@ -21,7 +22,7 @@ while time.time() < t_end:
     kw = dict(voxel_size=float(rng.choice([0.04, 0.05, 0.08])), seed_size=float(rng.choice([0.2, 0.25, 0.4])),
               graph_size=float(rng.choice([0.4, 0.5, 0.7])), spatial_impt=float(rng.choice([0.25, 0.5, 1.0])),
               normal_impt=float(rng.choice([0.25, 0.75, 1.0])), cut_thred=float(rng.choice([0.3, 0.5, 0.7])))
-    p = v.default_params(3, **kw)
+    p = v.default_params(3, vccs_mode=MODE, **kw)
     print("start", kind, n, seed, kw, flush=True)
     try:
         e = v.Engine(p); e.set_points(xyz); e.run()
@@ -29,7 +30,7 @@ while time.time() < t_end:
         print("skip", str(ex)[:90], flush=True)
         continue
     labels, max_label = e.supervoxel_labels()
-    ref_labels, ref_max = oracle.vccs(xyz, oracle_params(oracle, p))
+    ref_labels, ref_max = (oracle.vccs_pcl if MODE == 1 else oracle.vccs)(xyz, oracle_params(oracle, p))
     ok = max_label == ref_max and np.array_equal(labels, ref_labels)
     if ok:
         ref = oracle.run_svgs_from_labels(xyz, ref_labels, ref_max, oracle_params(oracle, p))
