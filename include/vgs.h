@@ -211,11 +211,13 @@ vgs_status vgs_set_grid(vgs_ctx* ctx, const vgs_grid_state* g);
  * their own connections are not trusted).  Components are then built from the connections that have an owned
  * endpoint, cluster sizes count owned voxels, and point labels wait for vgs_apply_root_labels. */
 vgs_status vgs_set_owned_region(vgs_ctx* ctx, const double* lo_xy, const double* hi_xy);
-/* Tiles whose ranks were handed points beyond their own regions (an object that reaches over a tile's edge): points [0, n_own)
- * of the context's cloud are the rank's own load, the rest came with the neighbours' strips.  A voxel that holds points of both
- * kinds then becomes a boundary voxel on the rank that owns it and on the rank that loaded the foreign points, so the latter
- * learns the label of those points from the owner's record.  Call after vgs_set_points*; -1 switches it off. */
-vgs_status vgs_set_own_point_count(vgs_ctx* ctx, int64_t n_own);
+/* A rank's cloud = the points it loaded itself + the border strips of the other ranks, assembled IN RANK ORDER: strips of lower
+ * ranks, own points, strips of higher ranks -- the order in which a single process would have inserted them, because a voxel's
+ * attributes depend on the order of its points (sequential float sums, the normal's flip looks at the voxel's first point, VS:1364,
+ * 1394).  Points [first, first + n_own) are the rank's own load.  A voxel that holds points of both kinds (an object that reaches over
+ * a tile's edge) becomes a boundary voxel on the rank that owns it and on the rank that loaded the foreign points, so the latter
+ * learns the label of those points from the owner's record.  Call after vgs_set_points*; n_own = -1 switches it off. */
+vgs_status vgs_set_own_point_range(vgs_ctx* ctx, int64_t first, int64_t n_own);
 /* after vgs_segment: (global voxel code, local component root) records of the boundary voxels -- both endpoints of
  * every connection that crosses the ownership border, and every owned voxel with a halo voxel in its neighbourhood
  * (a possible closestCheck target of the neighbouring rank); duplicates possible.  Records of all ranks that share

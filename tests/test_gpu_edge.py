@@ -61,9 +61,16 @@ def test_no_voxel_with_enough_points(gpu, oracle):
     eng = gpu.Engine(p); eng.set_points(xyz); eng.run()
     c = eng.counts()
     assert c["used"] == 0 and c["kept"] == 0 and c["clusters"] == c["voxels"] > 0
-    for which in ("adjacency", "connect_cut", "connect_cross", "connect_final"):
+    for which in ("connect_cut", "connect_cross", "connect_final"):
         off, idx = eng.lists(which)
         assert off[-1] == 0 and idx.size == 0
+    # findAllVoxelAdjacency builds a list for every voxel whether it is used or not (VS:236-263): the same as the oracle's
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    off, idx = eng.lists("adjacency")
+    roff, ridx = ref.lists("adjacency")
+    np.testing.assert_array_equal(off, roff)
+    np.testing.assert_array_equal(idx, ridx)
+    assert off[-1] >= c["voxels"]          # every voxel is its own first neighbour
     assert (eng.point_labels() == -1).all()
     root, kept = eng.node_labels()
     assert (root == np.arange(c["voxels"])).all() and (kept == -1).all()

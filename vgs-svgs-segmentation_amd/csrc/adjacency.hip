@@ -497,11 +497,12 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 vgs_status vgs_stage_adjacency(vgs_ctx* c) {
   const int64_t V = c->V, U = c->U;
   c->counts[VGS_N_ADJ] = 0;
-  if (V == 0 || U == 0) return VGS_OK;
+  if (V == 0) return VGS_OK;
   float r2 = 0.f;
-  vgs_status st = build_hash_and_offsets(c, &r2);
+  vgs_status st = build_hash_and_offsets(c, &r2);   // also without a used voxel: vgs_get_lists builds every voxel's list on request
   if (st != VGS_OK) return st;
   c->adj_r2 = r2;
+  if (U == 0) return VGS_OK;
   c->adj_pruned = vgs_unused_are_inert(c->P);
   VGS_HIP_TRY(c, c->adj_key.ensure((size_t)U * c->adj_stride));
   VGS_HIP_TRY(c, c->adj_cnt.ensure(U)); VGS_HIP_TRY(c, c->adj_mused.ensure(U));

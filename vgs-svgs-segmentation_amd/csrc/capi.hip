@@ -236,7 +236,7 @@ static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes)
   for (int i = 0; i < VGS_T_COUNT; ++i) c->times[i] = 0;
   // a supervoxel labelling belongs to the cloud it was made for (SS:279-331 rebuilds it per createSupervoxels call)
   c->sv_have_labels = false; c->sv_labels_external = false; c->sv_max_label = 0; c->sv_label_n = -1;
-  c->n_own = -1;   // tiles: vgs_set_own_point_count follows the cloud
+  c->n_own = -1; c->own_first = 0;   // tiles: vgs_set_own_point_range follows the cloud
   return VGS_OK;
 }
 
@@ -522,7 +522,7 @@ vgs_status vgs_get_attributes(vgs_ctx* c, float* centroid, float* normal, float*
 // (cutorder.hip); false: the members in the order of the adjacency row
 static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::vector<int32_t>>& L, bool ordered = false) {
   const int64_t V = c->V, U = c->U;
-  if (which == 0 && c->P.method == 2 && U > 0) {
+  if (which == 0 && c->P.method == 2 && V > 0) {
     // findAllVoxelAdjacency builds a list for EVERY voxel, used or not, with every neighbour (VS:236-263).  The hot path
     // keeps rows for the used voxels only (and only their used neighbours when unused ones are inert), so the full lists
     // are built here on request: the general kernel over all voxel ids, a chunk of rows at a time.

@@ -150,7 +150,8 @@ vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vecto
   const int64_t U = c->U;
   ord_host.clear(); k_host.assign((size_t)U, 0);
   if (U == 0) return VGS_OK;
-  if (c->adj_stride > CO_MAXK) { c->err = "vgs_cut_order: rows longer than 2048 entries"; return VGS_E_UNSUPPORTED; }
+  // rows hold at most CO_MAXK entries: a longer one fails the local cut itself (VGS_E_UNSUPPORTED there); the row STRIDE (all
+  // lattice offsets of the ball) may well be larger
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   DevBuf<uint32_t> d_k; DevBuf<uint16_t> d_ord; DevBuf<uint64_t> d_offs, d_keys_a, d_keys_b; DevBuf<uint8_t> d_tmp; DevBuf<unsigned int> d_bad;
   auto release = [&]() { d_k.release(); d_ord.release(); d_offs.release(); d_keys_a.release(); d_keys_b.release(); d_tmp.release(); d_bad.release(); };

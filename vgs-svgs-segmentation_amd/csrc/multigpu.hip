@@ -13,12 +13,13 @@
 #include "vgs_context.hpp"
 
 // per voxel: does it hold points this rank loaded itself (mix[v]) / points that came with another rank's strip (mix[V + v])?
-__global__ void k_point_sources(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, int64_t nf, int64_t n_own, int64_t V,
-                                uint8_t* __restrict__ mix) {
+__global__ void k_point_sources(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ pt_vox, int64_t nf, int64_t own_first, int64_t n_own,
+                                int64_t V, uint8_t* __restrict__ mix) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nf) return;
   const uint32_t v = pt_vox[j];
-  if (v != 0xffffffffu) mix[((int64_t)perm[j] < n_own ? 0 : V) + v] = 1;   // every writer stores the same value
+  const int64_t i = (int64_t)perm[j];
+  if (v != 0xffffffffu) mix[((i >= own_first && i < own_first + n_own) ? 0 : V) + v] = 1;   // every writer stores the same value
 }
 
 __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float res_f, float min_x, float min_y, double lo_x, double lo_y,
@@ -48,7 +49,7 @@ vgs_status vgs_compute_owned(vgs_ctx* c) {
   if (c->n_own >= 0 && c->Nf > 0) {
     VGS_HIP_TRY(c, c->mixsrc.ensure(2 * (size_t)c->V));
     VGS_HIP_TRY(c, hipMemsetAsync(c->mixsrc.p, 0, 2 * (size_t)c->V, c->stream));
-    hipLaunchKernelGGL(k_point_sources, dim3((unsigned)((c->Nf + 255) / 256)), dim3(256), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->Nf, c->n_own, c->V, c->mixsrc.p);
+    hipLaunchKernelGGL(k_point_sources, dim3((unsigned)((c->Nf + 255) / 256)), dim3(256), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->Nf, c->own_first, c->n_own, c->V, c->mixsrc.p);
     mix = c->mixsrc.p;
   }
   hipLaunchKernelGGL(k_owned, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, c->V, c->P.voxel_size,
@@ -318,8 +319,9 @@ vgs_status vgs_set_owned_region(vgs_ctx* c, const double* lo, const double* hi) 
   return VGS_OK;
 }
 
-vgs_status vgs_set_own_point_count(vgs_ctx* c, int64_t n_own) {
-  if (!c || n_own < -1) return VGS_E_ARG;
+vgs_status vgs_set_own_point_range(vgs_ctx* c, int64_t first, int64_t n_own) {
+  if (!c || n_own < -1 || first < 0) return VGS_E_ARG;
+  c->own_first = first;
   c->n_own = n_own;
   if (c->stage > ST_ADJACENCY) c->stage = ST_ADJACENCY;
   return VGS_OK;

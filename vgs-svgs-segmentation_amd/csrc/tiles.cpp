@@ -189,7 +189,7 @@ struct vgs_tiles {
   double pitch = 0, cx = 0, cy = 0;
   double lo[2] = {0, 0}, hi[2] = {0, 0};
   std::vector<float> local;   // tile + halo, packed xyz
-  int64_t n_own = 0, n_outside = 0, n_records = 0, kept = 0;
+  int64_t own_first = 0, n_own = 0, n_outside = 0, n_records = 0, kept = 0;
   std::string err;
 };
 
@@ -262,20 +262,24 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
   }
   std::vector<std::vector<float>> strips;
   TCOMM(all_gather_varlen(c, strip, strips));
-  t->local.resize((size_t)n * 3);
-  for (int64_t k = 0; k < n; ++k) { t->local[3 * k] = xyz[k * sf]; t->local[3 * k + 1] = xyz[k * sf + 1]; t->local[3 * k + 2] = xyz[k * sf + 2]; }
-  for (int r = 0; r < c.world; ++r) {
-    if (r == c.rank) continue;
+  // the local cloud in RANK ORDER: strips of lower ranks, own points, strips of higher ranks -- the order in which one process
+  // would have inserted the points (a voxel's attributes depend on the order of its points; see dist.py)
+  t->local.clear();
+  auto take_strip = [&](int r) {
     const std::vector<float>& s = strips[(size_t)r];
     for (size_t k = 0; k + 2 < s.size(); k += 3) {
       const double x = (double)s[k], y = (double)s[k + 1];
       if (x >= t->lo[0] - h && x < t->hi[0] + h && y >= t->lo[1] - h && y < t->hi[1] + h) { t->local.push_back(s[k]); t->local.push_back(s[k + 1]); t->local.push_back(s[k + 2]); }
     }
-  }
+  };
+  for (int r = 0; r < c.rank; ++r) take_strip(r);
+  t->own_first = (int64_t)(t->local.size() / 3);
+  for (int64_t k = 0; k < n; ++k) { t->local.push_back(xyz[k * sf]); t->local.push_back(xyz[k * sf + 1]); t->local.push_back(xyz[k * sf + 2]); }
+  for (int r = c.rank + 1; r < c.world; ++r) take_strip(r);
   t->n_own = n;
   TCTX(vgs_set_points(t->ctx, t->local.data(), (int64_t)(t->local.size() / 3), 12));
   TCTX(vgs_set_owned_region(t->ctx, t->lo, t->hi));
-  TCTX(vgs_set_own_point_count(t->ctx, t->n_own));
+  TCTX(vgs_set_own_point_range(t->ctx, t->own_first, t->n_own));
   return VGS_OK;
 }
 
@@ -375,7 +379,7 @@ vgs_status vgs_tiles_get_point_labels(vgs_tiles* t, int32_t* labels, int64_t* ke
   if (!t || (!labels && t->n_own > 0)) return VGS_E_ARG;
   std::vector<int32_t> all(t->local.size() / 3 + 1);
   TCTX(vgs_get_point_labels(t->ctx, all.data()));
-  std::copy(all.begin(), all.begin() + (ptrdiff_t)t->n_own, labels);   // halo points belong to other ranks
+  std::copy(all.begin() + (ptrdiff_t)t->own_first, all.begin() + (ptrdiff_t)(t->own_first + t->n_own), labels);   // halo points belong to other ranks
   if (kept_global) *kept_global = t->kept;
   return VGS_OK;
 }

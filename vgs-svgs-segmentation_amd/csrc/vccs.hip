@@ -405,11 +405,15 @@ __device__ __forceinline__ int vccs_pcl_fold(int64_t V, int64_t v, const int32_t
                                              float* d_out) {
   int lab[27];
   int nl = 0;
+  const int own = owner0[v];
   for (int o = 0; o < 27; ++o) {
     const int l = vccs_nbr27(nbr, V, v, o);
     if (l < 0) continue;
     const int s = owner0[l];
-    if (s < 0 || s >= limit || !live[l]) continue;
+    // an offer of the voxel's own owner changes nothing as long as nobody else offers: it is kept in the list only for the case
+    // that another supervoxel takes the voxel first, so the live flag of such a leaf is not even loaded when it cannot matter
+    if (s < 0 || s >= limit) continue;
+    if (!live[l]) continue;
     int pos = nl;
     bool dup = false;
     for (int q = 0; q < nl; ++q) if (lab[q] == s) { dup = true; break; }
@@ -418,8 +422,9 @@ __device__ __forceinline__ int vccs_pcl_fold(int64_t V, int64_t v, const int32_t
     lab[pos] = s;
     ++nl;
   }
-  int cur = owner0[v];
+  int cur = own;
   float cd = dist0[v];
+  if (nl == 0 || (nl == 1 && lab[0] == own)) { *d_out = cd; return cur; }   // interior voxel: nobody else reaches it
   const float c[3] = {cen[3 * v], cen[3 * v + 1], cen[3 * v + 2]};
   const float n[3] = {nrm[3 * v], nrm[3 * v + 1], nrm[3 * v + 2]};
   for (int q = 0; q < nl; ++q) {
@@ -462,6 +467,49 @@ __global__ void k_pcl_claim(int64_t V, const int32_t* __restrict__ nbr, const in
   float d;
   owner1[v] = vccs_pcl_fold(V, v, nbr, owner0, dist0, live, cen, nrm, st, w_s_over_seed, w_n, 0x7fffffff, &d);
   dist1[v] = d;
+}
+
+// per-supervoxel sums of all leaves: added up per workgroup in an LDS table keyed by label first (a workgroup's 256 voxels are
+// neighbours in space and belong to a handful of supervoxels), one global atomic per (workgroup, supervoxel, component)
+__global__ __launch_bounds__(256) void k_pcl_accumulate(int64_t V, const int32_t* __restrict__ label, const float* __restrict__ cen,
+                                                        const float* __restrict__ nrm, long long* __restrict__ sums, unsigned int* __restrict__ count) {
+  __shared__ int s_key[VX_SLOTS];
+  __shared__ unsigned long long s_sum[VX_SLOTS][6];
+  __shared__ int s_cnt[VX_SLOTS];
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x) {
+    s_key[k] = -1; s_cnt[k] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[k][a] = 0ull;
+  }
+  __syncthreads();
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) {
+    const int l = label[v];
+    if (l >= 0) {
+      long long f[6];
+      for (int a = 0; a < 3; ++a) { f[a] = vccs_fix_pos(cen[3 * v + a]); f[3 + a] = vccs_fix_nrm(nrm[3 * v + a]); }
+      int slot = -1;
+      unsigned int h = ((unsigned int)l * 2654435761u) >> 25;   // 7 bits
+      for (int probe = 0; probe < VX_SLOTS; ++probe) {
+        const int prev = atomicCAS(&s_key[h], -1, l);
+        if (prev == -1 || prev == l) { slot = (int)h; break; }
+        h = (h + 1) & (VX_SLOTS - 1);
+      }
+      if (slot >= 0) {
+        for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], (unsigned long long)f[a]);
+        atomicAdd(&s_cnt[slot], 1);
+      } else {   // a full table sends the contribution straight to memory
+        for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)f[a]);
+        atomicAdd(&count[l], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < VX_SLOTS; k += blockDim.x) {
+    const int l = s_key[k];
+    if (l < 0) continue;
+    for (int a = 0; a < 6; ++a) { const unsigned long long x = s_sum[k][a]; if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], x); }
+    if (s_cnt[k] > 0) atomicAdd(&count[l], (unsigned int)s_cnt[k]);
+  }
 }
 
 __global__ void k_pcl_update(int K, const long long* __restrict__ sums, const unsigned int* __restrict__ count, VccsState* __restrict__ st,
@@ -578,7 +626,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       cur ^= 1;
       VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * sizeof(long long), c->stream));
       VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
-      hipLaunchKernelGGL(k_vccs_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+      hipLaunchKernelGGL(k_pcl_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
       hipLaunchKernelGGL(k_pcl_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state, c->vc_alive.p);
     }
   }

@@ -226,7 +226,7 @@ struct vgs_ctx {
   bool have_region = false;
   double own_lo[2] = {0, 0}, own_hi[2] = {0, 0};
   DevBuf<uint8_t> owned;        // per voxel: 1 = centre inside this rank's region
-  int64_t n_own = -1;           // points [0, n_own) of the cloud were loaded by this rank itself, the rest came with other ranks' strips (-1: not told)
+  int64_t own_first = 0, n_own = -1;   // points [own_first, own_first + n_own) of the cloud were loaded by this rank itself, the rest came with other ranks' strips (-1: not told)
   DevBuf<uint8_t> mixsrc;       // per voxel: holds own-loaded points / holds points from other ranks' strips
   DevBuf<uint8_t> straddle;     // per voxel: 1 = its cube crosses the border of the region (it may hold points of two ranks)
   DevBuf<uint64_t> bnd_code;    // boundary records

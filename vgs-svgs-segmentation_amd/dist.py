@@ -201,6 +201,7 @@ class TiledSegmenter:
         self.coll_device = None  # where collective payloads live: the GPU for RCCL ("nccl"), the host for gloo
         self._keep = None
         self.n_own = 0
+        self.own_first = 0
         self.kept = 0
 
     # -- input: own points + halo strips of the neighbours (data loading, outside the timed region) --
@@ -220,30 +221,38 @@ class TiledSegmenter:
         x, y = xyz_host[:, 0].astype(np.float64), xyz_host[:, 1].astype(np.float64)
         # Points a rank holds beyond its border (generated tiles whose objects reach over the edge) reach the owner of that ground
         # through the strips below and take part in the owner's voxels.  Their labels are read from this rank's halo computation;
-        # the voxels that hold them are published as boundary voxels by this rank and by their owner (vgs_set_own_point_count),
+        # the voxels that hold them are published as boundary voxels by this rank and by their owner (vgs_set_own_point_range),
         # so the halo voxel's local root carries the owner's label.  n_outside says how many such points there are.
         self.n_outside = int(((x < lo[0]) | (x >= hi[0]) | (y < lo[1]) | (y >= hi[1])).sum())
         near = (x < lo[0] + h) | (x >= hi[0] - h) | (y < lo[1] + h) | (y >= hi[1] - h)
         strips = all_gather_varlen(self.dist, np.ascontiguousarray(xyz_host[near]).reshape(-1), self.coll_device)
-        extra = []
+        # The local cloud is assembled in RANK ORDER -- strips of lower ranks, own points, strips of higher ranks: the order in which
+        # one process would have inserted the points.  A voxel's attributes depend on the order of its points (sequential float
+        # sums; the normal's flip looks at the voxel's first point), so a voxel that holds points of two ranks must see them in the
+        # same order on every rank and in the single engine (found by tools/fuzz_tiles.py: with the own points always first, rank 1
+        # saw the voxels on its border with the two halves swapped, and a few normals in clutter flipped the other way).
+        lower, higher = [], []
         for r, s in enumerate(strips):
             if r == self.rank or s.size == 0:
                 continue
             s = s.reshape(-1, 3)
             sx, sy = s[:, 0].astype(np.float64), s[:, 1].astype(np.float64)
             m = (sx >= lo[0] - h) & (sx < hi[0] + h) & (sy >= lo[1] - h) & (sy < hi[1] + h)
-            extra.append(s[m])
+            (lower if r < self.rank else higher).append(s[m])
         self.n_own = xyz_host.shape[0]
-        if extra and sum(e.shape[0] for e in extra):
-            halo_pts = torch.from_numpy(np.concatenate(extra)).to(self.device)
-            local = torch.cat([d_xyz, halo_pts], dim=0).contiguous()
-        else:
-            local = d_xyz
+        self.own_first = int(sum(e.shape[0] for e in lower))
+        parts = []
+        if self.own_first:
+            parts.append(torch.from_numpy(np.concatenate(lower)).to(self.device))
+        parts.append(d_xyz)
+        if higher and sum(e.shape[0] for e in higher):
+            parts.append(torch.from_numpy(np.concatenate(higher)).to(self.device))
+        local = torch.cat(parts, dim=0).contiguous() if len(parts) > 1 else d_xyz
         torch.cuda.synchronize(self.device)
         self._keep = local
         self.engine.set_points_device(local.data_ptr(), local.shape[0], 12, keep=local)
         self.engine._ck(self.engine._L.vgs_set_owned_region(self.engine._h, _ptr(lo), _ptr(hi)))
-        self.engine._ck(self.engine._L.vgs_set_own_point_count(self.engine._h, int(self.n_own)))
+        self.engine._ck(self.engine._L.vgs_set_own_point_range(self.engine._h, int(self.own_first), int(self.n_own)))
 
     def _chain_grid(self):
         """The shared grid: what inserting the ranks' clouds one after the other does to the octree box.
@@ -346,4 +355,4 @@ class TiledSegmenter:
 
     def point_labels(self):
         """Labels of this rank's own points (halo points belong to other ranks)."""
-        return self.engine.point_labels()[: self.n_own]
+        return self.engine.point_labels()[self.own_first: self.own_first + self.n_own]
