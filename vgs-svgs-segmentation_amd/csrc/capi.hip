@@ -22,19 +22,35 @@ struct RoctxRange {   // a stage = one roctx range (rocprofv3 --marker-trace sho
   ~RoctxRange() { roctxRangePop(); }
 };
 
-// time a stage with HIP events on the context's stream
+// Time a stage with HIP events on the context's stream.  The stage is NOT waited for here (round 3): a stage function waits where
+// it needs a number on the host, and a wait only for the clock left the GPU idle for a host round trip after voxelize, adjacency and
+// the local cut.  The pair of events is read when the times are asked for or at the end of vgs_segment (vgs_resolve_times).
+// wait = true: the caller gets the stage complete (a single stage called through the C-ABI: the getters that may follow copy
+// with blocking calls that do not order against the context's stream); false: inside vgs_run / vgs_segment, whose last stage ends
+// with a read-back behind everything.
 template <typename F>
-static vgs_status timed(vgs_ctx* c, int slot, F&& f) {
+static vgs_status timed(vgs_ctx* c, int slot, F&& f, bool wait = true) {
   RoctxRange range(VGS_STAGE_NAMES[slot]);
   VGS_HIP_TRY(c, hipSetDevice(c->device));
-  VGS_HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  VGS_HIP_TRY(c, hipEventRecord(c->tev[slot][0], c->stream));
+  c->tev_pending[slot] = false;
   vgs_status s = f();
   if (s != VGS_OK) return s;
-  VGS_HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  VGS_HIP_TRY(c, hipEventSynchronize(c->ev[1]));
-  float ms = 0.f;
-  VGS_HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-  c->times[slot] = ms;
+  VGS_HIP_TRY(c, hipEventRecord(c->tev[slot][1], c->stream));
+  c->tev_pending[slot] = true;
+  if (wait) VGS_HIP_TRY(c, hipEventSynchronize(c->tev[slot][1]));
+  return VGS_OK;
+}
+
+static vgs_status vgs_resolve_times(vgs_ctx* c) {
+  for (int slot = 0; slot < VGS_T_COUNT; ++slot) {
+    if (!c->tev_pending[slot]) continue;
+    c->tev_pending[slot] = false;
+    VGS_HIP_TRY(c, hipEventSynchronize(c->tev[slot][1]));
+    float ms = 0.f;
+    VGS_HIP_TRY(c, hipEventElapsedTime(&ms, c->tev[slot][0], c->tev[slot][1]));
+    c->times[slot] = ms;
+  }
   return VGS_OK;
 }
 
@@ -53,6 +69,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
 // The hand-over kernels of the local cut end inside the merge stage's timed region (vgs_localcut_finish measures by how much):
 // that tail belongs to the local cut in the reported stage times.
 static void vgs_charge_localcut_tail(vgs_ctx* c) {
+  (void)vgs_resolve_times(c);   // the merge stage ended with a read-back: every event of the step has completed
   const double t = (double)c->lc_tail.tail_ms;
   if (t > 0.0 && t < c->times[VGS_T_MERGE]) { c->times[VGS_T_LOCALCUT] += t; c->times[VGS_T_MERGE] -= t; }
   c->lc_tail.tail_ms = 0.f;
@@ -158,6 +175,7 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
             hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_d2h, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < 14; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  for (int i = 0; ok && i < VGS_T_COUNT; ++i) ok = hipEventCreate(&c->tev[i][0]) == hipSuccess && hipEventCreate(&c->tev[i][1]) == hipSuccess;
   if (!ok) { g_create_err = "vgs_create: hipStreamCreate/hipEventCreate failed"; vgs_destroy(c); return VGS_E_HIP; }   // frees what exists
   vgs_read_env_knobs(c);
   *out = c;
@@ -191,6 +209,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   if (c->pin) (void)hipHostFree(c->pin);
   for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < VGS_T_COUNT; ++i) for (int k = 0; k < 2; ++k) if (c->tev[i][k]) (void)hipEventDestroy(c->tev[i][k]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -233,7 +252,7 @@ static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes)
   c->stride_f = stride_bytes / 4;
   c->stage = ST_POINTS;
   c->counts[VGS_N_POINTS] = n;
-  for (int i = 0; i < VGS_T_COUNT; ++i) c->times[i] = 0;
+  for (int i = 0; i < VGS_T_COUNT; ++i) { c->times[i] = 0; c->tev_pending[i] = false; }
   // a supervoxel labelling belongs to the cloud it was made for (SS:279-331 rebuilds it per createSupervoxels call)
   c->sv_have_labels = false; c->sv_labels_external = false; c->sv_max_label = 0; c->sv_label_n = -1;
   c->n_own = -1; c->own_first = 0;   // tiles: vgs_set_own_point_range follows the cloud
@@ -302,40 +321,46 @@ vgs_status vgs_set_points_device(vgs_ctx* c, const float* xyz_dev, int64_t n, in
   return VGS_OK;
 }
 
-vgs_status vgs_voxelize(vgs_ctx* c) {
+}  // extern "C"
+
+static vgs_status do_voxelize(vgs_ctx* c, bool wait) {
   if (!c) return VGS_E_ARG;
   if (c->stage < ST_POINTS) { c->err = "vgs_voxelize: no input cloud (setInputCloud/getCloudPointNum first)"; return VGS_E_STATE; }
-  vgs_status s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_voxelize(c); });
+  vgs_status s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_voxelize(c); }, wait);
   if (s == VGS_OK) c->stage = ST_VOXELS;
   return s;
 }
-
-vgs_status vgs_features(vgs_ctx* c) {
+static vgs_status do_features(vgs_ctx* c, bool wait) {
   if (!c) return VGS_E_ARG;
   if (c->stage < ST_VOXELS) { c->err = "vgs_features: voxel table missing (setVoxelCenters/getVoxelNum must precede calcualteVoxelCloudAttributes)"; return VGS_E_STATE; }
-  vgs_status s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); });
+  vgs_status s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); }, wait);
   if (s == VGS_OK) c->stage = ST_FEATURES;
   return s;
 }
-
-vgs_status vgs_adjacency(vgs_ctx* c) {
+static vgs_status do_adjacency(vgs_ctx* c, bool wait) {
   if (!c) return VGS_E_ARG;
   if (c->stage < ST_FEATURES) { c->err = "vgs_adjacency: attributes missing"; return VGS_E_STATE; }
-  vgs_status s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); });
+  vgs_status s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); }, wait);
   if (s == VGS_OK) c->stage = ST_ADJACENCY;
   return s;
 }
+
+extern "C" {
+
+vgs_status vgs_voxelize(vgs_ctx* c) { return do_voxelize(c, true); }
+vgs_status vgs_features(vgs_ctx* c) { return do_features(c, true); }
+vgs_status vgs_adjacency(vgs_ctx* c) { return do_adjacency(c, true); }
 
 vgs_status vgs_segment(vgs_ctx* c) {
   if (!c) return VGS_E_ARG;
   if (c->stage < ST_ADJACENCY) { c->err = "vgs_segment: adjacency missing (findAllVoxelAdjacency first)"; return VGS_E_STATE; }
   if (c->U > 0 && vgs_unused_are_inert(c->P) != c->adj_pruned) {  // sigma/cut changed what the rows must hold
-    vgs_status sa = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); });
+    vgs_status sa = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_adjacency(c); }, false);
     if (sa != VGS_OK) return sa;
   }
-  vgs_status s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); });
+  vgs_status s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); }, false);   // the merge stage's kernels queue up behind it
   if (s != VGS_OK) return s;
-  s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); });
+  s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); });   // ends with a read-back behind everything
   if (s == VGS_OK) { c->stage = ST_SEGMENTED; vgs_charge_localcut_tail(c); }
   return s;
 }
@@ -350,9 +375,9 @@ vgs_status vgs_run(vgs_ctx* c) {
     return svgs_segment(c);
   }
   vgs_status s;
-  if ((s = vgs_voxelize(c)) != VGS_OK) return s;
-  if ((s = vgs_features(c)) != VGS_OK) return s;
-  if ((s = vgs_adjacency(c)) != VGS_OK) return s;
+  if ((s = do_voxelize(c, false)) != VGS_OK) return s;
+  if ((s = do_features(c, false)) != VGS_OK) return s;
+  if ((s = do_adjacency(c, false)) != VGS_OK) return s;
   if ((s = vgs_segment(c)) != VGS_OK) return s;
   c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] +
                           c->times[VGS_T_MERGE];
@@ -399,10 +424,10 @@ vgs_status svgs_segment(vgs_ctx* c) {
   if (c->stage < ST_POINTS || !c->sv_have_labels) { c->err = "svgs_segment: needs the input cloud and supervoxel labels (createSupervoxels)"; return VGS_E_STATE; }
   if (c->sv_label_n != c->N) { c->err = "svgs_segment: the supervoxel labels were made for a different cloud"; return VGS_E_STATE; }
   vgs_status s;
-  if ((s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_svgs_group(c); })) != VGS_OK) return s;       // SS:279-331
-  if ((s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); })) != VGS_OK) return s;         // SS:1238-1303
-  if ((s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_svgs_neighbours(c); })) != VGS_OK) return s;  // SS:1477-1521
-  if ((s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); })) != VGS_OK) return s;          // SS:384-413
+  if ((s = timed(c, VGS_T_VOXELIZE, [&] { return vgs_stage_svgs_group(c); }, false)) != VGS_OK) return s;       // SS:279-331
+  if ((s = timed(c, VGS_T_FEATURES, [&] { return vgs_stage_features(c); }, false)) != VGS_OK) return s;         // SS:1238-1303
+  if ((s = timed(c, VGS_T_ADJACENCY, [&] { return vgs_stage_svgs_neighbours(c); }, false)) != VGS_OK) return s;  // SS:1477-1521
+  if ((s = timed(c, VGS_T_LOCALCUT, [&] { return vgs_stage_localcut(c); }, false)) != VGS_OK) return s;          // SS:384-413
   if ((s = timed(c, VGS_T_MERGE, [&] { return vgs_stage_merge(c); })) != VGS_OK) return s;                // SS:416-420
   c->stage = ST_SEGMENTED; vgs_charge_localcut_tail(c);
   c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] +
@@ -433,6 +458,9 @@ vgs_status vgs_get_counts(vgs_ctx* c, int64_t* counts) {
 
 vgs_status vgs_get_stage_times(vgs_ctx* c, double* ms) {
   if (!c || !ms) return VGS_E_ARG;
+  { vgs_status sr = vgs_resolve_times(c); if (sr != VGS_OK) return sr; }
+  if (c->P.method == 2 && c->stage >= ST_SEGMENTED)
+    c->times[VGS_T_TOTAL] = c->times[VGS_T_VOXELIZE] + c->times[VGS_T_FEATURES] + c->times[VGS_T_ADJACENCY] + c->times[VGS_T_LOCALCUT] + c->times[VGS_T_MERGE];
   for (int i = 0; i < VGS_T_COUNT; ++i) ms[i] = c->times[i];
   return VGS_OK;
 }

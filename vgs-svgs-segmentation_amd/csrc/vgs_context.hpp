@@ -203,6 +203,8 @@ struct vgs_ctx {
   int64_t counts[VGS_N_COUNTS] = {0};
   double times[VGS_T_COUNT] = {0};
   hipEvent_t ev[14] = {nullptr};
+  hipEvent_t tev[VGS_T_COUNT][2] = {{nullptr}};   // stage timers: begin / end of every stage, read lazily (capi.hip: timed)
+  bool tev_pending[VGS_T_COUNT] = {false};
 
   // SVGS
   DevBuf<int32_t> sv_label;     // per point: supervoxel label (0 = unassigned), what getLabeledCloud returns (SS:283)
