@@ -324,10 +324,19 @@ def main():
                 e.point_labels_async(bufs[k & 1])
             e.wait_labels()
 
+        thread_errors = []
+
+        def guarded(bar, e, b, k):
+            bar.wait()
+            try:
+                seq_on(e, b, k)
+            except Exception as ex:  # noqa: BLE001  (reported below: a failed leg must not print a number)
+                thread_errors.append(ex)
+
         def two_contexts(k_steps):
             ka, kb = (k_steps + 1) // 2, k_steps // 2
             bar = threading.Barrier(3)
-            th = [threading.Thread(target=lambda e=e, b=b, k=k: (bar.wait(), seq_on(e, b, k))) for e, b, k in ((eng2, hl, ka), (eng3, hl3, kb))]
+            th = [threading.Thread(target=guarded, args=(bar, e, b, k)) for e, b, k in ((eng2, hl, ka), (eng3, hl3, kb))]
             for t in th:
                 t.start()
             bar.wait()
@@ -341,6 +350,8 @@ def main():
         torch.cuda.synchronize(dev)
         k2 = max(args.steps, 2)
         two_elapsed = two_contexts(k2)
+        if thread_errors:
+            raise thread_errors[0]
         two_same = bool(np.array_equal(hl3[((k2 // 2) - 1) & 1], labels_dev)) if k2 // 2 > 0 else True
         eng2.close(); eng3.close()
         h2h = {"value": n_per * args.steps / h2h_elapsed, "unit": "points/s", "ms_per_step": h2h_elapsed / args.steps * 1e3,

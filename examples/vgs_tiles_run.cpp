@@ -136,7 +136,10 @@ int main(int argc, char** argv) {
     std::vector<std::string> errs((size_t)world);
     std::vector<int64_t> k((size_t)world), np((size_t)world), nr((size_t)world);
     for (int r = 0; r < world; ++r)
-      th.emplace_back([&, r] { rc[(size_t)r] = run_rank(J, VGS_TILES_COMM_LOCAL, group, r, world, &k[(size_t)r], &np[(size_t)r], &nr[(size_t)r], &errs[(size_t)r]); });
+      th.emplace_back([&, r] {
+        rc[(size_t)r] = run_rank(J, VGS_TILES_COMM_LOCAL, group, r, world, &k[(size_t)r], &np[(size_t)r], &nr[(size_t)r], &errs[(size_t)r]);
+        if (rc[(size_t)r]) vgs_tiles_local_group_abort(group);   // the other ranks must not wait for this one
+      });
     for (auto& t : th) t.join();
     vgs_tiles_local_group_destroy(group);
     for (int r = 0; r < world; ++r) if (rc[(size_t)r]) { std::fprintf(stderr, "error: %s\n", errs[(size_t)r].c_str()); return 1; }

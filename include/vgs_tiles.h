@@ -31,6 +31,8 @@ enum { VGS_TILES_COMM_RCCL = 0, VGS_TILES_COMM_LOCAL = 1 };
 
 vgs_status vgs_tiles_local_group_create(int world, void** group);
 void vgs_tiles_local_group_destroy(void* group);
+/* a rank thread that fails calls this so that the others leave their collectives with an error instead of waiting for it */
+void vgs_tiles_local_group_abort(void* group);
 
 /* layout: tiles_x x tiles_y tiles of side `pitch` centred on (center_x, center_y); rank k owns tile (k % tiles_x, k / tiles_x),
  * the outer tiles are open ended.  pitch <= 0: the largest x-extent over the ranks' clouds (agreed with one all-gather at the

@@ -205,6 +205,7 @@ vgs_status vgs_tiles_local_group_create(int world, void** group) {
   return VGS_OK;
 }
 void vgs_tiles_local_group_destroy(void* group) { delete (LocalGroup*)group; }
+void vgs_tiles_local_group_abort(void* group) { if (group) ((LocalGroup*)group)->abort(); }
 
 vgs_status vgs_tiles_create(const vgs_params* p, int comm_kind, void* comm_handle, int rank, int world, int tiles_x, int tiles_y, double pitch,
                             double center_x, double center_y, vgs_tiles** out) {
