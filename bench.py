@@ -91,9 +91,13 @@ def cpu_baseline(xyz_full, params, n_all_full, point_voxel, frac=0.05):
               points_min=params.points_min, adjacency_min=params.adjacency_min, voxels_min=params.voxels_min)
     out = {}
     sum_n2_full = float(n2.sum())
-    for name, math, flavour in (("faithful", 0, 0), ("lean", 0, 1)):
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for name, math, flavour, threads in (("faithful", 0, 0, 1), ("lean", 0, 1, 1), ("lean_all", 0, 1, cores)):
         t = time.perf_counter()
-        res = R.run_vgs(sample, R.vgs_params(math=math, flavour=flavour, **kw))
+        res = R.run_vgs(sample, R.vgs_params(math=math, flavour=flavour, threads=threads, **kw))
         dt = time.perf_counter() - t
         off, _ = res.lists("adjacency")
         n_i = np.diff(off).astype(np.float64) * (res.nodes()["used"] != 0)   # the local graphs are built for the used voxels (VS:384)
@@ -101,7 +105,7 @@ def cpu_baseline(xyz_full, params, n_all_full, point_voxel, frac=0.05):
         scale = sum_n2_full / max(sum_n2, 1.0)
         out[name] = dict(dt=dt, points=int(sample.shape[0]), voxels=int(res.V), used=int((n_i > 0).sum()), sum_n2=sum_n2, scale=scale,
                          scene_seconds=dt * scale, pair_evals=int(res.pair_evals))
-    f, l = out["faithful"], out["lean"]
+    f, l, la = out["faithful"], out["lean"], out["lean_all"]
     n_full = xyz_full.shape[0]
     return {"value": n_full / max(f["scene_seconds"], 1e-9), "unit": "points/s", "cores": 1, "kind": "port",
             "sample": (f"{f['points']} points ({100.0 * f['points'] / n_full:.1f} % of the scene, {f['used']} used voxels): contiguous strip "
@@ -112,7 +116,10 @@ def cpu_baseline(xyz_full, params, n_all_full, point_voxel, frac=0.05):
                        f"x{n_full / f['points']:.2f}) -> {f['scene_seconds']:.0f} s"),
             "sample_value": f["points"] / f["dt"],
             "cpu_lean": {"value": n_full / max(l["scene_seconds"], 1e-9), "unit": "points/s", "cores": 1,
-                         "sample": f"same tile, lean flavour (unique pairs, no per-pair allocations), {l['dt']:.1f} s, same extrapolation"}}
+                         "sample": f"same tile, lean flavour (unique pairs, no per-pair allocations), {l['dt']:.1f} s, same extrapolation"},
+            "cpu_lean_all_cores": {"value": n_full / max(la["scene_seconds"], 1e-9), "unit": "points/s", "cores": cores,
+                                   "sample": f"same tile, lean flavour with the nodes' local cuts on {cores} threads (OpenMP; voxelisation and radius search "
+                                             f"stay on one), {la['dt']:.1f} s, same extrapolation"}}
 
 
 def profiled_traffic(n_points):

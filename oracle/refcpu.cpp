@@ -565,6 +565,10 @@ void segment_graph(const std::vector<Node>& nodes, const std::vector<std::vector
   const float w_dead = distance_weight(d100, P, svgs);
   const bool prune_unused = !(w_dead > 1.0f - P.cut_thred);
   // ---- per-node local graph + cut (VS:376-412) ----
+  // The reference is single threaded (P.threads = 1).  The local cuts are independent per node, so the "CPU-lean, all cores"
+  // context row of BASELINE.md 2 runs this loop with OpenMP over nodes (same results: every node writes its own list).
+  int64_t pair_evals = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : pair_evals) num_threads(P.threads > 1 ? P.threads : 1)
   for (int i = 0; i < V; ++i) {
     if (!nodes[i].used) continue;
     const std::vector<int>& adj = adjacency[i];
@@ -580,7 +584,7 @@ void segment_graph(const std::vector<Node>& nodes, const std::vector<std::vector
           if (a != b) {
             std::vector<float> dist_all = measuring_distance_byvalue(p1, p2, n1, n2, e1, e2, svgs, P.math);
             W[(size_t)a * n + b] = distance_weight_byvalue(dist_all, P, svgs);
-            R.pair_evals++;
+            pair_evals++;
           } else {
             W[(size_t)a * n + b] = 1;
           }
@@ -595,7 +599,7 @@ void segment_graph(const std::vector<Node>& nodes, const std::vector<std::vector
         for (int b = a + 1; b < n; ++b) {
           if (prune_unused && !nodes[adj[b]].used) continue;
           float w = pair_weight(nodes[adj[a]], nodes[adj[b]], P, svgs);
-          R.pair_evals++;
+          pair_evals++;
           if (w != w) continue;  // NaN never merges (Q3)
           edges.push_back({w, a, b});
         }
@@ -605,6 +609,7 @@ void segment_graph(const std::vector<Node>& nodes, const std::vector<std::vector
     std::vector<int>& out = R.connect_cut[i];
     for (int v : local) out.push_back(adj[v]);
   }
+  R.pair_evals = pair_evals;
   // ---- crossValidation (VS:2111-2179): sequential, in place ----
   R.connect_cross = R.connect_cut;
   {

@@ -41,6 +41,7 @@ struct Params {
   int math = 0;      // 0 RefMath, 1 DevMath
   int flavour = 1;   // 0 faithful, 1 lean
   int q7_count_as_index = 1;  // closestCheck scans the leading neighbour count as a voxel id (VS:2243)
+  int threads = 1;   // local cuts of the nodes in parallel (OpenMP); 1 = the reference's single thread
 };
 
 struct Node {  // one graph node's attributes

@@ -13,7 +13,7 @@ struct RefParamsC {
   float voxel_size, graph_size, sig_p, sig_n, sig_o, sig_e, sig_c, sig_w, cut_thred;
   int points_min, adjacency_min, voxels_min;
   float seed_size, color_impt, spatial_impt, normal_impt;
-  int math, flavour, q7_count_as_index;
+  int math, flavour, q7_count_as_index, threads;
 };
 
 static Params to_params(const RefParamsC* c) {
@@ -24,6 +24,7 @@ static Params to_params(const RefParamsC* c) {
   P.points_min = c->points_min; P.adjacency_min = c->adjacency_min; P.voxels_min = c->voxels_min;
   P.seed_size = c->seed_size; P.color_impt = c->color_impt; P.spatial_impt = c->spatial_impt; P.normal_impt = c->normal_impt;
   P.math = c->math; P.flavour = c->flavour; P.q7_count_as_index = c->q7_count_as_index;
+  P.threads = c->threads > 1 ? c->threads : 1;
   return P;
 }
 

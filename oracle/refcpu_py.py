@@ -21,7 +21,7 @@ class RefParams(C.Structure):
         ("sig_c", C.c_float), ("sig_w", C.c_float), ("cut_thred", C.c_float),
         ("points_min", C.c_int), ("adjacency_min", C.c_int), ("voxels_min", C.c_int),
         ("seed_size", C.c_float), ("color_impt", C.c_float), ("spatial_impt", C.c_float), ("normal_impt", C.c_float),
-        ("math", C.c_int), ("flavour", C.c_int), ("q7_count_as_index", C.c_int),
+        ("math", C.c_int), ("flavour", C.c_int), ("q7_count_as_index", C.c_int), ("threads", C.c_int),
     ]
 
 
@@ -29,7 +29,7 @@ def vgs_params(**kw):
     """Task_File_VGS.txt defaults (TV:28-50); math=1 (DevMath), flavour=1 (lean) unless overridden."""
     d = dict(voxel_size=0.15, graph_size=0.5, sig_p=0.2, sig_n=0.2, sig_o=0.2, sig_e=0.2, sig_c=0.2, sig_w=2.0,
              cut_thred=0.3, points_min=10, adjacency_min=3, voxels_min=3, seed_size=0.25, color_impt=0.0,
-             spatial_impt=0.25, normal_impt=0.75, math=1, flavour=1, q7_count_as_index=1)
+             spatial_impt=0.25, normal_impt=0.75, math=1, flavour=1, q7_count_as_index=1, threads=1)
     d.update(kw)
     return RefParams(**d)
 

@@ -30,6 +30,7 @@ def test_single_gpu_line(gpu):
     assert h["labels_equal_device_resident_run"] is True and h["value"] > 0 and h["latency_ms_median"] > 0
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["cpu_lean"]["value"] >= cb["value"]
+    assert cb["cpu_lean_all_cores"]["cores"] >= 1 and cb["cpu_lean_all_cores"]["value"] > 0
     assert out["stage_ms"]["labels"] > 0.0
 
 
