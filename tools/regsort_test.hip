@@ -1,0 +1,120 @@
+// tools/regsort_test.hip -- csrc/regsort.hpp against the LDS bitonic network of the local cut, outside the kernel: same lists,
+// same LDS footprint and register budget as the bulk class (one wavefront per workgroup, 6368 bytes of LDS, 6 wavefronts per
+// SIMD), results compared key for key, both timed.   build: hipcc --offload-arch=gfx950 -O3 -o regsort_test regsort_test.hip
+// usage: regsort_test [lists] [mean length]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../vgs-svgs-segmentation_amd/csrc/regsort.hpp"
+
+constexpr int LCAP = 448;
+constexpr int LDS_BYTES = 6368;
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void k_sort(const uint64_t* keys, const int* offs, int n_lists, uint64_t* out) {
+  __shared__ uint64_t lds[LDS_BYTES / 8];
+  uint64_t* lk = lds;
+  const int lane = (int)threadIdx.x;
+  for (int li = (int)blockIdx.x; li < n_lists; li += (int)gridDim.x) {
+    const int o = offs[li], cnt = offs[li + 1] - o;
+    for (int e = lane; e < cnt; e += 64) lk[e] = keys[o + e];
+    wave_sync();
+    if constexpr (MODE == 0) {
+      int np = 64;
+      while (np < cnt) np <<= 1;
+      auto cmpx = [&](int lo, int hi) {
+        if (hi >= cnt) return;
+        const uint64_t x = lk[lo], y = lk[hi];
+        if (x < y) { lk[lo] = y; lk[hi] = x; }
+      };
+      for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {
+        for (int t = lane; t < (np >> 1); t += 64) {
+          const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
+          cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
+        }
+        wave_sync();
+        for (int sl = sbit - 2; sl >= 0; --sl) {
+          const int strd = 1 << sl;
+          for (int t = lane; t < (np >> 1); t += 64) {
+            const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
+            cmpx(lo, lo + strd);
+          }
+          wave_sync();
+        }
+      }
+    } else if constexpr (MODE == 3) {
+      regsort::sort_desc_512(lk, cnt);
+    } else {
+      if (cnt <= 64) regsort::sort_desc<1>(lk, cnt, lane);
+      else if (cnt <= 128) regsort::sort_desc<2>(lk, cnt, lane);
+      else if (cnt <= 256) regsort::sort_desc<4>(lk, cnt, lane);
+      else if constexpr (MODE == 1) regsort::sort_desc<8>(lk, cnt, lane);
+      else regsort::sort_desc_two_halves<4>(lk, cnt, lane);
+      wave_sync();
+    }
+    for (int e = lane; e < cnt; e += 64) out[o + e] = lk[e];
+    wave_sync();
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  const int n_lists = argc > 1 ? std::atoi(argv[1]) : 400000;
+  const int mean = argc > 2 ? std::atoi(argv[2]) : 200;
+  std::mt19937_64 rng(7);
+  std::vector<int> offs(n_lists + 1, 0);
+  for (int i = 0; i < n_lists; ++i) {
+    int c = (int)(rng() % (unsigned)(2 * mean + 1));
+    if (i < 16) c = i == 0 ? 0 : (i == 1 ? 1 : (i == 2 ? 64 : (i == 3 ? 65 : (i == 4 ? 128 : (i == 5 ? 129 : (i == 6 ? 256 : (i == 7 ? 257 : (i == 8 ? 448 : 447))))))));
+    c = std::min(c, LCAP);
+    offs[i + 1] = offs[i] + c;
+  }
+  std::vector<uint64_t> keys((size_t)offs[n_lists]);
+  for (size_t i = 0; i < keys.size(); ++i) {
+    const uint64_t r = rng();
+    // weight bits of a float in (0.3, 1], a 16-bit pair id; 3 % dropped entries (0); a few equal weights
+    const float w = 0.3f + 0.7f * (float)((r >> 11) % 1000003) / 1000003.0f;
+    uint32_t wb; memcpy(&wb, &w, 4);
+    if ((r & 63) == 1) wb = 0x3f000000u;
+    keys[i] = (r & 31) == 0 ? 0ull : (((uint64_t)wb << 32) | (uint32_t)(0xffffu - ((r >> 40) & 0x3fffu)));
+  }
+  uint64_t *d_keys, *d_out[3]; int* d_offs;
+  CK(hipMalloc(&d_keys, keys.size() * 8)); CK(hipMalloc(&d_out[0], keys.size() * 8)); CK(hipMalloc(&d_out[1], keys.size() * 8)); CK(hipMalloc(&d_out[2], keys.size() * 8));
+  CK(hipMalloc(&d_offs, offs.size() * 4));
+  CK(hipMemcpy(d_keys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_offs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int grid = 256 * 24 * 4;
+  float ms[3] = {0, 0, 0};
+  for (int rep = 0; rep < 4; ++rep)
+    for (int mode = 0; mode < 3; ++mode) {
+      CK(hipEventRecord(e0));
+      if (mode == 0) hipLaunchKernelGGL(k_sort<0>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[0]);
+      else if (mode == 1) hipLaunchKernelGGL(k_sort<1>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[1]);
+      else if (argc > 3) hipLaunchKernelGGL(k_sort<3>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[2]);
+      else hipLaunchKernelGGL(k_sort<2>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[2]);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float t; CK(hipEventElapsedTime(&t, e0, e1));
+      if (rep > 0) ms[mode] += t / 3.0f;
+    }
+  std::vector<uint64_t> a(keys.size()), b(keys.size()), c(keys.size());
+  CK(hipMemcpy(a.data(), d_out[0], keys.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), d_out[1], keys.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(c.data(), d_out[2], keys.size() * 8, hipMemcpyDeviceToHost));
+  size_t bad_ref = 0, bad = 0, bad2 = 0;
+  for (int i = 0; i < n_lists; ++i) {
+    std::vector<uint64_t> ref(keys.begin() + offs[i], keys.begin() + offs[i + 1]);
+    std::sort(ref.begin(), ref.end(), [](uint64_t x, uint64_t y) { return x > y; });
+    for (int e = 0; e < (int)ref.size(); ++e) { bad_ref += a[offs[i] + e] != ref[e]; bad += b[offs[i] + e] != ref[e]; bad2 += c[offs[i] + e] != ref[e]; }
+  }
+  std::printf("lists %d  keys %zu  lds network %.3f ms (wrong keys %zu)  register network %.3f ms (wrong keys %zu)  with two halves above 256 keys %.3f ms (wrong keys %zu)\n", n_lists, keys.size(), ms[0], bad_ref, ms[1], bad, ms[2], bad2);
+  return (bad_ref || bad || bad2) ? 1 : 0;
+}

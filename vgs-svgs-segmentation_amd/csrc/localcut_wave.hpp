@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "nearlist.hpp"
+#include "regsort.hpp"
 
 // VGS_PROF=1 builds accumulate per-phase shader cycles (s_memtime) into counters[16..31] (diagnostics only)
 #ifdef VGS_PROF
@@ -55,6 +56,10 @@
 // and the rank loops are chains of dependent LDS round trips, and this kernel is bound by exactly those at 24 wavefronts per CU)
 #ifndef LW_BUCKET_SORT
 #define LW_BUCKET_SORT 0
+#endif
+// phase A of the one-wavefront classes sorts its edge list in registers (regsort.hpp) instead of through LDS
+#ifndef LW_REG_SORT
+#define LW_REG_SORT 4
 #endif
 // groups of four vertices whose near-pair list entries are requested together (first shells)
 #ifndef LW_NEAR_GROUPS
@@ -936,18 +941,30 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int dropped = near_round ? 0 : run_eval(n_list, count);   // the lists hold weights above thr0 only
       n_evals += (unsigned int)count;
       auto sort_len = [](int c) { int np = 64; while (np < c) np <<= 1; return np; };
+      int behind = 0;   // dropped entries the sort leaves behind the real ones
       if (dropped > 0 && sort_len(n_list + count - dropped) < sort_len(n_list + count)) {
         // close the gaps before sorting when that halves the sort network (its length is the next power of two):
         // ascending and in place, a write never passes the read position
         wave_sync();
         const int kept = close_gaps(n_list, count);
         n_list = kept;
-        sort_list(n_list);
       } else {
         n_list += count;
-        sort_list(n_list);
-        n_list -= dropped;  // dropped entries sort to the end
+        behind = dropped;
       }
+      if constexpr (NW == 1 && LW_REG_SORT != 0) {
+        // the one call of the register network (regsort.hpp; its sizes are 2000 instructions: phase B keeps the LDS network)
+        wave_sync();
+        if (n_list <= 64) regsort::sort_desc<1>(lk, n_list, lane);
+        else if (n_list <= 128) regsort::sort_desc<2>(lk, n_list, lane);
+        else if (n_list <= 256) regsort::sort_desc<4>(lk, n_list, lane);
+        else if constexpr (LW_REG_SORT >= 8) regsort::sort_desc<8>(lk, n_list, lane);
+        else regsort::sort_desc_two_halves<4>(lk, n_list, lane);
+        wave_sync();
+      } else {
+        sort_list(n_list);
+      }
+      n_list -= behind;
       LW_ACC(2);  // evaluate
       if (P.dbg_stop == 2) return;
       // ---- 3. (sorted above) 4. merge down to the level ----

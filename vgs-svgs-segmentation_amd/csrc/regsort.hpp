@@ -1,0 +1,176 @@
+// regsort.hpp -- descending sort of up to 64*K 64-bit keys of ONE wavefront with the keys in registers: a bitonic network whose
+// comparators never touch LDS.  Key e lives in register e % K of lane e / K, so the strides used most (1 .. K/2: every merge
+// ends with them) are compare-exchanges between registers of one lane, lane strides 1, 2, 4, 8 are DPP moves inside a row of
+// 16 lanes (quad_perm, two bank-masked row shifts for 4, row_ror:8), and the two widest -- used once or twice per sort -- are
+// gfx950's v_permlane16_swap / v_permlane32_swap.  The LDS network it replaces in the one-wavefront classes of the local cut
+// reads and writes every key once per stage (36 stages for 256 keys: a third of the kernel's LDS instructions, all 8 bytes wide);
+// this one loads the list once and stores it once.  Slots at and behind cnt are the key 0, below every real key (real keys
+// carry weight bits > 0 in the upper word; dropped entries ARE 0 and end up behind the real ones, as in the LDS network).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef REGSORT_OPAQUE_LANE
+#define REGSORT_OPAQUE_LANE 1
+#endif
+
+namespace regsort {
+
+// lanes whose bit `b` is clear
+__host__ __device__ constexpr uint64_t lanes_bit_clear(int b) {
+  uint64_t m = 0;
+  for (int l = 0; l < 64; ++l) if (((l >> b) & 1) == 0) m |= 1ull << l;
+  return m;
+}
+
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, BANK, false);
+}
+template <int CTRL>   // every lane is written: no previous value to keep (saves the copy update_dpp needs for it)
+__device__ __forceinline__ uint32_t dpp_all(uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xf, 0xf, false);
+}
+
+// value of the key held by lane ^ (1 << J), J = 0..3
+template <int J>
+__device__ __forceinline__ uint64_t other_lane(uint64_t x) {
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32), olo, ohi;
+  if constexpr (J == 0) { olo = dpp_all<0xB1>(lo); ohi = dpp_all<0xB1>(hi); }          // quad_perm [1,0,3,2]
+  else if constexpr (J == 1) { olo = dpp_all<0x4E>(lo); ohi = dpp_all<0x4E>(hi); }     // quad_perm [2,3,0,1]
+  else if constexpr (J == 2) {                                                         // lanes 0-3, 8-11 of a row read l + 4, the others l - 4
+    olo = dpp_all<0x104>(lo); olo = dpp<0x114, 0xa>(olo, lo);
+    ohi = dpp_all<0x104>(hi); ohi = dpp<0x114, 0xa>(ohi, hi);
+  } else { olo = dpp_all<0x128>(lo); ohi = dpp_all<0x128>(hi); }                       // row_ror:8
+  return ((uint64_t)ohi << 32) | olo;
+}
+
+// One stage on lane stride 1 << J: `keepmax` = this lane keeps the larger key of the pair.
+template <int K, int J>
+__device__ __forceinline__ void lane_stage(uint64_t (&k)[K], bool keepmax) {
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    if constexpr (J <= 3) {
+      const uint64_t o = other_lane<J>(k[r]);
+      const bool take = (o > k[r]) == keepmax;
+      k[r] = take ? o : k[r];
+    } else {
+      // the swap leaves the key of the lower lane of the pair in a, of the upper lane in b -- in both lanes
+      const uint32_t lo = (uint32_t)k[r], hi = (uint32_t)(k[r] >> 32);
+      uint32_t alo, blo, ahi, bhi;
+      if constexpr (J == 4) {
+        auto s = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); alo = s[0]; blo = s[1];
+        auto t = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); ahi = t[0]; bhi = t[1];
+      } else {
+        auto s = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); alo = s[0]; blo = s[1];
+        auto t = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); ahi = t[0]; bhi = t[1];
+      }
+      const uint64_t a = ((uint64_t)ahi << 32) | alo, b = ((uint64_t)bhi << 32) | blo;
+      const bool take_b = (b > a) == keepmax;
+      k[r] = take_b ? b : a;
+    }
+  }
+}
+
+// One stage of the bitonic merge of blocks of 2^S keys, stride 2^J.  Blocks whose index bit S is clear sort descending, the
+// others ascending; the last merge (S == LOGN) is descending everywhere.
+template <int K, int LOGK, int LOGN, int S, int J>
+__device__ __forceinline__ void stage(uint64_t (&k)[K], int lane) {
+  if constexpr (J >= LOGK) {
+    // lane stride 2^(J - LOGK); descending block <=> bit (S - LOGK) of the lane clear
+    constexpr int JB = J - LOGK;
+    const bool lower = ((lane >> JB) & 1) == 0;
+    bool desc = true;
+    if constexpr (S != LOGN) desc = ((lane >> (S - LOGK)) & 1) == 0;
+    lane_stage<K, JB>(k, lower == desc);
+  } else {
+    // register stride 2^J: pairs (r, r + 2^J) with bit J of r clear
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      if ((r >> J) & 1) continue;
+      const int r2 = r + (1 << J);
+      bool desc = true;
+      if constexpr (S == LOGN) desc = true;
+      else if constexpr (S < LOGK) desc = ((r >> S) & 1) == 0;   // known at compile time once unrolled
+      else desc = ((lane >> (S - LOGK)) & 1) == 0;
+      const bool swap = (k[r2] > k[r]) == desc;
+      const uint64_t x = k[r], y = k[r2];
+      k[r] = swap ? y : x;
+      k[r2] = swap ? x : y;
+    }
+  }
+}
+
+template <int K, int LOGK, int LOGN, int S, int J>
+struct Strides {
+  static __device__ __forceinline__ void run(uint64_t (&k)[K], int lane) {
+    stage<K, LOGK, LOGN, S, J>(k, lane);
+    Strides<K, LOGK, LOGN, S, J - 1>::run(k, lane);
+  }
+};
+template <int K, int LOGK, int LOGN, int S>
+struct Strides<K, LOGK, LOGN, S, -1> {
+  static __device__ __forceinline__ void run(uint64_t (&)[K], int) {}
+};
+
+template <int K, int LOGK, int LOGN, int S>
+struct Net {
+  static __device__ __forceinline__ void run(uint64_t (&k)[K], int lane) {
+    Net<K, LOGK, LOGN, S - 1>::run(k, lane);
+    Strides<K, LOGK, LOGN, S, S - 1>::run(k, lane);
+  }
+};
+template <int K, int LOGK, int LOGN>
+struct Net<K, LOGK, LOGN, 0> {
+  static __device__ __forceinline__ void run(uint64_t (&)[K], int) {}
+};
+
+constexpr int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+__device__ __forceinline__ void lds_fence() {   // orders this wavefront's LDS accesses (one wavefront owns the list)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Sorts lk[0, cnt) (LDS, cnt <= 64 * K) descending.  The caller orders the list's earlier writes before the call and its later
+// reads after it (lds_fence).  FINAL_MERGE_ONLY: lk[0, cnt) is already bitonic (the last merge of the network alone).
+template <int K, bool FINAL_MERGE_ONLY = false>
+__device__ __forceinline__ void sort_desc(uint64_t* lk, int cnt, int lane) {
+  constexpr int LOGK = ilog2(K), LOGN = LOGK + 6;
+  uint64_t k[K];
+#if REGSORT_OPAQUE_LANE
+  // the stages' lane predicates depend on the lane alone: hoisted out of the caller's loops they would sit in forty SGPR pairs
+  // for the whole kernel; behind this they are recomputed where they are used (two or three instructions per stage)
+  asm volatile("" : "+v"(lane));
+#endif
+#pragma unroll
+  for (int r = 0; r < K; ++r) { const int e = lane * K + r; k[r] = e < cnt ? lk[e] : 0ull; }
+  if constexpr (FINAL_MERGE_ONLY) Strides<K, LOGK, LOGN, LOGN, LOGN - 1>::run(k, lane);
+  else Net<K, LOGK, LOGN, LOGN>::run(k, lane);
+#pragma unroll
+  for (int r = 0; r < K; ++r) { const int e = lane * K + r; if (e < cnt) lk[e] = k[r]; }
+}
+
+// 64*K < cnt <= 128*K keys with the register budget of K per lane: both halves sorted descending one after the other, the first
+// step of their merge as a mirror step through LDS (slot i against slot 128*K - 1 - i; slots at and behind cnt are keys below
+// every real one and never move, so the list need not reach 128*K slots), then the rest of the merge on each half in registers.
+template <int K>
+__device__ __forceinline__ void sort_desc_two_halves(uint64_t* lk, int cnt, int lane) {
+  constexpr int H = 64 * K;
+#pragma nounroll
+  for (int h = 0; h < 2; ++h) sort_desc<K>(lk + H * h, h ? cnt - H : H, lane);
+  lds_fence();
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const int i = lane + 64 * q, j = 2 * H - 1 - i;
+    if (j < cnt) {
+      const uint64_t x = lk[i], y = lk[j];
+      if (x < y) { lk[i] = y; lk[j] = x; }
+    }
+  }
+  lds_fence();
+#pragma nounroll
+  for (int h = 0; h < 2; ++h) sort_desc<K, true>(lk + H * h, h ? cnt - H : H, lane);
+}
+
+}  // namespace regsort
