@@ -51,17 +51,18 @@
 #ifndef LW_TRIP
 #define LW_TRIP 3
 #endif
-// bucket sort of the bulk class's edge lists (round-3 experiment, off: exact -- the parity tests pass with it -- but slower
-// than the bitonic network it replaces, 4.7 against 4.2 ms in the same build: fewer instructions, yet its LDS atomics, the scan
-// and the rank loops are chains of dependent LDS round trips, and this kernel is bound by exactly those at 24 wavefronts per CU)
-#ifndef LW_BUCKET_SORT
-#define LW_BUCKET_SORT 0
-#endif
+// (A bucket sort of the bulk class's edge lists by weight -- LDS histogram, scan, rank inside the bucket; a third of the LDS
+// network's instructions -- was measured in round 3: exact, but slower, 4.7 against 4.2 ms in the same build: its atomics, the scan
+// and the rank loops are chains of dependent LDS round trips.  What did pay is regsort.hpp: no LDS round trips at all.)
 // phase A of the one-wavefront classes sorts its edge list in registers (regsort.hpp) instead of through LDS
 #ifndef LW_REG_SORT
 #define LW_REG_SORT 4
 #endif
-// groups of four vertices whose near-pair list entries are requested together (first shells)
+// lanes per vertex when the first shell is read from the near-pair lists (8 or 16; see near_enum)
+#ifndef LW_NEAR_LPV1
+#define LW_NEAR_LPV1 9
+#endif
+// groups of vertices whose near-pair list entries are requested together (first shells)
 #ifndef LW_NEAR_GROUPS
 #define LW_NEAR_GROUPS 2
 #endif
@@ -315,103 +316,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
   // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
   // real one that never move, so cnt need not be a power of two and nothing is padded.
-  // One-wavefront classes, lists of more than 128 keys: a bucket sort.  The bitonic network costs 45 passes over 512 keys
-  // (800 VALU + 760 SALU instructions per voxel on URB10M, a fifth of the kernel); the weights of a shell lie in a narrow band,
-  // so the keys go into 128 buckets by weight (monotone float map of [wmin, wmax], descending), an LDS histogram gives every
-  // bucket its slice of the list, and a key's place inside its bucket (a handful of keys) is the number of larger keys there.
-  // Keys are unique (pair ids differ); dropped entries (0) keep their arrival order in the last bucket.  Returns false when the
-  // keys do not spread (one weight, or a bucket with more than 48 keys): the network below sorts those lists.
-  constexpr int BS_K = (LCAP + 63) / 64;
-  auto bucket_sort = [&](int cnt) -> bool {
-    uint64_t kk[BS_K];
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    wave_sync();
-#pragma unroll
-    for (int j = 0; j < BS_K; ++j) {
-      const int e = lane + 64 * j;
-      kk[j] = e < cnt ? lk[e] : ~0ull;    // ~0: no key
-      const uint32_t wb = (uint32_t)(kk[j] >> 32);
-      if (e < cnt && kk[j] != 0ull) { lo = wb < lo ? wb : lo; hi = wb > hi ? wb : hi; }
-    }
-    // claim[] is free between merges (all ones): words 0..63 hold two 16-bit bucket counters each, 64 and 65 the band
-    if (lane < 2) claim[64 + lane] = lane == 0 ? 0xffffffffu : 0u;
-    claim[lane] = 0u;
-    wave_sync();
-    if (lo != 0xffffffffu) { atomicMin(&claim[64], lo); atomicMax(&claim[65], hi); }
-    wave_sync();
-    const float wmin = vm_from_bits(claim[64]), wmax = vm_from_bits(claim[65]);
-    const bool spread = wmax > wmin;   // weights are non-negative floats: bit order = value order
-    const float scale = 126.99f / (wmax - wmin);
-    uint32_t bk[BS_K];                    // bucket | arrival index << 8
-#pragma unroll
-    for (int j = 0; j < BS_K; ++j) {
-      bk[j] = 0;
-      if (kk[j] != ~0ull && spread) {
-        int b = 127;                      // dropped entries: behind every real key
-        if (kk[j] != 0ull) { b = 126 - (int)((vm_from_bits((uint32_t)(kk[j] >> 32)) - wmin) * scale); b = b < 0 ? 0 : (b > 126 ? 126 : b); }
-        const uint32_t old = atomicAdd(&claim[b >> 1], 1u << (16 * (b & 1)));
-        bk[j] = (uint32_t)b | (((old >> (16 * (b & 1))) & 0xffffu) << 8);
-      }
-    }
-    wave_sync();
-    const uint32_t cw = claim[lane];
-    const uint32_t c0 = cw & 0xffffu, c1 = cw >> 16;
-    const bool crowded = (c0 > 48u && lane != 63) || (c1 > 48u && lane != 63) || (lane == 63 && c0 > 48u);   // bucket 127 holds the dropped entries: any number
-    if (!spread || __ballot(crowded) != 0ull) {
-      wave_sync();
-      claim[lane] = 0xffffffffu; if (lane < 2) claim[64 + lane] = 0xffffffffu;
-      wave_sync();
-      return false;
-    }
-    uint32_t inc = c0 + c1;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += v; }
-    const uint32_t s0 = inc - (c0 + c1), s1 = s0 + c0;
-    wave_sync();
-    claim[lane] = s0 | (s1 << 16);        // bucket starts; the end of bucket b is the start of b + 1 (cnt behind the last)
-    wave_sync();
-    // place inside the bucket: bk[j] becomes start | length << 9 | rank << 15 (starts < 512, buckets hold at most 48 keys)
-    uint32_t maxlen = 0;
-#pragma unroll
-    for (int j = 0; j < BS_K; ++j)
-      if (kk[j] != ~0ull) {
-        const int b = (int)(bk[j] & 255u);
-        const uint32_t st = (claim[b >> 1] >> (16 * (b & 1))) & 0xffffu;
-        const uint32_t en = b == 127 ? (uint32_t)cnt : ((claim[(b + 1) >> 1] >> (16 * ((b + 1) & 1))) & 0xffffu);
-        const uint32_t arrival = bk[j] >> 8;
-        lk[st + arrival] = kk[j];         // grouped by bucket, arrival order inside
-        // dropped entries (bucket 127) stay where they arrived: length 0, rank = arrival does not fit 6 bits, so they keep a flag
-        if (b == 127) bk[j] = (st + arrival) | (1u << 31);
-        else { bk[j] = st | ((en - st) << 9); maxlen = (en - st) > maxlen ? (en - st) : maxlen; }
-      }
-    wave_sync();
-    // the rank loops of a lane's keys run side by side: one trip reads one bucket mate for every key (independent LDS reads)
-    for (uint32_t q = 0; __ballot(q < maxlen) != 0ull; ++q) {
-#pragma unroll
-      for (int j0 = 0; j0 < BS_K; j0 += 4) {
-        uint64_t mate[4];
-#pragma unroll
-        for (int j = j0; j < j0 + 4 && j < BS_K; ++j) {   // unconditional reads (clamped address): issued together
-          const uint32_t a = (bk[j] & 511u) + q;
-          mate[j - j0] = lk[a < (uint32_t)LCAP ? a : (uint32_t)LCAP - 1u];
-        }
-#pragma unroll
-        for (int j = j0; j < j0 + 4 && j < BS_K; ++j) {
-          const uint32_t len = (bk[j] >> 9) & 63u;
-          const bool counts = kk[j] != ~0ull && !(bk[j] >> 31) && q < len && mate[j - j0] > kk[j];
-          bk[j] += counts ? (1u << 15) : 0u;
-        }
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int j = 0; j < BS_K; ++j)
-      if (kk[j] != ~0ull) lk[(bk[j] >> 31) ? (bk[j] & 0x7fffffffu) : ((bk[j] & 511u) + (bk[j] >> 15))] = kk[j];
-    claim[lane] = 0xffffffffu; if (lane < 2) claim[64 + lane] = 0xffffffffu;
-    wave_sync();
-    return true;
-  };
   auto sort_section = [&](int cnt) {   // all wavefronts of the workgroup
-    if constexpr (LW_BUCKET_SORT != 0 && NW == 1 && MAXM == 96) { if (cnt > 128 && bucket_sort(cnt)) return; }   // the bulk class (class B: the extra registers spill)
     int np = 64;
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {
@@ -562,7 +467,14 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // weight has the list's owner as first argument, which is the orientation the cut wants.
   // Four vertices per step, sixteen lanes each (lists are sorted by distance: on a surface the shell ends before entry 16);
   // a vertex whose sixteenth entry is still inside the shell gets a step of its own for the rest.
-  auto near_enum = [&](int n_list, float cut_lo, float cut_hi, bool merged, float act_level) -> int {
+  // LPV lanes per vertex: 8 for the first shell -- 98 % of the vertices of URB10M have at most eight entries inside it, so a
+  // trip of 64 lanes takes eight vertices instead of four and the enumeration half the trips -- 16 for the later, wider ones.
+  // Later shells (LATER): only the vertices that can still merge -- alist[0, n_act), kept by the freeze step -- own entries
+  // that count.
+  auto near_enum = [&](auto lpv_c, auto later_c, int n_act, int n_list, float cut_lo, float cut_hi, bool merged, float act_level) -> int {
+    constexpr int LPV = decltype(lpv_c)::value, ROWS = 64 / LPV;
+    constexpr bool LATER = decltype(later_c)::value;
+    const int nv = LATER ? n_act : m;
     int count = 0;
     auto vertex_id = [&](int va) -> uint32_t {   // global id of vertex va from the registers of lane va & 63
       const uint32_t lo = (uint32_t)__shfl((int)tid_reg0, va & 63, 64), hi = (uint32_t)__shfl((int)tid_reg1, va & 63, 64);
@@ -594,35 +506,40 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       count += __popcll(mk);
       return inside;
     };
-    const int j = lane & 15;
+    const int row = lane / LPV, j = lane - row * LPV;   // LPV need not divide 64: the last lanes then idle
     bool none = false;   // a vertex whose voxel has no list: NaN distance in entry 0 (nearlist.hip)
-    // LW_NEAR_GROUPS groups of four vertices per trip: their list entries are requested together (the ids come out of
+    // LW_NEAR_GROUPS groups of ROWS vertices per trip: their list entries are requested together (the ids come out of
     // registers, so the only memory round trip of a trip is the entries themselves)
-    for (int base = 0; base < m; base += 4 * LW_NEAR_GROUPS) {
+    for (int base = 0; base < nv; base += ROWS * LW_NEAR_GROUPS) {
       float2 e[LW_NEAR_GROUPS];
       uint32_t sl[LW_NEAR_GROUPS];
+      int vas[LW_NEAR_GROUPS];
       bool act[LW_NEAR_GROUPS], in[LW_NEAR_GROUPS];
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
-        const int va = base + 4 * g + (lane >> 4);
-        act[g] = va < m;
-        const size_t o = (size_t)vertex_id(va) * NL_S + (size_t)j;
+        const int iv = base + ROWS * g + row;
+        act[g] = iv < nv && row < ROWS;
+        vas[g] = LATER ? (act[g] ? (int)alist[iv] : 0) : iv;
+        const size_t o = (size_t)vertex_id(vas[g]) * NL_S + (size_t)j;
         e[g] = make_float2(0.f, 0.f); sl[g] = 0;
         if (act[g]) { e[g] = P.near.dw[o]; sl[g] = P.near.slot[o]; }
         none = none || (e[g].x != e[g].x);
       }
 #pragma unroll
-      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(base + 4 * g + (lane >> 4), act[g], e[g], sl[g]);
-      // the shell may go on behind entry 15 of a vertex: the rest of that list gets a step of its own
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(vas[g], act[g], e[g], sl[g]);
+      // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken two vertices per step, 32 lanes each
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
-        unsigned long long more = __ballot(in[g] && j == 15);
+        unsigned long long more = __ballot(in[g] && j == LPV - 1);
         while (more) {
           const int l0 = __ffsll((long long)more) - 1;
           more &= more - 1ull;
-          const int va = base + (l0 >> 4) + 4 * g;
-          const bool a2 = lane < NL_S - 16;
-          const size_t o = (size_t)vertex_id(va) * NL_S + 16 + (size_t)(lane & 15);
+          int l1 = -1;
+          if (more) { l1 = __ffsll((long long)more) - 1; more &= more - 1ull; }
+          const int va0 = __builtin_amdgcn_readlane(vas[g], l0), va1 = l1 >= 0 ? __builtin_amdgcn_readlane(vas[g], l1) : 0;
+          const int va = lane < 32 ? va0 : va1;
+          const bool a2 = (lane & 31) < NL_S - LPV && (lane < 32 || l1 >= 0);
+          const size_t o = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & 31);
           float2 e2 = make_float2(0.f, 0.f);
           uint32_t s2 = 0;
           if (a2) { e2 = P.near.dw[o]; s2 = P.near.slot[o]; }
@@ -798,12 +715,24 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       }
       const int nproc = __popcll(__ballot(alive));  // sorted: the processable edges are a prefix of the step
       while (true) {
+#ifdef VGS_PROF
+        int walk = 0;
+#endif
         if (alive) {
           int r;
+#ifdef VGS_PROF
+          while ((r = rep[sa]) != sa) { sa = r; ++walk; }
+          while ((r = rep[sb]) != sb) { sb = r; ++walk; }
+#else
           while ((r = rep[sa]) != sa) sa = r;
           while ((r = rep[sb]) != sb) sb = r;
+#endif
           alive = sa != sb;  // inside one segment: skipped now and for ever
         }
+#ifdef VGS_PROF
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(walk, o, 64); walk = v > walk ? v : walk; }
+        LW_CNT(14, walk); LW_CNT(7, 1);
+#endif
         if (__ballot(alive) == 0ull) break;
         if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
         wave_sync();
@@ -831,6 +760,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         alive = alive && !decided;
         wave_sync();
       }
+      LW_CNT(15, 1);
       if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
       if (merges >= m - 1) break;  // one segment left
     }
@@ -914,7 +844,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       } else if constexpr (NEAR) {
         count = 0;
         if (near_round) {
-          count = near_enum(n_list, cut_lo, cut_hi, merges > 0, act_level);
+          count = rounds == 1 ? near_enum(std::integral_constant<int, LW_NEAR_LPV1>{}, std::false_type{}, m, n_list, cut_lo, cut_hi, merges > 0, act_level)
+                              : near_enum(std::integral_constant<int, 16>{}, std::true_type{}, n_act, n_list, cut_lo, cut_hi, merges > 0, act_level);
           if (count < 0) { near_ok = false; near_round = false; }   // some vertex has no list: no shell of this voxel comes from the lists
         }
         if (!near_round) {
@@ -941,6 +872,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const int dropped = near_round ? 0 : run_eval(n_list, count);   // the lists hold weights above thr0 only
       n_evals += (unsigned int)count;
       auto sort_len = [](int c) { int np = 64; while (np < c) np <<= 1; return np; };
+      LW_ACC(2);  // evaluate
       int behind = 0;   // dropped entries the sort leaves behind the real ones
       if (dropped > 0 && sort_len(n_list + count - dropped) < sort_len(n_list + count)) {
         // close the gaps before sorting when that halves the sort network (its length is the next power of two):
@@ -965,7 +897,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         sort_list(n_list);
       }
       n_list -= behind;
-      LW_ACC(2);  // evaluate
       if (P.dbg_stop == 2) return;
       // ---- 3. (sorted above) 4. merge down to the level ----
       LW_CNT(9, n_list);
