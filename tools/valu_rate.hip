@@ -21,9 +21,10 @@
 constexpr int ITER = 2048;
 constexpr int CHAINS = 16;
 
-enum Op { FMA_F32 = 0, ADD_F32, MUL_F32, ADD_U32, MULLO_U32, MAD_U32_U24, PK_FMA_F32, RCP_F32, SQRT_F32, EXP_F32, CNDMASK, FMA_F64, FMA_SALU_MIX, LDS_READ, BPERMUTE, N_OPS };
+enum Op { FMA_F32 = 0, ADD_F32, MUL_F32, ADD_U32, MULLO_U32, MAD_U32_U24, PK_FMA_F32, RCP_F32, SQRT_F32, EXP_F32, CNDMASK, FMA_F64, FMA_SALU_MIX, LDS_READ, BPERMUTE, CMP_U64, CMP_U32, MOV_DPP, CNDMASK_SGPR, PERMLANE32_SWAP, MAX_U32, CMP_U32_DPP, CNDMASK_DPP, BCNT, MBCNT, N_OPS };
 static const char* OP_NAME[N_OPS] = {"v_fma_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_mul_lo_u32", "v_mad_u32_u24", "v_pk_fma_f32", "v_rcp_f32",
-                                     "v_sqrt_f32", "v_exp_f32", "v_cndmask_b32", "v_fma_f64", "v_fma_f32 + s_add_u32 (1:1)", "ds_read_b32", "ds_bpermute_b32"};
+                                     "v_sqrt_f32", "v_exp_f32", "v_cndmask_b32", "v_fma_f64", "v_fma_f32 + s_add_u32 (1:1)", "ds_read_b32", "ds_bpermute_b32",
+                                     "v_cmp_gt_u64 (to sgpr pair)", "v_cmp_gt_u32 (to sgpr pair)", "v_mov_b32_dpp quad_perm", "v_cndmask_b32 (sgpr mask)", "v_permlane32_swap_b32", "v_max_u32", "v_max_u32_dpp", "v_cndmask_b32_dpp", "v_bcnt_u32_b32", "v_mbcnt_lo_u32_b32"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void k_rate(float* out, unsigned long long* cyc, unsigned long long* wall, float seed, unsigned long long* rec) {
@@ -58,6 +59,16 @@ __global__ __launch_bounds__(1024) void k_rate(float* out, unsigned long long* c
       else if constexpr (OP == SQRT_F32) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
       else if constexpr (OP == EXP_F32) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
       else if constexpr (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(x) : );
+      else if constexpr (OP == CMP_U64) asm volatile("v_cmp_gt_u64 s[20:21], %0, %1" : : "v"(d[i & 7]), "v"(xd) : "s20", "s21");
+      else if constexpr (OP == CMP_U32) asm volatile("v_cmp_gt_u32 s[20:21], %0, %1" : : "v"(a[i]), "v"(xu) : "s20", "s21");
+      else if constexpr (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+      else if constexpr (OP == CNDMASK_SGPR) asm volatile("v_cndmask_b32 %0, %0, %1, s[22:23]" : "+v"(a[i]) : "v"(x) : );
+      else if constexpr (OP == PERMLANE32_SWAP) { if (i < CHAINS / 2) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[2 * i]), "+v"(a[2 * i + 1])); }
+      else if constexpr (OP == MAX_U32) asm volatile("v_max_u32 %0, %1, %0" : "+v"(a[i]) : "v"(xu));
+      else if constexpr (OP == CMP_U32_DPP) asm volatile("v_max_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(xu));
+      else if constexpr (OP == CNDMASK_DPP) asm volatile("v_cndmask_b32_dpp %0, %0, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(x) : );
+      else if constexpr (OP == BCNT) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(xu));
+      else if constexpr (OP == MBCNT) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(xu));
       else if constexpr (OP == FMA_F64) { if (i < CHAINS / 2) asm volatile("v_fma_f64 %0, %1, %0, %2" : "+v"(d[i]) : "v"(xd), "v"(yd)); }
       else if constexpr (OP == FMA_SALU_MIX) {
         asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(x), "v"(y));
@@ -119,7 +130,7 @@ static void run(int cus, int wg_per_cu, int threads, float* d_out, unsigned long
     min_w = std::min(min_w, kv.second.size()); max_w = std::max(max_w, kv.second.size());
     for (auto& a : kv.second) { int cnt = 0; for (auto& b : kv.second) if (b.first <= a.first && a.first < b.second) ++cnt; max_conc = std::max(max_conc, cnt); }
   }
-  const int per_trip = (OP == PK_FMA_F32 || OP == FMA_F64) ? CHAINS / 2 : CHAINS;
+  const int per_trip = (OP == PK_FMA_F32 || OP == FMA_F64 || OP == PERMLANE32_SWAP) ? CHAINS / 2 : CHAINS;
   const double insts_total = (double)ITER * per_trip * grid * wpw;       // wave instructions of the launch
   const double span_us = (double)(last - first) / 100.0;                  // first loop entry to last loop exit (100 MHz counter)
   const double simds = (double)per_simd.size();
@@ -143,7 +154,12 @@ static void sweep(int cus, float* d_out, unsigned long long* d_cyc, unsigned lon
   run<OP>(cus * 8, 4, 64, d_out, d_cyc, d_wall, d_rec);
 }
 
-int main() {
+template <int OP>
+static void quick(int cus, float* d_out, unsigned long long* d_cyc, unsigned long long* d_wall, unsigned long long* d_rec) {
+  run<OP>(cus, 4, 256, d_out, d_cyc, d_wall, d_rec);
+}
+
+int main(int argc, char** argv) {
   hipDeviceProp_t pr;
   CK(hipGetDeviceProperties(&pr, 0));
   printf("device %s  CUs %d  clockRate %d kHz  wavefront %d\n", pr.name, pr.multiProcessorCount, pr.clockRate, pr.warpSize);
@@ -151,6 +167,21 @@ int main() {
   float* d_out; unsigned long long *d_cyc, *d_wall, *d_rec;
   const size_t max_wg = (size_t)cus * 32;
   CK(hipMalloc(&d_out, 64)); CK(hipMalloc(&d_cyc, max_wg * 8)); CK(hipMalloc(&d_wall, max_wg * 8)); CK(hipMalloc(&d_rec, max_wg * 16 * 32));
+  if (argc > 1) {   // "sort": the instructions of csrc/regsort.hpp, four wavefronts per SIMD
+    quick<ADD_U32>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CMP_U64>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CMP_U32>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<MOV_DPP>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CNDMASK>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CNDMASK_SGPR>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<PERMLANE32_SWAP>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<MAX_U32>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CMP_U32_DPP>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<CNDMASK_DPP>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<BCNT>(cus, d_out, d_cyc, d_wall, d_rec);
+    quick<MBCNT>(cus, d_out, d_cyc, d_wall, d_rec);
+    return 0;
+  }
   sweep<FMA_F32>(cus, d_out, d_cyc, d_wall, d_rec);
   sweep<ADD_F32>(cus, d_out, d_cyc, d_wall, d_rec);
   sweep<ADD_U32>(cus, d_out, d_cyc, d_wall, d_rec);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
           const bool pass = decided && (w > ta) && (w > tb);
           if (pass) {
             const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
-            const int gone = (ta >= tb) ? sb : sa;
+            const int gone = sa ^ sb ^ keep;          // see localcut_wave.hpp
             rep[gone] = (idx_t)keep;
             thr[keep] = vm_cut_threshold(w, cut, nsz);   // seg_int = w (VS:1988)
             ssz[keep] = (idx_t)nsz;
