@@ -170,7 +170,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     }
   };
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63;   // (not const: see the top of the shell loop)
+  const int wave = threadIdx.x >> 6;
   auto blk_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_sync(); };
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
   // Morton-ordered work list so that neighbouring voxels share their L2
@@ -822,6 +823,11 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     int rounds = 0;
     float act_level = __builtin_huge_valf();   // vertices whose segment's threshold is below this are still active
     while (true) {
+      // what the shell loop derives from the lane id alone (LDS addresses of its arrays, the row pointer) is loop invariant;
+      // hoisted, it outlives the register budget and was spilled -- six dwords per lane written to scratch by every wavefront,
+      // 0.47 GB of HBM writes per launch -- although each is one instruction away from the lane id.  Opaque here, it is
+      // recomputed where it is used.
+      if constexpr (NW == 1) asm volatile("" : "+v"(lane));
       // a neighbourhood that keeps hundreds of edges waiting above thr0 makes slow progress here: after a few
       // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
       // (examining all remaining pairs in this kernel and keeping the survivors only was tried: the neighbourhoods that
