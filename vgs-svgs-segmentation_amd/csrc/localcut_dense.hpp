@@ -21,6 +21,10 @@
 // <512, 4096, 2048, 512> for the hand-overs of the classes above (78 KB, two per CU).  MAXM neighbours at most; LCAP edges
 // heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it); QCAP pairs per block of
 // pass 1 = queue slots; TB threads.  The grid is fixed and strides over the hand-over list, whose length is on the device.
+// the sort's chunk-local stages in registers (regsort.hpp); 0: every stage through LDS
+#ifndef LD_REG_SORT
+#define LD_REG_SORT 1
+#endif
 #define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
 #define DN_ABIN 256     // histogram bins of the banded phase A, over (thr0, 1]
 #define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
@@ -122,6 +126,11 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(co
   };
   // descending sort of lk[0, cnt): one-direction bitonic network, slots >= cnt never move (localcut_wave.hpp: sort_section)
   auto sort_list = [&](int cnt) {
+    if constexpr (LD_REG_SORT != 0) {   // 512 keys per wavefront in registers, the widest strides through LDS (regsort.hpp)
+      static_assert(LCAP <= 512 * (TB / 64), "one block of 512 keys per wavefront");
+      regsort::sort_desc_block<TB / 64>(lk, cnt, wave, lane, [&]() { __syncthreads(); });
+      return;
+    }
     int np = 128;
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {

@@ -326,38 +326,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       if (x < y) { lk[lo] = y; lk[hi] = x; }
     };
     blk_sync();
-    if constexpr (NW > 1 && LW_REG_SORT != 0) {
-      // Multi-wavefront classes: wavefront w sorts keys [512 w, 512 w + 512) in registers (regsort.hpp); the merges of 1024, 2048
-      // and 4096 keys then take their mirror step and their strides of 512 and more through LDS, all wavefronts together, and the
-      // strides 256 .. 1 again in registers, every wavefront on its own 512 keys.  Against the LDS network this is a dozen passes
-      // over the list and as many workgroup barriers instead of 66 (2048 keys).
-      const int nblk = (cnt + 511) >> 9;
-      const int mine = cnt - 512 * wave < 512 ? cnt - 512 * wave : 512;   // keys of this wavefront's block
-      uint64_t* const blk_keys = lk + 512 * wave;
-      if (wave < nblk) {
-        if (mine <= 64) regsort::sort_desc<1>(blk_keys, mine, lane);
-        else if (mine <= 128) regsort::sort_desc<2>(blk_keys, mine, lane);
-        else if (mine <= 256) regsort::sort_desc<4>(blk_keys, mine, lane);
-        else regsort::sort_desc<8>(blk_keys, mine, lane);
-      }
-      blk_sync();
-      for (int size = 1024, sbit = 10; (size >> 1) < cnt; size <<= 1, ++sbit) {
-        for (int t = (int)threadIdx.x; t < (np >> 1); t += 64 * NW) {
-          const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
-          cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
-        }
-        blk_sync();
-        for (int sl = sbit - 2; sl >= 9; --sl) {
-          const int strd = 1 << sl;
-          for (int t = (int)threadIdx.x; t < (np >> 1); t += 64 * NW) {
-            const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
-            cmpx(lo, lo + strd);
-          }
-          blk_sync();
-        }
-        if (wave < nblk) regsort::sort_desc<8, true>(blk_keys, mine, lane);
-        blk_sync();
-      }
+    if constexpr (NW > 1 && LW_REG_SORT != 0) {   // 512 keys per wavefront in registers, the widest strides through LDS
+      regsort::sort_desc_block<NW>(lk, cnt, wave, lane, [&]() { __syncthreads(); });
       return;
     }
     for (int size = 2, sbit = 1; size <= np; size <<= 1, ++sbit) {

@@ -173,4 +173,50 @@ __device__ __forceinline__ void sort_desc_two_halves(uint64_t* lk, int cnt, int 
   for (int h = 0; h < 2; ++h) sort_desc<K, true>(lk + H * h, h ? cnt - H : H, lane);
 }
 
+// lk[0, cnt) of a workgroup of NWAVES wavefronts (cnt <= 512 * NWAVES; every thread calls, sync() is the workgroup barrier):
+// wavefront w sorts keys [512 w, 512 w + 512) in registers; the merges of 1024, 2048 and 4096 keys then take their mirror step and
+// their strides of 512 and more through LDS, all wavefronts together (the one-direction form: every comparator puts the larger key
+// at the lower index, slots at and behind cnt never move), and the strides 256 .. 1 again in registers, every wavefront on its own
+// 512 keys.  Against a network that runs every stage through LDS this is a dozen passes over the list and as many barriers instead
+// of 66 (2048 keys).
+template <int NWAVES, typename Sync>
+__device__ __forceinline__ void sort_desc_block(uint64_t* lk, int cnt, int wave, int lane, Sync sync) {
+  int np = 512;
+  while (np < cnt) np <<= 1;
+  const int tid = wave * 64 + lane;
+  auto cmpx = [&](int lo, int hi) {
+    if (hi >= cnt) return;
+    const uint64_t x = lk[lo], y = lk[hi];
+    if (x < y) { lk[lo] = y; lk[hi] = x; }
+  };
+  const int nblk = (cnt + 511) >> 9;
+  const int mine = cnt - 512 * wave < 512 ? cnt - 512 * wave : 512;   // keys of this wavefront's block
+  uint64_t* const blk_keys = lk + 512 * wave;
+  sync();
+  if (wave < nblk) {
+    if (mine <= 64) sort_desc<1>(blk_keys, mine, lane);
+    else if (mine <= 128) sort_desc<2>(blk_keys, mine, lane);
+    else if (mine <= 256) sort_desc<4>(blk_keys, mine, lane);
+    else sort_desc<8>(blk_keys, mine, lane);
+  }
+  sync();
+  for (int size = 1024, sbit = 10; (size >> 1) < cnt; size <<= 1, ++sbit) {
+    for (int t = tid; t < (np >> 1); t += 64 * NWAVES) {
+      const int blk = t >> (sbit - 1), i = t & ((size >> 1) - 1);
+      cmpx((blk << sbit) + i, (blk << sbit) + size - 1 - i);
+    }
+    sync();
+    for (int sl = sbit - 2; sl >= 9; --sl) {
+      const int strd = 1 << sl;
+      for (int t = tid; t < (np >> 1); t += 64 * NWAVES) {
+        const int lo = ((t >> sl) << (sl + 1)) | (t & (strd - 1));
+        cmpx(lo, lo + strd);
+      }
+      sync();
+    }
+    if (wave < nblk) sort_desc<8, true>(blk_keys, mine, lane);
+    sync();
+  }
+}
+
 }  // namespace regsort
