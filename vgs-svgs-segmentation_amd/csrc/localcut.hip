@@ -503,7 +503,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 #define LC_NCLASS 5   // A, B, C, D, A1
 __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
                                                    int max_a, int max_b, int max_c, const uint32_t* __restrict__ used_ids,
-                                                   const uint8_t* __restrict__ nl_cnt, int a1_max, uint32_t* __restrict__ ids_a,
+                                                   const uint8_t* __restrict__ nl_cnt, const uint32_t* __restrict__ nl_tot, int a1_max, uint32_t* __restrict__ ids_a,
                                                    uint32_t* __restrict__ ids_b, uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d,
                                                    uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc) {
   __shared__ unsigned int s_cnt[16][LC_NCLASS];   // per wavefront and class: count, then base
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
     cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3));
-    if (cls == 0 && nl_cnt && (int)nl_cnt[used_ids[u]] <= a1_max) cls = 4;   // NL_NONE (255) stays in A
+    if (cls == 0 && nl_cnt && nl_cnt[used_ids[u]] != NL_NONE && (int)nl_tot[used_ids[u]] <= a1_max) cls = 4;   // a voxel without a list stays in A
   }
   unsigned long long mk[LC_NCLASS];
   for (int k = 0; k < LC_NCLASS; ++k) {
@@ -663,7 +663,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   const int a1_max = c->K.a1_max;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
-                     0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, a1_max, ids_a, ids_b, ids_c,
+                     0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, c->nl_tot.p, a1_max, ids_a, ids_b, ids_c,
                      ids_d, ids_a1, d_nabc);
   unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
   VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
@@ -714,7 +714,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // rounding puts a hair outside their voxel's cube.
     const int steps = c->nl_enabled ? c->nl_reach_steps : NL_REACH;
     const float reach = (float)steps * c->P.voxel_size;
-    WP.near.cnt = c->nl_cnt.p; WP.near.slot = c->nl_slot.p; WP.near.dw = c->nl_dw.p;
+    WP.near.cnt = c->nl_cnt.p; WP.near.tot = c->nl_tot.p; WP.near.ent = c->nl_ent.p;
     // centroids may sit NL_CUBE_TOL voxels outside their cubes: (1 - 2 * NL_CUBE_TOL / steps)^2, rounded down
     WP.near.d2max = reach * reach * (steps >= 2 ? NL_D2_SLACK : 0.996f);
     WP.near.enabled = c->nl_enabled ? 1 : 0;
@@ -943,13 +943,13 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     fprintf(stderr, "[vgs] handed-over voxels: %u, m avg %.1f min %u max %u, evaluations avg %.0f of %.0f pairs, slow-path %llu\n", nfg[0], sm / nfg[0], mn, mx, se / nfg[0], sp / nfg[0], h[7]);
     if (c->nl_enabled) {
       // how well does a voxel's own near-list length predict a hand-over?
-      std::vector<uint8_t> nc((size_t)c->V);
+      std::vector<uint32_t> nc((size_t)c->V);
       std::vector<uint32_t> uid((size_t)U);
-      VGS_HIP_TRY(c, hipMemcpy(nc.data(), c->nl_cnt.p, nc.size(), hipMemcpyDeviceToHost));
+      VGS_HIP_TRY(c, hipMemcpy(nc.data(), c->nl_tot.p, nc.size() * 4, hipMemcpyDeviceToHost));
       VGS_HIP_TRY(c, hipMemcpy(uid.data(), c->used_ids.p, uid.size() * 4, hipMemcpyDeviceToHost));
       long long hall[34] = {0}, hho[34] = {0};
-      for (size_t u2 = 0; u2 < (size_t)U; ++u2) { int k = nc[uid[u2]]; hall[k > 32 ? 33 : k]++; }
-      for (uint32_t u2 : idf) { int k = nc[uid[u2]]; hho[k > 32 ? 33 : k]++; }
+      for (size_t u2 = 0; u2 < (size_t)U; ++u2) { int k = (int)nc[uid[u2]]; hall[k > 32 ? 33 : k]++; }
+      for (uint32_t u2 : idf) { int k = (int)nc[uid[u2]]; hho[k > 32 ? 33 : k]++; }
       fprintf(stderr, "[vgs] own near-list length: all / handed over:");
       for (int k = 0; k < 34; ++k) if (hall[k]) fprintf(stderr, " %d:%lld/%lld", k, hall[k], hho[k]);
       fprintf(stderr, "\n");

@@ -60,7 +60,10 @@
 #endif
 // lanes per vertex when the first shell is read from the near-pair lists (8 or 16; see near_enum)
 #ifndef LW_NEAR_LPV1
-#define LW_NEAR_LPV1 9
+#define LW_NEAR_LPV1 5
+#endif
+#ifndef LW_NEAR_LPV2
+#define LW_NEAR_LPV2 8
 #endif
 // groups of vertices whose near-pair list entries are requested together (first shells)
 #ifndef LW_NEAR_GROUPS
@@ -277,9 +280,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           uint32_t h = h_slot(key15);
           while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
         }
-        const int nc = (int)P.near.cnt[t];
-        if (!inb || nc == NL_NONE) sh_i[SH_NEARBAD] = 1;
-        near_sum += nc;
+        if (!inb || P.near.cnt[t] == NL_NONE) sh_i[SH_NEARBAD] = 1;
+        near_sum += (int)P.near.tot[t];
       }
     }
   }
@@ -472,10 +474,11 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // weight has the list's owner as first argument, which is the orientation the cut wants.
   // Four vertices per step, sixteen lanes each (lists are sorted by distance: on a surface the shell ends before entry 16);
   // a vertex whose sixteenth entry is still inside the shell gets a step of its own for the rest.
-  // LPV lanes per vertex: 8 for the first shell -- 98 % of the vertices of URB10M have at most eight entries inside it, so a
-  // trip of 64 lanes takes eight vertices instead of four and the enumeration half the trips -- 16 for the later, wider ones.
+  // LPV lanes per vertex.  Every pair is in ONE list (nearlist.hpp): a vertex on a surface owns four of its eight first-shell
+  // pairs, so five lanes per vertex read the first shell (twelve vertices per trip of 64 lanes; nine lanes and seven vertices
+  // while every pair was listed twice, sixteen and four at first) and eight the later, wider ones.
   // Later shells (LATER): only the vertices that can still merge -- alist[0, n_act), kept by the freeze step -- own entries
-  // that count.
+  // that count (a pair needs both ends active, so its owner is among them).
   auto near_enum = [&](auto lpv_c, auto later_c, int n_act, int n_list, float cut_lo, float cut_hi, bool merged, float act_level) -> int {
     constexpr int LPV = decltype(lpv_c)::value, ROWS = 64 / LPV;
     constexpr bool LATER = decltype(later_c)::value;
@@ -485,28 +488,34 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       const uint32_t lo = (uint32_t)__shfl((int)tid_reg0, va & 63, 64), hi = (uint32_t)__shfl((int)tid_reg1, va & 63, 64);
       return va < 64 ? lo : hi;
     };
-    // entry e = (d2, w), s = packed offset of vertex va's list; all lanes call
-    auto take = [&](int va, bool act, float2 e, uint32_t sl) -> bool {
+    // entry E = (d2, w(va, b), w(b, va), offset of b from va) of vertex va's list; all lanes call
+    auto take = [&](int va, bool act, float4 E) -> bool {
       bool inr = false;
       uint32_t pid = 0;
-      const bool inside = act && e.x < cut_hi;
-      if (inside && e.x >= cut_lo) {
+      float w = 0.0f;
+      const bool inside = act && E.x < cut_hi;
+      if (inside && E.x >= cut_lo) {
         // nibble-wise (a + 5) + (s + 2): the partner's offset from the voxel, + 7
-        const uint32_t q = (uint32_t)nlat[va] + sl;
+        const uint32_t q = (uint32_t)nlat[va] + __float_as_uint(E.w);
         const int bx = (int)(q & 15u) - NL_REACH, by = (int)((q >> 4) & 15u) - NL_REACH, bz = (int)((q >> 8) & 15u) - NL_REACH;
         if ((unsigned)bx < (unsigned)NMAP_DIM && (unsigned)by < (unsigned)NMAP_DIM && (unsigned)bz < (unsigned)NMAP_DIM) {
           const int vb = nmap[(bz * NMAP_DIM + by) * NMAP_DIM + bx];
-          if (vb != 0xff && va < vb) {
-            inr = true;
-            if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
-            pid = ((uint32_t)va << PSH) | (uint32_t)vb;
+          if (vb != 0xff) {
+            // the row's order decides which end is the weight's first argument (fact S: an edge at or below thr0 is not stored)
+            w = va < vb ? E.y : E.z;
+            if (w > thr0) {
+              inr = true;
+              if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+              const int lo = va < vb ? va : vb, hi = va ^ vb ^ lo;
+              pid = ((uint32_t)lo << PSH) | (uint32_t)hi;
+            }
           }
         }
       }
       const unsigned long long mk = __ballot(inr);
       if (inr) {
         const int pos = n_list + count + __popcll(mk & lt_mask);
-        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(e.y) << 32) | (uint64_t)(PCOMP - pid);
+        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
       }
       count += __popcll(mk);
       return inside;
@@ -516,8 +525,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     // LW_NEAR_GROUPS groups of ROWS vertices per trip: their list entries are requested together (the ids come out of
     // registers, so the only memory round trip of a trip is the entries themselves)
     for (int base = 0; base < nv; base += ROWS * LW_NEAR_GROUPS) {
-      float2 e[LW_NEAR_GROUPS];
-      uint32_t sl[LW_NEAR_GROUPS];
+      float4 E[LW_NEAR_GROUPS];
       int vas[LW_NEAR_GROUPS];
       bool act[LW_NEAR_GROUPS], in[LW_NEAR_GROUPS];
 #pragma unroll
@@ -526,29 +534,32 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         act[g] = iv < nv && row < ROWS;
         vas[g] = LATER ? (act[g] ? (int)alist[iv] : 0) : iv;
         const size_t o = (size_t)vertex_id(vas[g]) * NL_S + (size_t)j;
-        e[g] = make_float2(0.f, 0.f); sl[g] = 0;
-        if (act[g]) { e[g] = P.near.dw[o]; sl[g] = P.near.slot[o]; }
-        none = none || (e[g].x != e[g].x);
+        E[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act[g]) E[g] = P.near.ent[o];
+        none = none || (E[g].x != E[g].x);
       }
 #pragma unroll
-      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(vas[g], act[g], e[g], sl[g]);
-      // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken two vertices per step, 32 lanes each
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(vas[g], act[g], E[g]);
+      // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken four vertices per step, 16 lanes each
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
         unsigned long long more = __ballot(in[g] && j == LPV - 1);
         while (more) {
-          const int l0 = __ffsll((long long)more) - 1;
-          more &= more - 1ull;
-          int l1 = -1;
-          if (more) { l1 = __ffsll((long long)more) - 1; more &= more - 1ull; }
-          const int va0 = __builtin_amdgcn_readlane(vas[g], l0), va1 = l1 >= 0 ? __builtin_amdgcn_readlane(vas[g], l1) : 0;
-          const int va = lane < 32 ? va0 : va1;
-          const bool a2 = (lane & 31) < NL_S - LPV && (lane < 32 || l1 >= 0);
-          const size_t o = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & 31);
-          float2 e2 = make_float2(0.f, 0.f);
-          uint32_t s2 = 0;
-          if (a2) { e2 = P.near.dw[o]; s2 = P.near.slot[o]; }
-          take(va, a2, e2, s2);
+          int va = 0;
+          bool a2 = false;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            if (more) {
+              const int l0 = __ffsll((long long)more) - 1;
+              more &= more - 1ull;
+              const int vh = __builtin_amdgcn_readlane(vas[g], l0);
+              if ((lane >> 4) == h) { va = vh; a2 = (lane & 15) < NL_S - LPV; }
+            }
+          }
+          const size_t o2 = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & 15);   // all lanes: a cross-lane read returns 0 from a lane that is switched off
+          float4 E2 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a2) E2 = P.near.ent[o2];
+          take(va, a2, E2);
         }
       }
     }
@@ -559,20 +570,24 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // The same for the multi-wavefront classes (a section: all wavefronts, candidates appended through the LDS counter):
   // four vertices per trip and wavefront, partner vertices found through the hash.
   auto near_enum_h = [&](int n_list, float cut_lo, float cut_hi, bool merged, float act_level) {
-    auto take = [&](int va, bool act, float2 e, uint32_t sl) -> bool {
+    auto take = [&](int va, bool act, float4 E) {
       bool inr = false;
       uint32_t pid = 0;
-      const bool inside = act && e.x < cut_hi;
-      if (inside && e.x >= cut_lo) {
-        const uint32_t la = hlat[va];
+      float w = 0.0f;
+      if (act && E.x < cut_hi && E.x >= cut_lo) {
+        const uint32_t la = hlat[va], sl = __float_as_uint(E.w);
         const int bx = (int)(la & 31u) + (int)(sl & 15u) - NL_REACH, by = (int)((la >> 5) & 31u) + (int)((sl >> 4) & 15u) - NL_REACH,
                   bz = (int)((la >> 10) & 31u) + (int)((sl >> 8) & 15u) - NL_REACH;
         if ((unsigned)bx < 32u && (unsigned)by < 32u && (unsigned)bz < 32u) {
           const int vb = h_find((uint32_t)bx | ((uint32_t)by << 5) | ((uint32_t)bz << 10));
-          if (vb >= 0 && va < vb) {
-            inr = true;
-            if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
-            pid = ((uint32_t)va << PSH) | (uint32_t)vb;
+          if (vb >= 0) {
+            w = va < vb ? E.y : E.z;   // the row's order decides which end is the weight's first argument
+            if (w > thr0) {
+              inr = true;
+              if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+              const int lo = va < vb ? va : vb, hi = va ^ vb ^ lo;
+              pid = ((uint32_t)lo << PSH) | (uint32_t)hi;
+            }
           }
         }
       }
@@ -582,29 +597,17 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       b = __builtin_amdgcn_readfirstlane(b);
       if (inr) {
         const int pos = n_list + b + __popcll(mk & lt_mask);
-        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(e.y) << 32) | (uint64_t)(PCOMP - pid);
+        if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
       }
-      return inside;
     };
+    static_assert(NL_S == 16, "sixteen lanes read a vertex's whole list");
     const int j = lane & 15;
     for (int base = wave * 4; base < m; base += NW * 4) {
       const int va = base + (lane >> 4);
       const bool act = va < m;
-      float2 e = make_float2(0.f, 0.f);
-      uint32_t sl = 0;
-      if (act) { const size_t o = (size_t)(uint32_t)row[va] * NL_S + (size_t)j; e = P.near.dw[o]; sl = P.near.slot[o]; }
-      const bool in = take(va, act, e, sl);
-      unsigned long long more = __ballot(in && j == 15);   // the shell goes on behind entry 15 of a vertex
-      while (more) {
-        const int l0 = __ffsll((long long)more) - 1;
-        more &= more - 1ull;
-        const int va2 = base + (l0 >> 4);
-        const bool a2 = lane < NL_S - 16;
-        float2 e2 = make_float2(0.f, 0.f);
-        uint32_t s2 = 0;
-        if (a2) { const size_t o = (size_t)(uint32_t)row[va2] * NL_S + 16 + (size_t)(lane & 15); e2 = P.near.dw[o]; s2 = P.near.slot[o]; }
-        take(va2, a2, e2, s2);
-      }
+      float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act) E = P.near.ent[(size_t)(uint32_t)row[va] * NL_S + (size_t)j];
+      take(va, act, E);
     }
   };
 
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         count = 0;
         if (near_round) {
           count = rounds == 1 ? near_enum(std::integral_constant<int, LW_NEAR_LPV1>{}, std::false_type{}, m, n_list, cut_lo, cut_hi, merges > 0, act_level)
-                              : near_enum(std::integral_constant<int, 16>{}, std::true_type{}, n_act, n_list, cut_lo, cut_hi, merges > 0, act_level);
+                              : near_enum(std::integral_constant<int, LW_NEAR_LPV2>{}, std::true_type{}, n_act, n_list, cut_lo, cut_hi, merges > 0, act_level);
           if (count < 0) { near_ok = false; near_round = false; }   // some vertex has no list: no shell of this voxel comes from the lists
         }
         if (!near_round) {

@@ -16,9 +16,9 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
                                                    float lat_d2_lim, float d2max, const uint64_t* __restrict__ vox_code,
                                                    float res_f, float min_x, float min_y, float min_z, float cube_tol,
-                                                   uint8_t* __restrict__ out_cnt, uint16_t* __restrict__ out_slot, float2* __restrict__ out_dw) {
+                                                   uint8_t* __restrict__ out_cnt, uint32_t* __restrict__ out_tot, float4* __restrict__ out_ent) {
   __shared__ uint32_t q_t[NLB_QCAP];      // partner voxel id
-  __shared__ float q_d2[NLB_QCAP], q_w[NLB_QCAP];   // centroid distance^2; weight, NaN = not kept
+  __shared__ float q_d2[NLB_QCAP], q_w[NLB_QCAP], q_w2[NLB_QCAP];   // centroid distance^2; w(a, b), NaN = pair not kept; w(b, a)
   __shared__ uint16_t q_slot[NLB_QCAP];
   __shared__ uint8_t q_g[NLB_QCAP];       // which voxel of the group
   __shared__ uint32_t s_vid[NLB_G];
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
     const int g_first = g;
     int nq = 0;
     for (; g < ng; ++g) {
-      // (2 * NL_REACH + 1)^3 - 1 cells can qualify at most
-      if (nq + ((2 * NL_REACH + 1) * (2 * NL_REACH + 1) * (2 * NL_REACH + 1) - 1) > NLB_QCAP) break;
+      // half of the (2 * NL_REACH + 1)^3 - 1 cells can qualify at most (positive offsets)
+      if (nq + ((2 * NL_REACH + 1) * (2 * NL_REACH + 1) * (2 * NL_REACH + 1) - 1) / 2 > NLB_QCAP) break;
       const int64_t u = u0 + g;
       const uint32_t i = used_ids[u];
       if (lane == 0) { s_vid[g] = i; s_start[g] = nq; }
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
           const uint32_t npad = nb.pad;
           const int dx = nl_diff10(npad & 1023u, mpad & 1023u), dy = nl_diff10((npad >> 10) & 1023u, (mpad >> 10) & 1023u),
                     dz = nl_diff10((npad >> 20) & 1023u, (mpad >> 20) & 1023u);
-          if (dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
+          const bool positive = dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0)));   // the pair lives in this voxel's list
+          if (positive && dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
             const float bx = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
             const float ex = ax - bx, ey = ay - nb.c[1], ez = az - nb.c[2];   // the cut's own expression (order-free: squares)
             d2 = (ex * ex + ey * ey) + ez * ez;
@@ -108,10 +109,19 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
     }
     if (lane == 0) s_start[g] = nq;
     __syncthreads();
-    // ---- 2. weights, on full wavefronts ----
-    for (int e = lane; e < nq; e += 64) {
-      const float w = vm_pair_weight(node[s_vid[q_g[e]]], node[q_t[e]], W);   // the list's owner is the FIRST argument
-      q_w[e] = (w > thr0) ? w : vm_nan();   // NaN compares false
+    // ---- 2. weights, on full wavefronts: both orientations of every queued pair ----
+    for (int e = lane; e < 2 * nq; e += 64) {
+      const int q = e >> 1;
+      const NodeRec& A = node[s_vid[q_g[q]]];
+      const NodeRec& B = node[q_t[q]];
+      const float w = (e & 1) ? vm_pair_weight(B, A, W) : vm_pair_weight(A, B, W);
+      if (e & 1) q_w2[q] = w; else q_w[q] = w;
+    }
+    __syncthreads();
+    for (int q = lane; q < nq; q += 64) {
+      const float w1 = q_w[q], w2 = q_w2[q];
+      if (!((w1 > thr0) || (w2 > thr0))) q_w[q] = vm_nan();   // NaN compares false: a pair is kept when either orientation is heavy
+      else if (!(w1 == w1)) q_w[q] = 0.0f;                     // (kept for w(b, a): its own weight must not look like the mark)
     }
     __syncthreads();
     // ---- 3. every kept entry finds its place in its voxel's list: ascending (d2, slot) among the kept ones ----
@@ -129,9 +139,10 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
         }
         if (r < NL_S) {
           const size_t o = (size_t)s_vid[gg] * NL_S + (size_t)r;
-          out_dw[o] = make_float2(md, mw); out_slot[o] = (uint16_t)ms;
+          out_ent[o] = make_float4(md, mw, q_w2[e], __uint_as_float(ms));
         }
         if (s_kept[gg] >= 0) atomicAdd(&s_kept[gg], 1);
+        atomicAdd(&out_tot[s_vid[gg]], 1u); atomicAdd(&out_tot[q_t[e]], 1u);
       }
     }
     __syncthreads();
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ 
     for (int x = lane; x < (g - g_first) * NL_S; x += 64) {
       const int gg = g_first + x / NL_S, j = x % NL_S;
       const int kept = s_kept[gg];
-      if (kept >= 0 && kept <= NL_S && j >= kept) out_dw[(size_t)s_vid[gg] * NL_S + (size_t)j] = make_float2(__builtin_huge_valf(), 0.0f);
+      if (kept >= 0 && kept <= NL_S && j >= kept) out_ent[(size_t)s_vid[gg] * NL_S + (size_t)j] = make_float4(__builtin_huge_valf(), 0.0f, 0.0f, 0.0f);
       if (j == 0) {
         const bool none = kept < 0 || kept > NL_S || !((cube_ok >> gg) & 1ull);
         out_cnt[s_vid[gg]] = none ? (uint8_t)NL_NONE : (uint8_t)kept;
         // a reader that does not look at the count (the one-wavefront classes of the cut) finds "no list" as a NaN distance in entry 0
-        if (none) out_dw[(size_t)s_vid[gg] * NL_S] = make_float2(vm_nan(), 0.0f);
+        if (none) out_ent[(size_t)s_vid[gg] * NL_S] = make_float4(vm_nan(), 0.0f, 0.0f, 0.0f);
       }
     }
     __syncthreads();
@@ -171,8 +182,9 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   c->nl_reach_steps = reach_steps;
   if (reach_steps == 0) return VGS_OK;
   const int64_t V = c->V, U = c->U;
-  VGS_HIP_TRY(c, c->nl_cnt.ensure(V)); VGS_HIP_TRY(c, c->nl_slot.ensure((size_t)V * NL_S));
-  VGS_HIP_TRY(c, c->nl_dw.ensure((size_t)V * NL_S));
+  VGS_HIP_TRY(c, c->nl_cnt.ensure(V)); VGS_HIP_TRY(c, c->nl_tot.ensure(V));
+  VGS_HIP_TRY(c, c->nl_ent.ensure((size_t)V * NL_S));
+  VGS_HIP_TRY(c, hipMemsetAsync(c->nl_tot.p, 0, (size_t)V * sizeof(uint32_t), c->stream));
   VgsWeightParams W;
   W.inv_sig_p = 1.0f / c->P.sig_p; W.inv_sig_n = 1.0f / c->P.sig_n; W.inv_sig_o = 1.0f / c->P.sig_o;
   W.inv_sig_e = 1.0f / c->P.sig_e; W.inv_sig_c = 1.0f / c->P.sig_c;
@@ -185,7 +197,7 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   const float lat_lim = ((float)(3 * NL_REACH * NL_REACH) + 0.5f) * res * res;
   hipLaunchKernelGGL(k_near_lists, dim3(vgs_xcd_grid((U + NLB_G - 1) / NLB_G)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                      c->node.p, c->adj_gtab.p, c->adj_gstride, W, thr0, lat_lim, reach * reach, c->vox_code.p, res, (float)c->box.min[0],
-                     (float)c->box.min[1], (float)c->box.min[2], NL_CUBE_TOL * res, c->nl_cnt.p, c->nl_slot.p, c->nl_dw.p);
+                     (float)c->box.min[1], (float)c->box.min[2], NL_CUBE_TOL * res, c->nl_cnt.p, c->nl_tot.p, c->nl_ent.p);
   VGS_HIP_TRY(c, hipGetLastError());
   c->nl_enabled = true;
   return VGS_OK;

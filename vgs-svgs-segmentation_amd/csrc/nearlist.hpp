@@ -4,11 +4,15 @@
 // centroids are closer than about 1.5 voxels -- the same few pairs for every i that has both in its neighbourhood, about
 // 70 times each on a surface.  Voxels sit on a lattice, so these pairs are known per VOXEL: for every used voxel a the
 // builder lists its used neighbours b at most NL_REACH lattice steps away (Chebyshev) with
-//     centroid distance^2  d2(a, b) < (NL_REACH * voxel_size)^2   and   w(a, b) > 1 - cut  (not NaN),
-// sorted by d2, as (d2, w, packed lattice offset).  w(a, b) is vm_pair_weight with a as its FIRST argument (the
-// weight is symmetric only up to an ulp; the cut needs w(first, second) in the order of i's adjacency row, so both
-// orientations exist, one in each voxel's list).  The cut then walks the lists of its vertices instead of testing all
-// n^2/2 pairs, and takes the stored weight instead of evaluating it.
+//     centroid distance^2  d2(a, b) < (NL_REACH * voxel_size)^2   and   w(a, b) > 1 - cut or w(b, a) > 1 - cut,
+// sorted by d2, as (d2, w(a, b), w(b, a), packed lattice offset) -- and every pair ONCE (round 3): in the list of the voxel from
+// which the other lies at a lexicographically positive offset (dz, dy, dx).  The weight is symmetric only up to an ulp and the
+// cut needs w(first, second) in the order of i's adjacency row, so an entry carries both orientations and the reader picks.
+// (Rounds 2 and early 3 kept each pair in both voxels' lists, one orientation each; a reader then found half of the entries it
+// looked at pointing the wrong way.  A voxel with a complete neighbourhood has exactly half of its near partners at positive
+// offsets -- four of eight on a surface --, so five lanes per vertex read the first shell where nine were needed.)
+// The cut then walks the lists of its vertices instead of testing all n^2/2 pairs, and takes the stored weight instead of
+// evaluating it.
 // Exactness: a listed voxel's centroid lies inside its voxel's cube widened by NL_CUBE_TOL voxel sizes (the builder checks
 // it, counting the rounding of the float cube centre as well; a voxel that fails -- float sums of coordinates kilometres from
 // the origin -- gets NL_NONE), so two listed voxels more than R lattice steps apart on some axis are farther apart
@@ -23,7 +27,7 @@
 
 #include <stdint.h>
 
-#define NL_S 32       // entries per voxel; a voxel with more heavy near pairs is marked NL_NONE and its neighbourhoods take the general path
+#define NL_S 16       // entries per voxel (pairs at positive offsets); a voxel with more is marked NL_NONE and its neighbourhoods take the general path
 #define NL_REACH 2    // Chebyshev reach of the lists in lattice steps
 #define NL_NONE 0xffu
 #define NL_CUBE_TOL 0.9e-3f   // centroid may sit this many voxel sizes outside its cube (per axis) and still be listed
@@ -32,9 +36,10 @@
 
 struct NearLists {
   const uint8_t* cnt;    // [V]        number of entries, NL_NONE = no list
-  const uint16_t* slot;  // [V * NL_S] lattice offset of b from a: (dx+2) | (dy+2) << 4 | (dz+2) << 8
-  const float2* dw;      // [V * NL_S] (squared centroid distance, vm_pair_weight(a, b)), ascending distance; unused entries
-                         //            hold (+inf, 0), so a reader needs no count: "d2 < shell radius" ends the list; a voxel
+  const uint32_t* tot;   // [V]        heavy near pairs the voxel is part of, in either voxel's list (scheduling only)
+  const float4* ent;     // [V * NL_S] (squared centroid distance, vm_pair_weight(a, b), vm_pair_weight(b, a), bits of the lattice
+                         //            offset of b from a: (dx+2) | (dy+2) << 4 | (dz+2) << 8), ascending distance; unused entries
+                         //            hold d2 = +inf, so a reader needs no count: "d2 < shell radius" ends the list; a voxel
                          //            without a list (NL_NONE) has a NaN distance in entry 0
   float d2max;           // lists are complete for shells up to this squared centroid distance
   int enabled;           // the lists exist

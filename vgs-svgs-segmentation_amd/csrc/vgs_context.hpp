@@ -171,8 +171,8 @@ struct vgs_ctx {
 
   // near-pair lists (nearlist.hip): per voxel id, the heavy pairs with a used voxel at most two lattice steps away
   DevBuf<uint8_t> nl_cnt;
-  DevBuf<uint16_t> nl_slot;
-  DevBuf<float2> nl_dw;
+  DevBuf<uint32_t> nl_tot;
+  DevBuf<float4> nl_ent;
   bool nl_enabled = false;
   int nl_reach_steps = 0;     // lattice steps up to which the lists are complete (nearlist.hip)
   bool nl_direct = false;     // the ball fits the direct offset map of the one-wavefront classes
