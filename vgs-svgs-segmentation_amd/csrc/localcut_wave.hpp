@@ -540,7 +540,9 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       }
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(vas[g], act[g], E[g]);
-      // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken four vertices per step, 16 lanes each
+      // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken MV vertices per step, MW lanes each
+      constexpr int MW = (NL_S - LPV <= 16) ? 16 : 32, MV = 64 / MW;
+      static_assert(NL_S - LPV <= MW, "one step reads the rest of a list");
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
         unsigned long long more = __ballot(in[g] && j == LPV - 1);
@@ -548,15 +550,15 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           int va = 0;
           bool a2 = false;
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
+          for (int h = 0; h < MV; ++h) {
             if (more) {
               const int l0 = __ffsll((long long)more) - 1;
               more &= more - 1ull;
               const int vh = __builtin_amdgcn_readlane(vas[g], l0);
-              if ((lane >> 4) == h) { va = vh; a2 = (lane & 15) < NL_S - LPV; }
+              if (lane / MW == h) { va = vh; a2 = (lane & (MW - 1)) < NL_S - LPV; }
             }
           }
-          const size_t o2 = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & 15);   // all lanes: a cross-lane read returns 0 from a lane that is switched off
+          const size_t o2 = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & (MW - 1));   // all lanes: a cross-lane read returns 0 from a lane that is switched off
           float4 E2 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (a2) E2 = P.near.ent[o2];
           take(va, a2, E2);
@@ -600,14 +602,16 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         if (pos < LCAP) lk[pos] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
       }
     };
-    static_assert(NL_S == 16, "sixteen lanes read a vertex's whole list");
     const int j = lane & 15;
     for (int base = wave * 4; base < m; base += NW * 4) {
       const int va = base + (lane >> 4);
       const bool act = va < m;
-      float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (act) E = P.near.ent[(size_t)(uint32_t)row[va] * NL_S + (size_t)j];
-      take(va, act, E);
+      for (int c0 = 0; c0 < NL_S; c0 += 16) {   // sixteen entries of four vertices at a time; lists are sorted: stop behind the shell
+        float4 E = make_float4(__builtin_huge_valf(), 0.f, 0.f, 0.f);
+        if (act && c0 + j < NL_S) E = P.near.ent[(size_t)(uint32_t)row[va] * NL_S + (size_t)(c0 + j)];
+        take(va, act, E);
+        if (__ballot(act && j == 15 && E.x < cut_hi) == 0ull) break;
+      }
     }
   };
 

@@ -27,7 +27,10 @@
 
 #include <stdint.h>
 
-#define NL_S 16       // entries per voxel (pairs at positive offsets); a voxel with more is marked NL_NONE and its neighbourhoods take the general path
+#ifndef NL_S
+#define NL_S 16
+#endif
+// NL_S: entries per voxel (pairs at positive offsets); a voxel with more is marked NL_NONE and its neighbourhoods take the general path
 #define NL_REACH 2    // Chebyshev reach of the lists in lattice steps
 #define NL_NONE 0xffu
 #define NL_CUBE_TOL 0.9e-3f   // centroid may sit this many voxel sizes outside its cube (per axis) and still be listed
