@@ -492,7 +492,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 #include "localcut_wave.hpp"
 #include "localcut_dense.hpp"
-#define DN_SMALL 128, 2048, 2048, 256   // hand-overs of the one-wavefront classes
+#ifndef LD_SMALL_LCAP
+#define LD_SMALL_LCAP 2048
+#endif
+#define DN_SMALL 128, LD_SMALL_LCAP, 2048, 256   // hand-overs of the one-wavefront classes
 #define DN_LARGE 512, 4096, 2048, 512   // hand-overs of classes C and D up to 512 neighbours
 
 // split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.

@@ -25,6 +25,10 @@
 #ifndef LD_REG_SORT
 #define LD_REG_SORT 1
 #endif
+// workgroups per CU the small instantiation is compiled for (registers: 512 / this per lane)
+#ifndef LD_SMALL_WG_PER_CU
+#define LD_SMALL_WG_PER_CU 5
+#endif
 #define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
 #define DN_ABIN 256     // histogram bins of the banded phase A, over (thr0, 1]
 #define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
@@ -39,7 +43,7 @@ __device__ unsigned long long g_dn_prof[16];
 #endif
 
 template <int MAXM, int LCAP, int QCAP, int TB>
-__global__ __launch_bounds__(TB, (MAXM <= 255 ? 5 : 4)) void k_localcut_dense(const uint32_t* __restrict__ work, int work_stride, int n_lists, const unsigned int* __restrict__ n_work_dev,
+__global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_localcut_dense(const uint32_t* __restrict__ work, int work_stride, int n_lists, const unsigned int* __restrict__ n_work_dev,
                                                           const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                           int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                           uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
