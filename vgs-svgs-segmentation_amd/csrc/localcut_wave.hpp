@@ -539,7 +539,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         none = none || (E[g].x != E[g].x);
       }
 #pragma unroll
-      for (int g = 0; g < LW_NEAR_GROUPS; ++g) in[g] = take(vas[g], act[g], E[g]);
+      for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
+        in[g] = false;
+        if (g == 0 || base + ROWS * g < nv) in[g] = take(vas[g], act[g], E[g]);   // (uniform) the last trip may hold one group only
+      }
       // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken MV vertices per step, MW lanes each
       constexpr int MW = (NL_S - LPV <= 16) ? 16 : 32, MV = 64 / MW;
       static_assert(NL_S - LPV <= MW, "one step reads the rest of a list");
