@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
     b = nv - 1 - (int)(q - ((r * (r + 1u)) >> 1));
   };
   // descending sort of lk[0, cnt): one-direction bitonic network, slots >= cnt never move (localcut_wave.hpp: sort_section)
-  auto sort_list = [&](int cnt) {
+  auto sort_list = [&](int cnt) __attribute__((always_inline)) {
     if constexpr (LD_REG_SORT != 0) {   // 512 keys per wavefront in registers, the widest strides through LDS (regsort.hpp)
       static_assert(LCAP <= 512 * (TB / 64), "one block of 512 keys per wavefront");
       regsort::sort_desc_block<TB / 64>(lk, cnt, wave, lane, [&]() { __syncthreads(); });

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
   // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
   // real one that never move, so cnt need not be a power of two and nothing is padded.
-  auto sort_section = [&](int cnt) {   // all wavefronts of the workgroup
+  auto sort_section = [&](int cnt) __attribute__((always_inline)) {   // all wavefronts of the workgroup
     int np = 64;
     while (np < cnt) np <<= 1;
     auto cmpx = [&](int lo, int hi) {
