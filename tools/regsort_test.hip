@@ -49,8 +49,6 @@ void k_sort(const uint64_t* keys, const int* offs, int n_lists, uint64_t* out) {
           wave_sync();
         }
       }
-    } else if constexpr (MODE == 3) {
-      regsort::sort_desc_512(lk, cnt);
     } else {
       if (cnt <= 64) regsort::sort_desc<1>(lk, cnt, lane);
       else if (cnt <= 128) regsort::sort_desc<2>(lk, cnt, lane);
@@ -61,6 +59,23 @@ void k_sort(const uint64_t* keys, const int* offs, int n_lists, uint64_t* out) {
     }
     for (int e = lane; e < cnt; e += 64) out[o + e] = lk[e];
     wave_sync();
+  }
+}
+
+// the workgroup form (multi-wavefront classes, dense hand-over kernels): four wavefronts, lists of up to 2048 keys
+__global__ __launch_bounds__(256) void k_sort_block(const uint64_t* keys, const int* offs, int n_lists, int scale, uint64_t* out) {
+  __shared__ uint64_t lk[2048];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int li = (int)blockIdx.x; li < n_lists; li += (int)gridDim.x) {
+    // list li of the block test = `scale` consecutive lists of the input glued together (up to 2048 keys)
+    const int first = li * scale, last = first + scale < n_lists * scale ? first + scale : n_lists * scale;
+    const int o = offs[first];
+    int cnt = offs[last] - o;
+    cnt = cnt < 2048 ? cnt : 2048;
+    __syncthreads();
+    for (int e = tid; e < cnt; e += 256) lk[e] = keys[o + e];
+    regsort::sort_desc_block<4>(lk, cnt, wave, lane, [&]() { __syncthreads(); });
+    for (int e = tid; e < cnt; e += 256) out[o + e] = lk[e];
   }
 }
 
@@ -99,7 +114,6 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0));
       if (mode == 0) hipLaunchKernelGGL(k_sort<0>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[0]);
       else if (mode == 1) hipLaunchKernelGGL(k_sort<1>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[1]);
-      else if (argc > 3) hipLaunchKernelGGL(k_sort<3>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[2]);
       else hipLaunchKernelGGL(k_sort<2>, dim3(grid), dim3(64), 0, 0, d_keys, d_offs, n_lists, d_out[2]);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float t; CK(hipEventElapsedTime(&t, e0, e1));
@@ -114,6 +128,22 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> ref(keys.begin() + offs[i], keys.begin() + offs[i + 1]);
     std::sort(ref.begin(), ref.end(), [](uint64_t x, uint64_t y) { return x > y; });
     for (int e = 0; e < (int)ref.size(); ++e) { bad_ref += a[offs[i] + e] != ref[e]; bad += b[offs[i] + e] != ref[e]; bad2 += c[offs[i] + e] != ref[e]; }
+  }
+  {   // block form: glue `scale` lists into one of up to 2048 keys
+    const int scale = std::max(1, 1400 / std::max(1, mean)), nb = n_lists / scale;
+    hipLaunchKernelGGL(k_sort_block, dim3(std::min(nb, 256 * 5)), dim3(256), 0, 0, d_keys, d_offs, nb, scale, d_out[2]);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(c.data(), d_out[2], keys.size() * 8, hipMemcpyDeviceToHost));
+    size_t bad3 = 0;
+    for (int li = 0; li < nb; ++li) {
+      const int o = offs[li * scale];
+      const int cnt = std::min(offs[li * scale + scale] - o, 2048);
+      std::vector<uint64_t> ref(keys.begin() + o, keys.begin() + o + cnt);
+      std::sort(ref.begin(), ref.end(), [](uint64_t x, uint64_t y) { return x > y; });
+      for (int e = 0; e < cnt; ++e) bad3 += c[o + e] != ref[e];
+    }
+    std::printf("block form, %d lists of up to 2048 keys (wrong keys %zu)\n", nb, bad3);
+    if (bad3) return 1;
   }
   std::printf("lists %d  keys %zu  lds network %.3f ms (wrong keys %zu)  register network %.3f ms (wrong keys %zu)  with two halves above 256 keys %.3f ms (wrong keys %zu)\n", n_lists, keys.size(), ms[0], bad_ref, ms[1], bad, ms[2], bad2);
   return (bad_ref || bad || bad2) ? 1 : 0;
