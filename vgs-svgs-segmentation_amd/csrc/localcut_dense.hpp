@@ -218,22 +218,25 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
           alive = true;
         }
         while (true) {
+          // One wavefront of the workgroup merges and nothing hides its LDS round trips: both representative chains are walked
+          // at once, and every step brings the size and the threshold of the node reached along (the chains are about one step
+          // long), so an iteration waits for the walk, the claims, their read-back and the stores -- four trips instead of seven.
+          float ta = 0.f, tb = 0.f;
+          int nsz = 1;
           if (alive) {
-            int r;
-            while ((r = rep[sa]) != sa) sa = r;
-            while ((r = rep[sb]) != sb) sb = r;
+            int r = rep[sa], rb = rep[sb], za = (int)ssz[sa], zb = (int)ssz[sb];
+            ta = thr[sa]; tb = thr[sb];
+            while (r != sa || rb != sb) { sa = r; sb = rb; r = rep[sa]; rb = rep[sb]; za = (int)ssz[sa]; zb = (int)ssz[sb]; ta = thr[sa]; tb = thr[sb]; }
+            nsz = za + zb;
             alive = sa != sb;
           }
           if (__ballot(alive) == 0ull) break;
           if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
           wave_sync();
           bool decided = false;
-          float ta = 0.f, tb = 0.f;
-          int nsz = 1;
           if (alive) {
-            decided = (claim[sa] == (uint32_t)lane) && (claim[sb] == (uint32_t)lane);
-            ta = thr[sa]; tb = thr[sb];
-            nsz = (int)ssz[sa] + (int)ssz[sb];
+            const uint32_t ca = claim[sa], cb = claim[sb];   // both loads before either compare
+            decided = (ca == (uint32_t)lane) & (cb == (uint32_t)lane);
           }
           wave_sync();
           if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }

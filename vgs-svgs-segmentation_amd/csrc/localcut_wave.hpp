@@ -739,8 +739,12 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           while ((r = rep[sa]) != sa) { sa = r; ++walk; }
           while ((r = rep[sb]) != sb) { sb = r; ++walk; }
 #else
-          while ((r = rep[sa]) != sa) sa = r;
-          while ((r = rep[sb]) != sb) sb = r;
+          // both chains at once: one LDS round trip per step of the longer one (they are 1.08 steps long on average; the kernel
+          // waits for LDS round trips here, not for LDS issue slots).  (Loading sizes and thresholds along with every step, so
+          // that the cross-lane lookup of cut / size can travel with the claims, saved another trip and no time.)
+          int rb = rep[sb];
+          r = rep[sa];
+          while (r != sa || rb != sb) { sa = r; sb = rb; r = rep[sa]; rb = rep[sb]; }
 #endif
           alive = sa != sb;  // inside one segment: skipped now and for ever
         }
@@ -755,7 +759,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         float ta = 0.f, tb = 0.f;
         int nsz = 1;
         if (alive) {
-          decided = (claim[sa] == (uint32_t)lane) && (claim[sb] == (uint32_t)lane);
+          const uint32_t ca = claim[sa], cb = claim[sb];   // both loads before either compare
+          decided = (ca == (uint32_t)lane) & (cb == (uint32_t)lane);
           ta = thr[sa]; tb = thr[sb];
           nsz = (int)ssz[sa] + (int)ssz[sb];
         }
