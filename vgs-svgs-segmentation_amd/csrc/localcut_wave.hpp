@@ -489,14 +489,15 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       return va < 64 ? lo : hi;
     };
     // entry E = (d2, w(va, b), w(b, va), offset of b from va) of vertex va's list; all lanes call
-    auto take = [&](int va, bool act, float4 E) -> bool {
+    // (lat = nlat[va], read by the caller while the entry is still on its way: one LDS round trip less behind the memory one)
+    auto take = [&](int va, uint32_t lat, bool act, float4 E) -> bool {
       bool inr = false;
       uint32_t pid = 0;
       float w = 0.0f;
       const bool inside = act && E.x < cut_hi;
       if (inside && E.x >= cut_lo) {
         // nibble-wise (a + 5) + (s + 2): the partner's offset from the voxel, + 7
-        const uint32_t q = (uint32_t)nlat[va] + __float_as_uint(E.w);
+        const uint32_t q = lat + __float_as_uint(E.w);
         const int bx = (int)(q & 15u) - NL_REACH, by = (int)((q >> 4) & 15u) - NL_REACH, bz = (int)((q >> 8) & 15u) - NL_REACH;
         if ((unsigned)bx < (unsigned)NMAP_DIM && (unsigned)by < (unsigned)NMAP_DIM && (unsigned)bz < (unsigned)NMAP_DIM) {
           const int vb = nmap[(bz * NMAP_DIM + by) * NMAP_DIM + bx];
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     for (int base = 0; base < nv; base += ROWS * LW_NEAR_GROUPS) {
       float4 E[LW_NEAR_GROUPS];
       int vas[LW_NEAR_GROUPS];
+      uint32_t lats[LW_NEAR_GROUPS];
       bool act[LW_NEAR_GROUPS], in[LW_NEAR_GROUPS];
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
@@ -536,12 +538,13 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         const size_t o = (size_t)vertex_id(vas[g]) * NL_S + (size_t)j;
         E[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act[g]) E[g] = P.near.ent[o];
+        lats[g] = (uint32_t)nlat[vas[g]];
         none = none || (E[g].x != E[g].x);
       }
 #pragma unroll
       for (int g = 0; g < LW_NEAR_GROUPS; ++g) {
         in[g] = false;
-        if (g == 0 || base + ROWS * g < nv) in[g] = take(vas[g], act[g], E[g]);   // (uniform) the last trip may hold one group only
+        if (g == 0 || base + ROWS * g < nv) in[g] = take(vas[g], lats[g], act[g], E[g]);   // (uniform) the last trip may hold one group only
       }
       // the shell may go on behind entry LPV - 1 of a vertex: the rest of such lists is taken MV vertices per step, MW lanes each
       constexpr int MW = (NL_S - LPV <= 16) ? 16 : 32, MV = 64 / MW;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           const size_t o2 = (size_t)vertex_id(va) * NL_S + LPV + (size_t)(lane & (MW - 1));   // all lanes: a cross-lane read returns 0 from a lane that is switched off
           float4 E2 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (a2) E2 = P.near.ent[o2];
-          take(va, a2, E2);
+          take(va, (uint32_t)nlat[va], a2, E2);
         }
       }
     }
