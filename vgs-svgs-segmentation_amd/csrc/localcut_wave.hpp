@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
             w = va < vb ? E.y : E.z;
             if (w > thr0) {
               inr = true;
-              if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+              if (merged) { const int sa = seg[va], sb = seg[vb]; const float t1 = thr[sa], t2 = thr[sb]; inr = (sa != sb) & (t1 < act_level) & (t2 < act_level); }   // (both loads before either compare)
               const int lo = va < vb ? va : vb, hi = va ^ vb ^ lo;
               pid = ((uint32_t)lo << PSH) | (uint32_t)hi;
             }
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
             w = va < vb ? E.y : E.z;   // the row's order decides which end is the weight's first argument
             if (w > thr0) {
               inr = true;
-              if (merged) { const int sa = seg[va], sb = seg[vb]; inr = sa != sb && thr[sa] < act_level && thr[sb] < act_level; }
+              if (merged) { const int sa = seg[va], sb = seg[vb]; const float t1 = thr[sa], t2 = thr[sb]; inr = (sa != sb) & (t1 < act_level) & (t2 < act_level); }   // (both loads before either compare)
               const int lo = va < vb ? va : vb, hi = va ^ vb ^ lo;
               pid = ((uint32_t)lo << PSH) | (uint32_t)hi;
             }
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         int best = -1;
         for (int base = 0; base < m; base += 64) {
           const int c = base + lane;
-          if (c < m && ssz[c] != 0 && thr[c] < level) { const int key = ((int)ssz[c] << 16) | c; best = key > best ? key : best; }
+          if (c < m && ((ssz[c] != 0) & (thr[c] < level))) { const int key = ((int)ssz[c] << 16) | c; best = key > best ? key : best; }
         }
         for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(best, o, 64); best = other > best ? other : best; }
         big = best >= 0 ? (best & 0xffff) : -1;
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       int active_segs = 0;
       for (int base = 0; base < m; base += 64) {
         const int c = base + lane;
-        active_segs += __popcll(__ballot((c < m) && (ssz[c] != 0) && (thr[c] < level)));
+        active_segs += __popcll(__ballot((c < m) && ((ssz[c] != 0) & (thr[c] < level))));
       }
       if (active_segs < 2) break;  // nothing can merge at any weight <= level
       int kept = 0;
@@ -990,7 +990,8 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           kk = lk[e];
           const uint32_t pid = PCOMP - (uint32_t)kk;
           const int sa = seg[pid >> PSH], sb = seg[pid & PMASK];
-          keep_e = (sa != sb) && (thr[sa] < level) && (thr[sb] < level);
+          const float t1 = thr[sa], t2 = thr[sb];   // both loads before either compare
+          keep_e = (sa != sb) & (t1 < level) & (t2 < level);
         }
         const unsigned long long mk = __ballot(keep_e);
         wave_sync();  // all lanes have read their entry before anyone overwrites the front of the list
