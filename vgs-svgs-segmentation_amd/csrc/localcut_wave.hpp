@@ -59,6 +59,9 @@
 #define LW_REG_SORT 4
 #endif
 // lanes per vertex when the first shell is read from the near-pair lists (8 or 16; see near_enum)
+#ifndef LW_CUT_OVER_ONE
+#define LW_CUT_OVER_ONE 1
+#endif
 #ifndef LW_NEAR_LPV1
 #define LW_NEAR_LPV1 5
 #endif
@@ -709,6 +712,9 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     if constexpr (MAXM <= 128) {
       const int a = ((nsz - 1) & 63) << 2;
       const float lo = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(cut_tab0)));
+#if LW_CUT_OVER_ONE
+      if (__ballot(nsz > 64) == 0ull) return lo;   // (wave-uniform) sizes above 64 come late: most iterations need one lookup
+#endif
       const float hi = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(cut_tab1)));
       return nsz > 64 ? hi : lo;
     } else {
