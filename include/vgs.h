@@ -140,6 +140,9 @@ vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
  * outside every kernel's limits (result incomplete: vgs_segment reports it), 6 rows crossValidation put off, 7 voxels for which a dense
  * kernel took a phase in bands of descending weight (more edges than its list holds) */
 vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
+/* The same with room to grow (n <= 16): 8 neighbourhoods above 2048 used voxels, cut by the extra-large instantiation of the general
+ * kernel (the reference sizes its matrix to any n, VS:1815-1818; round 4 -- such a voxel used to end the run with VGS_E_UNSUPPORTED) */
+vgs_status vgs_get_schedule_counters_ex(vgs_ctx* ctx, int64_t* out, int32_t n);
 /* Screening table of the dense hand-over kernels for a parameter set (host arithmetic, no context, no GPU; for tests): a
  * pair of valid positions and normals whose squared centroid distance d2 is >= *d2_stop, or whose dot(n1, n2) lies in
  * [-1, ctab[min(63, int(d2 * *ctab_scale))]], weighs at most 1 - cut_thred and is not evaluated (csrc/localcut.hip). */

@@ -60,6 +60,28 @@ def test_hand_over_from_the_wide_kernels(gpu, oracle, monkeypatch):
         assert np.array_equal(off, roff) and ragged_sets(off, idx) == ragged_sets(roff, ridx)
 
 
+def test_extra_large_class_on_small_neighbourhoods(gpu, oracle, monkeypatch):
+    """The instantiation that takes neighbourhoods above 2048 used voxels (k_localcut<8192, 4096>: whole-ball vertex state in LDS,
+    half the edge list, so more histogram rounds) on a scene the oracle finishes quickly: VGS_DBG_MAXM sends everything above 600
+    neighbours down the hand-over chain and VGS_DBG_XL_FROM makes the 2048-vertex kernel queue it for the extra-large one."""
+    monkeypatch.setenv("VGS_DBG_MAXM", "600")
+    monkeypatch.setenv("VGS_DBG_XL_FROM", "600")
+    name, make, kw, _ = CASES[1]
+    xyz = make(gpu)
+    p = gpu.default_params(2, **kw)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    sc = eng.schedule_counters()
+    assert sc["extra_large"] > 100 and sc["outside_limits"] == 0, sc
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p))
+    for which in ("connect_cut", "connect_final"):
+        off, idx = eng.lists(which)
+        roff, ridx = ref.lists(which)
+        assert np.array_equal(off, roff) and ragged_sets(off, idx) == ragged_sets(roff, ridx)
+    np.testing.assert_array_equal(eng.point_labels(), ref.labels()[0])
+
+
 def test_case_reaches_the_class(run):
     c = run["eng"].counts()
     assert run["pred"](c["class_a"], c["class_bc"], c["class_d"]), c

@@ -3,7 +3,7 @@ clouds far from the origin whose bounding box grows in every direction, and the 
 import numpy as np
 import pytest
 
-from helpers import canonical_labels, oracle_params
+from helpers import canonical_labels, oracle_params, ragged_sets
 
 pytestmark = pytest.mark.gpu
 
@@ -128,6 +128,31 @@ def test_limits_are_reported_not_silently_wrong(gpu):
     eng2 = gpu.Engine(gpu.default_params(2)); eng2.set_points(far)
     with pytest.raises(gpu.VgsError):
         eng2.run()
+
+
+def test_neighbourhoods_above_2048_voxels(gpu, oracle):
+    """A solid block seen through a ball of eight voxels: 275 voxels have more than 2048 used neighbours.  The reference sizes its
+    matrix to any n (voxel_segmentation.h:1815-1818, 1913-1933); until round 3 one such voxel ended the run with VGS_E_UNSUPPORTED.
+    Now they are cut by the extra-large instantiation of the general kernel: connect lists and labels identical to the oracle
+    (DevMath + lean; its local cuts on every core -- 1.2e10 pair weights)."""
+    import os
+    rng = np.random.default_rng(12)
+    xyz = (rng.uniform(0, 1, (300_000, 3)) * 1.15 + np.array([1.0, -2.0, 0.2])).astype(np.float32)
+    p = gpu.default_params(2, voxel_size=0.0625, graph_size=0.5)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    n = eng.adjacency_counts()
+    sc = eng.schedule_counters()
+    assert n.max() > 2048 and sc["extra_large"] == int((n > 2048).sum()) and sc["outside_limits"] == 0, (n.max(), sc)
+    ref = oracle.run_vgs(xyz, oracle_params(oracle, p, threads=os.cpu_count() or 1))
+    for which in ("connect_cut", "connect_cross", "connect_final"):
+        off, idx = eng.lists(which)
+        roff, ridx = ref.lists(which)
+        assert np.array_equal(off, roff)
+        assert ragged_sets(off, idx) == ragged_sets(roff, ridx)
+    np.testing.assert_array_equal(eng.point_labels(), ref.labels()[0])
+    assert eng.counts()["kept"] == ref.kept_clusters
 
 
 def test_dense_volume_adjacency_second_pass(gpu, oracle):

@@ -5,7 +5,7 @@ map identical against DevMath/lean, P2 partition agreement against RefMath/faith
 import numpy as np
 import pytest
 
-from helpers import canonical_labels, oracle_params, partition_agreement, ragged_lists, ragged_sets
+from helpers import assert_p2, canonical_labels, oracle_params, ragged_lists, ragged_sets
 
 pytestmark = pytest.mark.gpu
 
@@ -89,8 +89,11 @@ def test_labels_identical(run):
     go, gi = eng.clusters()
     ro, ri = ref.lists("clusters_points")
     assert len(go) == len(ro)
-    for k in range(len(go) - 1):
-        assert sorted(gi[go[k]:go[k + 1]].tolist()) == sorted(ri[ro[k]:ro[k + 1]].tolist())
+    pv = eng.point_voxel()
+    for k in range(len(go) - 1):    # the documented default order, asserted as such: voxels ascending, points ascending inside a voxel
+        want = ri[ro[k]:ro[k + 1]]
+        want = want[np.lexsort((want, pv[want]))]
+        np.testing.assert_array_equal(gi[go[k]:go[k + 1]], want)
 
 
 def test_cluster_index_lists_in_reference_order(run):
@@ -114,11 +117,13 @@ def test_cluster_index_lists_in_reference_order(run):
 
 def test_partition_vs_refmath_faithful(run, oracle):
     """P2: against the oracle in the reference's own arithmetic (libm, promotions) and data flow
-    (n x n matrix, std::sort): >= 99.5 % of points in matching segments."""
+    (n x n matrix, std::sort), all three clauses of SURVEY 8c: >= 99.5 % of the used voxels in matching segments, point-set
+    IoU >= 0.98 for every oracle segment of >= 20 voxels, kept-segment count within +-1 %."""
     ref = oracle.run_vgs(run["xyz"], oracle_params(oracle, run["p"], math=0, flavour=0))
     pl_ref, _ = ref.labels()
-    agree = partition_agreement(run["eng"].point_labels(), pl_ref)
-    assert agree >= 0.995, agree
+    eng = run["eng"]
+    r = assert_p2(eng.point_labels(), pl_ref, eng.point_voxel(), eng.attributes()["used"])
+    assert r["big_segments"] >= 2, r          # the IoU clause has something to bite on
 
 
 def test_pair_weights_vs_refmath(run, oracle):

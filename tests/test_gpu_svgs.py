@@ -4,7 +4,7 @@ pcl::SupervoxelClustering: SURVEY.md 8 rows a13-a15; the VCCS-style clustering i
 import numpy as np
 import pytest
 
-from helpers import canonical_labels, oracle_params, ragged_lists, ragged_sets
+from helpers import assert_p2, canonical_labels, oracle_params, ragged_lists, ragged_sets
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,17 @@ def test_connect_lists_exact(run, which):
     gs, rs = ragged_sets(go, gi), ragged_sets(ro, ri)
     bad = [v for v in range(len(rs)) if gs[v] != rs[v]]
     assert not bad, f"{which}: {len(bad)} of {len(rs)} supervoxels differ, first {bad[:5]}"
+
+
+def test_partition_vs_refmath_faithful(run, oracle):
+    """P2 (all three clauses) against the oracle in the reference's own arithmetic and data flow (SS:1565-2305)."""
+    ref = oracle.run_svgs_from_labels(run["xyz"], run["labels"], run["max_label"], oracle_params(oracle, run["p"], math=0, flavour=0))
+    lab, mx = run["labels"].astype(np.int64), run["max_label"]
+    # supervoxel (node) of a point: rank of its label among the kept labels 1 .. max_label-1 (SS:303-313)
+    keep = (lab >= 1) & (lab < mx)
+    node = np.full(lab.size, -1, np.int64)
+    node[keep] = np.unique(lab[keep], return_inverse=True)[1]
+    assert_p2(run["eng"].point_labels(), ref.labels()[0], node)
 
 
 def test_labels_identical(run):

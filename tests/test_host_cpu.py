@@ -266,3 +266,32 @@ def test_grid_replay_from_bounding_boxes(vgs):
     L.vgs_grid_state_init(C.byref(g))
     need = C.c_int32(0)
     assert L.vgs_grid_advance_bbox(C.byref(g), C.c_double(res), np.zeros(6, np.float32).ctypes.data_as(C.c_void_p), C.byref(need)) == 0 and need.value == 1
+
+
+def test_p2_protocol_catches_what_it_is_for():
+    """tests/helpers.p2_protocol: identical partitions pass under renaming; a big segment split in two fails the
+    IoU clause although 99.5 % agreement alone would not notice a small scene's; dropped small segments fail the count clause."""
+    from helpers import assert_p2, p2_protocol
+    rng = np.random.default_rng(1)
+    V = 4000
+    pv = np.repeat(np.arange(V), 5)                       # five points per voxel
+    seg = np.minimum(np.arange(V) // 40, 60)              # 60 segments of 40 voxels and a large one
+    ref = seg[pv]
+    perm = rng.permutation(seg.max() + 1)
+    r = assert_p2(perm[seg][pv], ref, pv)                 # renaming does not matter
+    assert r["agreement"] == 1.0 and r["min_iou"] == 1.0 and r["big_segments"] == 61 and r["kept_ref"] == 61
+    split = seg.copy()
+    split[:3] = 99                                        # three voxels of a 40-voxel segment elsewhere: IoU 37/40
+    r = p2_protocol(split[pv], ref, pv)
+    assert r["agreement"] > 0.999 and abs(r["min_iou"] - 37 / 40) < 1e-9 and r["worst"]["ref_label"] == 0
+    with pytest.raises(AssertionError):
+        assert_p2(split[pv], ref, pv)
+    merged = np.where(seg == 1, 0, seg)                   # two oracle segments under one label: IoU 0.5 for both
+    with pytest.raises(AssertionError):
+        assert_p2(merged[pv], ref, pv)
+    dropped = np.where(seg < 2, -1, seg)                  # two of 61 segments dropped: count off by 3 %
+    r = p2_protocol(dropped[pv], ref, pv)
+    assert r["kept_test"] == 59 and r["min_iou"] == 0.0
+    used = np.ones(V, bool)
+    used[:80] = False                                     # agreement is over USED voxels only
+    assert p2_protocol(dropped[pv], ref, pv, used)["agreement"] == 1.0

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("svgs_get_supervoxel_labels", C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     ("vgs_get_counts", C.c_int, [_P, _P]),
     ("vgs_get_schedule_counters", C.c_int, [_P, _P]),
+    ("vgs_get_schedule_counters_ex", C.c_int, [_P, _P, C.c_int32]),
     ("vgs_screen_table", C.c_int, [_P, _P, _P, _P]),
     ("vgs_get_stage_times", C.c_int, [_P, _P]),
     ("vgs_get_bbox", C.c_int, [_P, _P]),

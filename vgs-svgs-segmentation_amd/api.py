@@ -141,9 +141,10 @@ class Engine:
         return {k: int(c[i]) for i, k in enumerate(names)}
 
     def schedule_counters(self):
-        c = np.zeros(8, dtype=np.int64)
-        self._ck(self._L.vgs_get_schedule_counters(self._h, _ptr(c)))
-        names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded")
+        c = np.zeros(9, dtype=np.int64)
+        self._ck(self._L.vgs_get_schedule_counters_ex(self._h, _ptr(c), 9))
+        names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded",
+                 "extra_large")
         return dict(zip(names, (int(x) for x in c)))
 
     def stage_times(self):

@@ -60,7 +60,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
   auto getf = [](const char* n, float d) { const char* v = getenv(n); return v ? (float)atof(v) : d; };
   auto has = [](const char* n) { return getenv(n) != nullptr; };
   k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
-  k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m);
+  k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m); k.dbg_xl_from = geti("VGS_DBG_XL_FROM", k.dbg_xl_from);
   k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
   k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS");
   k.debug = has("VGS_DEBUG");
@@ -465,9 +465,11 @@ vgs_status vgs_get_stage_times(vgs_ctx* c, double* ms) {
   return VGS_OK;
 }
 
-vgs_status vgs_get_schedule_counters(vgs_ctx* c, int64_t* out) {
-  if (!c || !out) return VGS_E_ARG;
-  for (int i = 0; i < 8; ++i) out[i] = c->lc_diag[i];
+vgs_status vgs_get_schedule_counters(vgs_ctx* c, int64_t* out) { return vgs_get_schedule_counters_ex(c, out, 8); }
+
+vgs_status vgs_get_schedule_counters_ex(vgs_ctx* c, int64_t* out, int32_t n) {
+  if (!c || !out || n < 0 || n > 16) return VGS_E_ARG;
+  for (int i = 0; i < n; ++i) out[i] = c->lc_diag[i];
   return VGS_OK;
 }
 

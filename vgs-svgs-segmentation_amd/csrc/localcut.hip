@@ -46,6 +46,7 @@ struct LcParams {
   // (k = int(d2 * ctab_scale)) and dot(n1, n2) in [-1, ctab[k]] weighs <= 1 - cut (lc_screen_table)
   float ctab_scale;
   const float* ctab;   // LC_TBINS floats on the device
+  int xl_from;         // tests (VGS_DBG_XL_FROM): a kernel with an overflow list passes neighbourhoods above this on (0: its own limit only)
 };
 
 __device__ __forceinline__ int lc_bin1(float w) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
                                                     int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                     uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
-                                                    uint32_t* __restrict__ evals_out) {
+                                                    uint32_t* __restrict__ evals_out, uint32_t* __restrict__ over_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* list = (uint64_t*)smem;                 // CAP keys, descending after the sort
   uint32_t* hist = (uint32_t*)smem;                 // aliases the list between rounds
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   uint16_t* loc = (uint16_t*)q; q += (size_t)MAXM * 2;   // position in the adjacency row
   uint16_t* seg = (uint16_t*)q; q += (size_t)MAXM * 2;   // vertex -> segment representative
   uint16_t* ssize = (uint16_t*)q; q += (size_t)MAXM * 2; // size of the segment represented by this vertex
-  __shared__ int s_m, s_nlist, s_rdone, s_sel, s_err, s_act[LC_TB / 64];
+  __shared__ int s_m, s_nlist, s_rdone, s_sel, s_err, s_frozen, s_act[LC_TB / 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // a hand-over list is launched with a fixed grid while its length is still on the device: n_work_dev, when given,
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   uint8_t* crow = conn + (int64_t)u * adj_stride;
 
   // ---- gather the (used) neighbours in adjacency order ----
-  if (tid == 0) { s_m = 0; s_err = 0; s_rdone = LC_NBIN * LC_NBIN; evals_out[u] = 0; }
+  if (tid == 0) { s_m = 0; s_err = 0; s_frozen = 0; s_rdone = LC_NBIN * LC_NBIN; evals_out[u] = 0; }
   for (int k = tid; k < n; k += LC_TB) crow[k] = 0;
   __syncthreads();
   if (wave == 0) {
@@ -131,8 +132,14 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
   }
   __syncthreads();
   const int m = s_m;
-  if (m > MAXM) {  // outside this instantiation's limits: report, keep only the self connection
-    if (tid == 0) { atomicAdd(&counters[1], 1ull); crow[0] = 1; }
+  if (m > MAXM || (over_ids && P.xl_from > 0 && m > P.xl_from)) {
+    // outside this instantiation's limits: counted, and queued for the next larger instantiation when there is one (the host reads
+    // the count back and launches it: vgs_localcut_finish); the row keeps only the self connection until then
+    if (tid == 0) {
+      const unsigned long long at = atomicAdd(&counters[1], 1ull);
+      if (over_ids) over_ids[at] = u;
+      crow[0] = 1;
+    }
     return;
   }
   for (int c = tid; c < m; c += LC_TB) {
@@ -230,6 +237,9 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
         pos += f + 1;
         // stop when fewer than two segments can still merge at the next (and every later) weight
         const float wn = (pos < nl) ? vm_from_bits((uint32_t)(list[pos] >> 32)) : 0.f;
+        // ... or when the voxel's own segment is frozen (fact F of localcut_wave.hpp): its threshold moves only when it merges,
+        // every later edge weighs <= wn, so with thr >= wn no later edge joins it -- what the other segments still do is not asked
+        if (pos < nl && !(thr[seg[0]] < wn)) { if (lane == 0) s_frozen = 1; break; }
         int active = 0;
         for (int c = lane; c < m; c += 64) active += (ssize[c] != 0 && thr[c] < wn) ? 1 : 0;
         for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o, 64);
@@ -460,9 +470,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
     sort_desc(nl);
     merge_all(nl);
     __syncthreads();
-    if (single || take_from <= 0) break;
+    if (single || take_from <= 0 || s_frozen) break;
     // every unexamined edge has rank < take_from, i.e. weight below wub: go on only if two segments can merge there
     const float wub = (float)(take_from + 1) / ((float)LC_NBIN * (float)LC_NBIN) * 1.0001f;
+    if (!(thr[seg[0]] < wub)) break;   // the voxel's own segment is frozen (fact F)
     int active = 0;
     for (int c = tid; c < m; c += LC_TB) active += (ssize[c] != 0 && thr[c] < wub) ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) active += __shfl_xor(active, o, 64);
@@ -627,6 +638,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // (the adjacency stage already dropped the unused neighbours from the rows when that is the case)
   if (vgs_unused_are_inert(c->P) != c->adj_pruned) { c->err = "adjacency rows do not match the current sigma/cut parameters"; return VGS_E_STATE; }
   LP.prune_unused = 0;
+  LP.xl_from = c->K.dbg_xl_from;
   LP.d2_stop = __builtin_huge_valf();   // set below, once the neighbourhood's reach is known
   LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
@@ -734,13 +746,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, strm, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt, c->evals.p);
+                         c->node.p, LP, c->conn.p, cnt, c->evals.p, (uint32_t*)nullptr);
     } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, strm, ids, arg_n, n_dev, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                         c->node.p, LP, c->conn.p, cnt, c->evals.p);
+                         c->node.p, LP, c->conn.p, cnt, c->evals.p, ids_d /* overflow list: class D's own list is consumed by then */);
     }
     return VGS_OK;
   };
@@ -861,6 +873,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   LP.W = make_weight_params(c->P);
   LP.cut = c->P.cut_thred;
   LP.prune_unused = 0;
+  LP.xl_from = c->K.dbg_xl_from;
   {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, reach * reach * 1.01f);
@@ -868,6 +881,12 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   }
   constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
+  // Neighbourhoods above LARGE_M used voxels (the reference sizes its matrix to any n, VS:1815-1818): the same kernel with the
+  // per-vertex state of a whole search ball in LDS (the adjacency rows end at 8192 ball offsets) and half the edge list --
+  // 144 KB, one workgroup per CU.  The large instantiation queues them (its overflow list reuses class D's work list, which
+  // is consumed by now).
+  constexpr int XL_M = 8192, XL_CAP = 4096;
+  uint32_t* ids_xl = c->work_ids.p + 3 * U;
   auto launch_rest = [&](const uint32_t* ids, unsigned int nw, bool mid) -> vgs_status {
     if (nw == 0) return VGS_OK;
     if (mid) {
@@ -875,13 +894,13 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
       const size_t sm = lc_smem_bytes<SMALL_M, SMALL_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p);
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p, (uint32_t*)nullptr);
     } else {
       auto kern = k_localcut<LARGE_M, LARGE_CAP, false>;
       const size_t sm = lc_smem_bytes<LARGE_M, LARGE_CAP, false>();
       VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
       hipLaunchKernelGGL(kern, dim3(nw), dim3(LC_TB), sm, c->stream, ids, (int)nw, (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p);
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p, ids_xl);
     }
     return VGS_OK;
   };
@@ -918,6 +937,24 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
       VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
       VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+  }
+  c->lc_diag[8] = 0;
+  if (hc[1] > 0) {
+    // the extra-large class: everything the 2048-vertex instantiation queued
+    static_assert(XL_M <= 65535 && XL_M >= 8192, "pair ids are 2 x 16 bits; a row holds at most 8192 ball offsets");
+    const unsigned int n_xl = (unsigned int)hc[1];
+    if ((int64_t)n_xl > U) { c->err = "local cut: corrupt overflow count"; return VGS_E_HIP; }
+    auto kern = k_localcut<XL_M, XL_CAP, false>;
+    const size_t sm = lc_smem_bytes<XL_M, XL_CAP, false>();
+    VGS_HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    VGS_HIP_TRY(c, hipMemsetAsync(cnt + 1, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(kern, dim3(n_xl), dim3(LC_TB), sm, c->stream, ids_xl, (int)n_xl, (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p,
+                       c->adj_stride, c->node.p, LP, c->conn.p, cnt, c->evals.p, (uint32_t*)nullptr);
+    VGS_HIP_TRY(c, hipGetLastError());
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+    VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->lc_diag[8] = (int64_t)n_xl;
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
   c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
@@ -997,7 +1034,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     fprintf(stderr, "\n");
   }
 #endif
-  if (h[1]) { c->err = "a voxel has more than 2048 used neighbours (local-graph kernel limit)"; return VGS_E_UNSUPPORTED; }
+  if (h[1]) { c->err = "a voxel has more than 8192 used neighbours (beyond the adjacency rows' own limit)"; return VGS_E_UNSUPPORTED; }
   if (h[2]) { c->err = "degenerate neighbourhood: more than 8192 pair weights inside one 2^-22 interval"; return VGS_E_UNSUPPORTED; }
   return VGS_OK;
 }

@@ -82,6 +82,7 @@ struct VgsKnobs {
   int dbg_stop = 0;          // VGS_DBG_STOP
   int max_rounds = 6;        // VGS_ROUNDS
   int dbg_max_m = 0;         // VGS_DBG_MAXM
+  int dbg_xl_from = 0;       // VGS_DBG_XL_FROM: tests -- the 2048-vertex general kernel passes neighbourhoods above N on to the extra-large one
   int near_min_own = 7;      // VGS_NEARMINOWN
   int fv_blocks = 512;       // VGS_FV_BLOCKS
   int only_class = -1;       // VGS_ONLY_CLASS (-DVGS_PROF builds)
@@ -185,7 +186,7 @@ struct vgs_ctx {
   DevBuf<uint8_t> lc_pending;
   DevBuf<uint32_t> lc_defer;
   struct { bool open = false; bool dense = true; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
-  int64_t lc_diag[8] = {0};   // vgs_get_schedule_counters
+  int64_t lc_diag[16] = {0};   // vgs_get_schedule_counters[_ex]
   DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
   float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;
   bool lc_ctab_valid = false;
