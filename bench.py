@@ -13,7 +13,12 @@ configuration the metric is quoted on.  Two timed regions, both K steps after W 
     streams beside cloud k's stages (vgs_stage_points / vgs_commit_points / vgs_get_point_labels_async, include/vgs.h);
     `latency_ms_median` is one cloud on its own (set_points -> run -> labels, nothing overlapped, median of 5).
 N > 1: weak scaling, every rank owns one 10 M-point tile of the URB80M layout (configs[4]); tiles are segmented on one
-shared grid and boundary segments are merged with one all-gather of boundary records (vgs-svgs-segmentation_amd/dist.py).
+shared grid and boundary segments are merged with one all-gather of boundary records.  The driver is the NATIVE one
+(include/vgs_tiles.h = csrc/tiles.cpp, libvgs_tiles.so, through vgs-svgs-segmentation_amd/tiles_native.py): every rank creates
+its own ncclComm_t (ncclGetUniqueId on rank 0, the id broadcast through the process group that also carries the barrier and
+the max-over-ranks reduction), hands it to vgs_tiles_create(VGS_TILES_COMM_RCCL, ...) and times vgs_tiles_run; the line carries
+the communicator's own rank count (ncclCommCount), per-rank stage times and the exchange time.  `--python-twin` runs the
+test harness instead (vgs-svgs-segmentation_amd/dist.py, torch.distributed collectives) -- same protocol, same labels.
 Launched by the driver through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment); when it is NOT
 (plain `python bench.py --gpus N`), this script starts that launcher itself as a child process BEFORE anything touches
 the GPU, passes its output through and exits with its status.
@@ -166,6 +171,43 @@ def dry_run(args, world, rank):
             allrec = [torch.zeros_like(rec) for _ in range(world)]
             dist.all_gather(allrec, rec)
             assert [int(r[0]) for r in allrec] == list(range(world))
+    native_kept = None
+    if (args.native or world > 1) and not args.python_twin:
+        # the native driver's side of the exchange that needs no GPU: libvgs_tiles.so loads, and its boundary union-find
+        # (vgs_tiles_merge_boundary) runs on stand-in records gathered over the process group -- every rank must get the same tables
+        import ctypes as C
+        from importlib import import_module
+        tn = import_module("vgs_svgs_segmentation_amd.tiles_native")
+        L = tn.lib()
+        m = 16
+        mine = np.zeros(2 + 3 * m, dtype=np.int64)
+        mine[0], mine[1] = m, 5 + rank                                   # records, purely local segments
+        mine[2:2 + m] = 1000 * (np.arange(m) // 4) + np.arange(m) % 4     # codes shared by every rank: the segments cross every border
+        mine[2 + m:2 + 2 * m] = 7 * (np.arange(m) // 4) + rank            # four local roots
+        mine[2 + 2 * m:] = 2 + (np.arange(m) // 4)                        # owned voxels of each root
+        allr = [torch.zeros(mine.size, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, torch.from_numpy(mine))
+        else:
+            allr = [torch.from_numpy(mine)]
+        recs = [a.numpy() for a in allr]
+        off = np.arange(world + 1, dtype=np.int64) * m
+        code = np.concatenate([r[2:2 + m] for r in recs]).astype(np.uint64)
+        root = np.concatenate([r[2 + m:2 + 2 * m] for r in recs]).astype(np.int32)
+        cnt = np.concatenate([r[2 + 2 * m:] for r in recs]).astype(np.int32)
+        kl = np.array([r[1] for r in recs], dtype=np.int64)
+        base, uoff = np.zeros(world, np.int64), np.zeros(world + 1, np.int64)
+        uroot, ulabel = np.zeros(world * m, np.int32), np.zeros(world * m, np.int32)
+        kept = C.c_int64(0)
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = L.vgs_tiles_merge_boundary(world, P(off), P(code), P(root), P(cnt), P(kl), 1, P(base), P(uoff), P(uroot), P(ulabel), C.byref(kept))
+        assert st == 0, st
+        native_kept = int(kept.value)
+        assert native_kept == int(kl.sum()) + 4, (native_kept, kl)      # four segments span all ranks
+        if world > 1:
+            ks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(ks, torch.tensor([native_kept], dtype=torch.int64))
+            assert len({int(k.item()) for k in ks}) == 1, ks
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -174,6 +216,8 @@ def dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "segmented points/sec (end-to-end VGS)", "value": None, "unit": "points/s", "n_gpus": world, "ranks": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "backend": "gloo",
+                          "driver": "native (libvgs_tiles.so: boundary merge on stand-in records)" if native_kept is not None else "python twin",
+                          "native_merge_kept": native_kept,
                           "config": {"workload": f"dry run: {tiles[0]}x{tiles[1]} tiles of {xyz.shape[0]} pts", "points_per_gpu": n_per}}))
     if world > 1:
         dist.destroy_process_group()
@@ -188,6 +232,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU only: exercise the launch path and the collectives (gloo), no engine")
+    ap.add_argument("--native", action="store_true", help="tiled runs through libvgs_tiles.so (the default for --gpus > 1; with --gpus 1: a one-rank communicator)")
+    ap.add_argument("--python-twin", action="store_true", help="tiled runs through the Python twin of the native driver (dist.py)")
     args = ap.parse_args()
 
     have_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -233,10 +279,45 @@ def main():
         xyz = v.scenes.tiled_urban_scene(n_per * world, tiles=tiles, tile_index=rank)
         workload = f"URB{n_per * world // 1_000_000}M: {tiles[0]}x{tiles[1]} tiles of {n_per} pts, VGS, voxel 0.1 m, one tile per GPU"
 
-    d_xyz = torch.from_numpy(xyz).to(dev)  # inputs resident in HBM before the timed region
+    native = (args.native or world > 1) and not args.python_twin
+    d_xyz = None
+    if not native:
+        d_xyz = torch.from_numpy(xyz).to(dev)  # inputs resident in HBM before the timed region
     torch.cuda.synchronize(dev)
 
-    if world == 1:
+    tiles_drv, rccl_comm, rccl_ranks = None, None, None
+    if native:
+        from vgs_svgs_segmentation_amd import tiles_native as tn
+        tiles = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(world, (world, 1))
+        pitch = 50.0 * (n_per / 10_000_000) ** 0.5
+        if backend == "nccl":
+            # every rank creates its own communicator for the driver: the id comes from rank 0 through the process group
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(tn.rccl_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(uid, src=0)
+            rccl_comm = tn.RcclComm(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank)
+            rccl_ranks = rccl_comm.count()
+            tiles_drv = tn.NativeTiles(p, tn.COMM_RCCL, rccl_comm.handle, rank, world, tiles, pitch, keep=rccl_comm)
+        else:
+            # test harness (two processes on ONE GPU, which RCCL refuses): the driver's collectives over the caller's gloo group
+            def _ag(send, recv):
+                t = torch.from_numpy(np.array(send, copy=True))
+                outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t)
+                torch.from_numpy(recv).copy_(torch.cat(outs))
+
+            def _bc(buf, root):
+                dist.broadcast(torch.from_numpy(buf), src=root)
+
+            tiles_drv = tn.NativeTiles.with_callbacks(p, rank, world, tiles, pitch, _ag, _bc)
+        tiles_drv.set_points(xyz)       # tile + halo uploaded once: inputs resident in HBM before the timed region
+
+        def step():
+            tiles_drv.run()
+        runner = tiles_drv
+    elif world == 1:
         eng = v.Engine(p)
         eng.set_points_device(d_xyz.data_ptr(), d_xyz.shape[0], 12, keep=d_xyz)
 
@@ -259,7 +340,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     kern_ms, step_ms = [], []
-    stage_acc = {}
+    stage_acc, tiles_acc = {}, {}
     for _ in range(args.steps):
         ts = time.perf_counter()
         step()
@@ -268,6 +349,9 @@ def main():
         kern_ms.append(st["localcut_bulk"])
         for k, val in st.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + val
+        if tiles_drv is not None:
+            for k, val in tiles_drv.times().items():
+                tiles_acc[k] = tiles_acc.get(k, 0.0) + val
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -277,9 +361,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    per_rank = None
+    if tiles_drv is not None:
+        mine = {"rank": rank, "device": local_rank, "points": int(xyz.shape[0]), **tiles_drv.info(),
+                "stage_ms": {k: val / args.steps for k, val in stage_acc.items()}, "tiles_ms": {k: val / args.steps for k, val in tiles_acc.items()}}
+        per_rank = [mine]
+        if dist is not None:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+
     # ---- host -> host (single GPU): pinned staging buffers, uploads and downloads beside the stages -----------------
     h2h = None
-    if world == 1 and not args.no_host_to_host:
+    if world == 1 and not native and not args.no_host_to_host:
         hx = v.pinned_empty(xyz.shape, np.float32)        # the caller's cloud in host memory (a PCD reader's buffer)
         hx[...] = xyz
         hl = [v.pinned_empty((xyz.shape[0],), np.int32) for _ in range(2)]
@@ -381,7 +474,7 @@ def main():
         alg_bytes = int(alg_run * (c["class_a"] / max(c["used"], 1)))
         k_avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        traffic, valu, traffic_src = profiled_traffic(N) if world == 1 else (None, None, None)
+        traffic, valu, traffic_src = profiled_traffic(N) if (world == 1 and not native) else (None, None, None)
         # the kernel works on-chip (VALU issue + LDS latency): its VALU wave instructions at the measured issue peak of a SIMD
         valu_frac = (valu * VALU_NS_PER_WAVE_INSTR * 1e-9 / N_SIMD) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
         sm = sorted(step_ms)
@@ -403,7 +496,7 @@ def main():
             "value_definition": "inputs resident in HBM, labels left in HBM (task contract); host_to_host is the SURVEY 8d metric",
             "config": {"workload": workload, "points_per_gpu": n_per, "voxels": V, "used_voxels": c["used"], "adjacency_entries": E,
                        "segments": c["kept"], "pair_evaluations": c["pairs"],
-                       "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles, shared grid, one all-gather of boundary labels ({backend})"},
+                       "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles, shared grid, one all-gather of boundary labels ({'RCCL, native driver' if rccl_comm is not None else backend})"},
             "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,448,1> (local affinity graph + threshold-merge cut, bulk class)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
@@ -413,11 +506,24 @@ def main():
                          "pair_evals_per_s": c["pairs"] / (k_avg_ms * 1e-3) if k_avg_ms > 0 else 0.0},
             "stage_ms": {k: val / args.steps for k, val in stage_acc.items()},
         }
+        if tiles_drv is not None:
+            out["driver"] = {"kind": "native: libvgs_tiles.so (csrc/tiles.cpp) through ctypes",
+                             "communicator": "RCCL: ncclComm_t created by this process (ncclGetUniqueId / ncclCommInitRank), ncclAllGather / ncclBroadcast inside the driver"
+                                             if rccl_comm is not None else f"caller's callbacks over torch.distributed/{backend} (test harness: ranks share a GPU)",
+                             "rccl_ranks": rccl_ranks, "exchange_ms": max(r["tiles_ms"]["exchange"] for r in per_rank),
+                             "grid_ms": max(r["tiles_ms"]["grid"] for r in per_rank), "per_rank": per_rank}
+            out["ranks"] = rccl_ranks if rccl_ranks is not None else world
+        elif world > 1:
+            out["driver"] = {"kind": "python twin: vgs-svgs-segmentation_amd/dist.py (test harness)"}
         if h2h is not None:
             out["host_to_host"] = h2h
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not native and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(xyz, p, runner.adjacency_counts(), runner.point_voxel())
         print(json.dumps(out))
+    if tiles_drv is not None:
+        tiles_drv.close()
+    if rccl_comm is not None:
+        rccl_comm.destroy()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -28,7 +28,8 @@ typedef enum {
   VGS_E_HIP = 3,          /* HIP runtime error / no device */
   VGS_E_NOMEM = 4,
   VGS_E_UNSUPPORTED = 5,  /* configuration outside the built kernels' limits (message says which) */
-  VGS_E_IO = 6
+  VGS_E_IO = 6,
+  VGS_E_PEER = 7          /* tiled driver (vgs_tiles.h): another rank reported a failure; this rank stopped with it */
 } vgs_status;
 
 /* Parameter surface = Task_File_VGS.txt / Task_File_SVGS.txt (T:25-37, T:108-125). */

@@ -27,7 +27,22 @@ typedef struct vgs_tiles vgs_tiles;
  * process is rank `rank` and uses HIP device p->device.  kind VGS_TILES_COMM_LOCAL: `handle` comes from
  * vgs_tiles_local_group_create -- `world` driver THREADS of one process meet in shared memory (what the tests use to run
  * several ranks on a single GPU, where RCCL refuses two ranks on one device). */
-enum { VGS_TILES_COMM_RCCL = 0, VGS_TILES_COMM_LOCAL = 1 };
+enum { VGS_TILES_COMM_RCCL = 0, VGS_TILES_COMM_LOCAL = 1, VGS_TILES_COMM_CALLBACKS = 2 };
+
+/* kind VGS_TILES_COMM_CALLBACKS: `handle` points to this struct (copied by vgs_tiles_create) -- the caller's own transport over HOST
+ * buffers (MPI, gloo, a test harness that runs two processes on one GPU).  Both return 0 on success.  all_gather: every rank sends
+ * `bytes` bytes, recv holds world * bytes in rank order.  bcast: `bytes` bytes from rank `root` to everyone, in place. */
+typedef struct vgs_tiles_callbacks {
+  void* user;
+  int (*all_gather)(void* user, const void* send, void* recv, uint64_t bytes);
+  int (*bcast)(void* user, void* buf, uint64_t bytes, int root);
+} vgs_tiles_callbacks;
+
+/* Failures.  A rank that fails locally (a stage error, out of memory, an injected fault) still takes part in the next collective and
+ * sends its status as a word of that payload, so that no peer is left waiting inside a collective: the failing rank returns its own
+ * status and message, every other rank returns VGS_E_PEER naming it.  After either, the process should exit non-zero and let the
+ * launcher end the job; a vgs_tiles handle is not usable after a failed run.  An error of the collective itself (RCCL, a callback)
+ * is returned as VGS_E_HIP. */
 
 vgs_status vgs_tiles_local_group_create(int world, void** group);
 void vgs_tiles_local_group_destroy(void* group);
@@ -42,11 +57,22 @@ vgs_status vgs_tiles_create(const vgs_params* p, int comm_kind, void* comm_handl
 void vgs_tiles_destroy(vgs_tiles* t);
 const char* vgs_tiles_last_error_string(const vgs_tiles* t);
 
+/* options.  VGS_TILES_OPT_STRICT_REGION (0 / 1, default 0): points a rank holds outside its own region may come back unlabelled
+ * (their voxels are owned and cut by another rank).  0: vgs_tiles_set_points warns once on stderr; 1: it fails with VGS_E_ARG on that
+ * rank and VGS_E_PEER on the others.  vgs_tiles_get_info reports the count either way. */
+enum { VGS_TILES_OPT_STRICT_REGION = 1 };
+vgs_status vgs_tiles_set_option(vgs_tiles* t, int32_t option, int64_t value);
+
 /* this rank's points (host memory, stride_bytes 12 or 16).  The ranks exchange their border strips (2 * graph_size + voxel_size
  * wide, one all-gather: data loading, not part of a run) and every rank uploads its tile + halo. */
 vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz_host, int64_t n, int32_t stride_bytes);
 /* shared grid, the four stages, the boundary exchange, global labels */
 vgs_status vgs_tiles_run(vgs_tiles* t);
+/* host wall time of the last run's phases on this rank, milliseconds: shared grid (collectives included), the four stages,
+ * boundary records off the GPU, the exchange (ONE all-gather), the boundary union-find, labels applied on the GPU, total */
+enum { VGS_TILES_T_GRID = 0, VGS_TILES_T_STAGES = 1, VGS_TILES_T_RECORDS = 2, VGS_TILES_T_EXCHANGE = 3, VGS_TILES_T_MERGE = 4,
+       VGS_TILES_T_LABELS = 5, VGS_TILES_T_TOTAL = 6, VGS_TILES_T_COUNT = 7 };
+vgs_status vgs_tiles_get_times(vgs_tiles* t, double* ms, int32_t n /* <= VGS_TILES_T_COUNT */);
 /* labels of this rank's own points (global segment ids, -1 = dropped), the number of segments kept over all ranks */
 vgs_status vgs_tiles_get_point_labels(vgs_tiles* t, int32_t* labels /* n */, int64_t* kept_global);
 /* points this rank holds outside its own region (they may come back unlabelled: load by region) */

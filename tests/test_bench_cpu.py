@@ -29,6 +29,18 @@ def test_bench_spawns_its_own_ranks():
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["dry_run"] is True and out["steps"] == 2
 
 
+def test_bench_dry_run_exercises_the_native_driver():
+    """N > 1 defaults to the native tiled driver (libvgs_tiles.so): the dry run loads it, runs its boundary merge on records
+    gathered over the process group and checks that every rank gets the same tables; --python-twin leaves it out."""
+    r = _run(["--gpus", "2", "--dry-run", "--points", "20000", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["driver"].startswith("native") and out["native_merge_kept"] == 5 + 6 + 4
+    r = _run(["--gpus", "2", "--dry-run", "--python-twin", "--points", "20000", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["driver"] == "python twin"
+
+
 def test_bench_four_ranks_2x2():
     r = _run(["--gpus", "4", "--dry-run", "--points", "10000", "--steps", "1", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -39,3 +39,20 @@ def test_two_ranks_on_one_gpu(gpu):
                env_extra={"VGS_BENCH_BACKEND": "gloo", "VGS_BENCH_SINGLE_DEVICE": "1"})
     assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert "2x1" in out["config"]["workload"]
+    # the product's driver ran (libvgs_tiles.so; its collectives through the caller's gloo group, as two ranks share the GPU)
+    d = out["driver"]
+    assert d["kind"].startswith("native") and len(d["per_rank"]) == 2 and d["exchange_ms"] >= 0
+    assert all(r["tiles_ms"]["stages"] > 0 and r["n_boundary_records"] > 0 for r in d["per_rank"])
+    twin = _run(["--gpus", "2", "--points", "300000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--python-twin"],
+                env_extra={"VGS_BENCH_BACKEND": "gloo", "VGS_BENCH_SINGLE_DEVICE": "1"})
+    assert twin["driver"]["kind"].startswith("python twin")
+    assert twin["config"]["voxels"] == out["config"]["voxels"]        # rank 0's tile + halo: the same cloud either way
+
+
+def test_native_driver_with_a_one_rank_rccl_communicator(gpu):
+    """`--gpus 1 --native`: the path every rank of a multi-GPU run takes -- ncclGetUniqueId, ncclCommInitRank, vgs_tiles_create over
+    VGS_TILES_COMM_RCCL, ncclAllGather inside vgs_tiles_run -- with the world a 1-GPU box can form."""
+    out = _run(["--gpus", "1", "--native", "--points", "300000", "--steps", "2", "--warmup", "1"])
+    d = out["driver"]
+    assert d["kind"].startswith("native") and d["rccl_ranks"] == 1 and out["ranks"] == 1 and out["value"] > 0
+    assert d["per_rank"][0]["tiles_ms"]["exchange"] > 0

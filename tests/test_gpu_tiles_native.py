@@ -54,3 +54,79 @@ def test_native_driver_over_rccl_one_rank(gpu, tmp_path):
     eng.run()
     assert w == 1 and kept == eng.counts()["kept"]
     np.testing.assert_array_equal(labels[0], eng.point_labels())
+
+
+# ---- failures must not leave a peer waiting inside a collective: agreed status words --------------------------------
+def _two_rank_threads(gpu, parts, pitch, body, timeout=120.0):
+    """Two ranks of the native driver as threads of this process (VGS_TILES_COMM_LOCAL); body(rank, driver) -> anything.
+    Returns the per-rank results or exceptions; fails if a rank is still waiting after `timeout` seconds."""
+    import threading
+    from vgs_svgs_segmentation_amd import tiles_native as tn
+    grp = tn.LocalGroup(2)
+    out = [None, None]
+
+    def rank_main(r):
+        try:
+            t = tn.NativeTiles(gpu.default_params(2, voxel_size=0.1), tn.COMM_LOCAL, grp.handle, r, 2, (2, 1), pitch)
+            try:
+                out[r] = body(r, t, parts[r])
+            finally:
+                t.close()
+        except Exception as ex:  # noqa: BLE001
+            out[r] = ex
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    hung = [r for r, t in enumerate(th) if t.is_alive()]
+    if hung:
+        grp.abort()
+        pytest.fail(f"rank(s) {hung} still inside the driver after {timeout} s: a peer's failure left them waiting")
+    grp.close()
+    return out
+
+
+@pytest.mark.parametrize("phase", ["points", "grid", "stages"])
+def test_a_failing_rank_takes_its_peers_out_with_it(gpu, monkeypatch, phase):
+    """Rank 1 fails locally (injected: VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT) before the collective of the named phase.  It still
+    takes part in that collective with its status in the payload; it returns its own error, rank 0 returns VGS_E_PEER naming it,
+    and nobody waits."""
+    monkeypatch.setenv("VGS_TILES_FAIL_RANK", "1")
+    monkeypatch.setenv("VGS_TILES_FAIL_AT", phase)
+    n_per = 60_000
+    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
+    parts = [gpu.scenes.tiled_urban_scene(n_per * 2, tiles=(2, 1), tile_index=r) for r in range(2)]
+
+    def body(r, t, xyz):
+        t.set_points(xyz)
+        t.run()
+        return "finished"
+    out = _two_rank_threads(gpu, parts, pitch, body)
+    assert isinstance(out[1], gpu.VgsError) and "VGS_E_STATE" in str(out[1]) and "failure requested" in str(out[1]), out[1]
+    assert isinstance(out[0], gpu.VgsError) and "VGS_E_PEER" in str(out[0]) and "rank 1" in str(out[0]), out[0]
+
+
+def test_strict_region_refuses_points_outside_the_rank(gpu):
+    """VGS_TILES_OPT_STRICT_REGION: a rank that holds points beyond its region makes every rank refuse the cloud (by default it is
+    a warning on stderr and a count in vgs_tiles_get_info)."""
+    from vgs_svgs_segmentation_amd import tiles_native as tn
+    n_per = 60_000
+    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
+    parts = [gpu.scenes.tiled_urban_scene(n_per * 2, tiles=(2, 1), tile_index=r) for r in range(2)]
+    parts[1] = np.concatenate([parts[1], parts[0][:100]])        # rank 1 also holds a few of rank 0's points
+
+    def strict(r, t, xyz):
+        t.set_option(tn.OPT_STRICT_REGION, 1)
+        t.set_points(xyz)
+        return "accepted"
+    out = _two_rank_threads(gpu, parts, pitch, strict)
+    assert isinstance(out[1], gpu.VgsError) and "VGS_E_ARG" in str(out[1]) and "outside" in str(out[1]), out[1]
+    assert isinstance(out[0], gpu.VgsError) and "VGS_E_PEER" in str(out[0]), out[0]
+
+    def lenient(r, t, xyz):
+        t.set_points(xyz)
+        t.run()
+        return t.info()["n_outside"], t.times()
+    out = _two_rank_threads(gpu, parts, pitch, lenient)
+    assert out[1][0] >= 100 and out[0][1]["total"] > 0 and out[0][1]["exchange"] >= 0, out

@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("VGS_LIB", "libvgs_hip.so")))
 CSRC = os.path.join(_HERE, "csrc")
 
-VGS_OK, VGS_E_ARG, VGS_E_STATE, VGS_E_HIP, VGS_E_NOMEM, VGS_E_UNSUPPORTED, VGS_E_IO = range(7)
-STATUS_NAMES = ["VGS_OK", "VGS_E_ARG", "VGS_E_STATE", "VGS_E_HIP", "VGS_E_NOMEM", "VGS_E_UNSUPPORTED", "VGS_E_IO"]
+VGS_OK, VGS_E_ARG, VGS_E_STATE, VGS_E_HIP, VGS_E_NOMEM, VGS_E_UNSUPPORTED, VGS_E_IO, VGS_E_PEER = range(8)
+STATUS_NAMES = ["VGS_OK", "VGS_E_ARG", "VGS_E_STATE", "VGS_E_HIP", "VGS_E_NOMEM", "VGS_E_UNSUPPORTED", "VGS_E_IO", "VGS_E_PEER"]
 
 # indices of vgs_get_counts / vgs_get_stage_times (include/vgs.h)
 N_POINTS, N_FINITE, N_VOXELS, N_USED, N_ADJ, N_CLUSTERS, N_KEPT, N_PAIRS, N_DEPTH, N_ISOLATED, N_REATTACHED, N_SUPERVOXELS = range(12)

@@ -6,8 +6,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -106,6 +109,20 @@ struct RcclComm : Comm {
   }
 };
 
+// the caller's own transport (MPI, gloo, a test harness): two C callbacks over host buffers
+struct CallbackComm : Comm {
+  vgs_tiles_callbacks cb;
+  CallbackComm(const vgs_tiles_callbacks& c, int r, int w) : cb(c) { rank = r; world = w; }
+  bool all_gather(const void* send, void* recv, size_t bytes) override {
+    if (cb.all_gather(cb.user, send, recv, (uint64_t)bytes) != 0) { err = "caller's all_gather callback failed"; return false; }
+    return true;
+  }
+  bool bcast(void* buf, size_t bytes, int root) override {
+    if (cb.bcast(cb.user, buf, (uint64_t)bytes, root) != 0) { err = "caller's bcast callback failed"; return false; }
+    return true;
+  }
+};
+
 // arrays of different lengths: one size exchange + one padded payload exchange
 template <typename T>
 bool all_gather_varlen(Comm& c, const std::vector<T>& mine, std::vector<std::vector<T>>& out) {
@@ -190,12 +207,29 @@ struct vgs_tiles {
   double lo[2] = {0, 0}, hi[2] = {0, 0};
   std::vector<float> local;   // tile + halo, packed xyz
   int64_t own_first = 0, n_own = 0, n_outside = 0, n_records = 0, kept = 0;
+  double times[VGS_TILES_T_COUNT] = {0};   // last run, milliseconds of host wall time per phase (vgs_tiles_get_times)
+  int strict_region = 0;      // VGS_TILES_OPT_STRICT_REGION
+  int fail_phase = 0;         // tests (VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT): 1 grid, 2 stages, 3 points
+  bool warned_outside = false;
   std::string err;
 };
 
 static vgs_status tfail(vgs_tiles* t, vgs_status s, const std::string& msg) { t->err = msg; return s; }
 #define TCTX(call) do { vgs_status s_ = (call); if (s_ != VGS_OK) return tfail(t, s_, std::string(#call) + ": " + vgs_last_error_string(t->ctx)); } while (0)
 #define TCOMM(call) do { if (!(call)) return tfail(t, VGS_E_HIP, std::string("collective failed: ") + t->comm->err); } while (0)
+// A LOCAL failure between two collectives must not make this rank leave while its peers are already inside the next collective
+// (they would wait for ever: ADVICE r3).  So a failing step only records its status (`carry`), the rank still takes part in the
+// next collective with that status as a word of the payload, and every rank sees it there and returns: the failing rank its own
+// error, the others VGS_E_PEER naming the rank.  The caller's process then exits non-zero and the launcher ends the job.
+#define TCARRY(call) do { if (carry == VGS_OK) { vgs_status s_ = (call); if (s_ != VGS_OK) { carry = s_; t->err = std::string(#call) + ": " + vgs_last_error_string(t->ctx); } } } while (0)
+
+static vgs_status agreed(vgs_tiles* t, vgs_status mine, int first_bad_rank, const char* phase) {
+  if (mine != VGS_OK) return mine;   // t->err already says what failed here
+  if (first_bad_rank >= 0) return tfail(t, VGS_E_PEER, std::string("rank ") + std::to_string(first_bad_rank) + " failed in the " + phase + " phase; this rank stops with it");
+  return VGS_OK;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" {
 
@@ -217,7 +251,17 @@ vgs_status vgs_tiles_create(const vgs_params* p, int comm_kind, void* comm_handl
   t->tiles_x = tiles_x; t->tiles_y = tiles_y; t->pitch = pitch; t->cx = center_x; t->cy = center_y;
   if (comm_kind == VGS_TILES_COMM_LOCAL) t->comm = new LocalComm((LocalGroup*)comm_handle, rank);
   else if (comm_kind == VGS_TILES_COMM_RCCL) t->comm = new RcclComm((ncclComm_t)comm_handle, rank, world, p->device);
-  else { delete t; return VGS_E_ARG; }
+  else if (comm_kind == VGS_TILES_COMM_CALLBACKS) {
+    const vgs_tiles_callbacks* cb = (const vgs_tiles_callbacks*)comm_handle;
+    if (!cb->all_gather || !cb->bcast) { delete t; return VGS_E_ARG; }
+    t->comm = new CallbackComm(*cb, rank, world);
+  } else { delete t; return VGS_E_ARG; }
+  {
+    // failure injection for the tests of the agreed-status protocol; read once, here
+    const char* fr = std::getenv("VGS_TILES_FAIL_RANK");
+    const char* fa = std::getenv("VGS_TILES_FAIL_AT");
+    if (fr && fa && std::atoi(fr) == rank) t->fail_phase = !std::strcmp(fa, "grid") ? 1 : !std::strcmp(fa, "stages") ? 2 : !std::strcmp(fa, "points") ? 3 : 0;
+  }
   vgs_status s = vgs_create(p, &t->ctx);
   if (s != VGS_OK) { delete t->comm; delete t; return s; }
   *out = t;
@@ -233,6 +277,18 @@ void vgs_tiles_destroy(vgs_tiles* t) {
 
 const char* vgs_tiles_last_error_string(const vgs_tiles* t) { return t ? t->err.c_str() : "null handle"; }
 vgs_ctx* vgs_tiles_context(vgs_tiles* t) { return t ? t->ctx : nullptr; }
+
+vgs_status vgs_tiles_set_option(vgs_tiles* t, int32_t option, int64_t value) {
+  if (!t) return VGS_E_ARG;
+  if (option == VGS_TILES_OPT_STRICT_REGION) { t->strict_region = value != 0; return VGS_OK; }
+  return tfail(t, VGS_E_ARG, "unknown option");
+}
+
+vgs_status vgs_tiles_get_times(vgs_tiles* t, double* ms, int32_t n) {
+  if (!t || !ms || n < 0 || n > VGS_TILES_T_COUNT) return VGS_E_ARG;
+  for (int i = 0; i < n; ++i) ms[i] = t->times[i];
+  return VGS_OK;
+}
 
 vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32_t stride_bytes) {
   if (!t || (!xyz && n > 0) || n < 0 || (stride_bytes != 12 && stride_bytes != 16)) return VGS_E_ARG;
@@ -261,6 +317,30 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
     if (x < t->lo[0] || x >= t->hi[0] || y < t->lo[1] || y >= t->hi[1]) ++t->n_outside;
     if (x < t->lo[0] + h || x >= t->hi[0] - h || y < t->lo[1] + h || y >= t->hi[1] - h) { strip.push_back(xyz[k * sf]); strip.push_back(xyz[k * sf + 1]); strip.push_back(xyz[k * sf + 2]); }
   }
+  // Points a rank holds beyond its own region may come back unlabelled (their voxels are owned, and cut, elsewhere; found by
+  // tools/fuzz_tiles.py): a caller with an arbitrary partition is told so once -- or, with VGS_TILES_OPT_STRICT_REGION, every
+  // rank refuses the cloud (the count travels in the strips' size exchange below, so the ranks agree on it)
+  if (t->n_outside > 0 && !t->strict_region && !t->warned_outside) {
+    t->warned_outside = true;
+    std::fprintf(stderr, "[vgs_tiles] rank %d: %lld of %lld points lie outside this rank's region; they may come back unlabelled (-1). "
+                         "Load points by region, or set VGS_TILES_OPT_STRICT_REGION to make this an error.\n", c.rank, (long long)t->n_outside, (long long)n);
+  }
+  vgs_status carry = VGS_OK;
+  if (t->fail_phase == 3) { carry = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=points"; }
+  if (t->strict_region && t->n_outside > 0 && carry == VGS_OK) {
+    carry = VGS_E_ARG;
+    t->err = std::to_string(t->n_outside) + " points lie outside this rank's region (VGS_TILES_OPT_STRICT_REGION)";
+  }
+  {
+    // agreed status before the payload: one word per rank
+    int64_t st = (int64_t)carry;
+    std::vector<int64_t> all((size_t)c.world);
+    TCOMM(c.all_gather(&st, all.data(), sizeof(int64_t)));
+    int bad = -1;
+    for (int r = 0; r < c.world && bad < 0; ++r) if (all[(size_t)r] != 0) bad = r;
+    vgs_status a = agreed(t, carry, bad, "point loading");
+    if (a != VGS_OK) return a;
+  }
   std::vector<std::vector<float>> strips;
   TCOMM(all_gather_varlen(c, strip, strips));
   // the local cloud in RANK ORDER: strips of lower ranks, own points, strips of higher ranks -- the order in which one process
@@ -278,6 +358,8 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
   for (int64_t k = 0; k < n; ++k) { t->local.push_back(xyz[k * sf]); t->local.push_back(xyz[k * sf + 1]); t->local.push_back(xyz[k * sf + 2]); }
   for (int r = c.rank + 1; r < c.world; ++r) take_strip(r);
   t->n_own = n;
+  // failures from here on are local and no collective follows inside this call: the next one (the grid's) is in vgs_tiles_run,
+  // which this rank's caller does not reach
   TCTX(vgs_set_points(t->ctx, t->local.data(), (int64_t)(t->local.size() / 3), 12));
   TCTX(vgs_set_owned_region(t->ctx, t->lo, t->hi));
   TCTX(vgs_set_own_point_range(t->ctx, t->own_first, t->n_own));
@@ -288,74 +370,104 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
 // of the clouds' bounding boxes lets every rank replay the growth on the host wherever the box alone decides it
 // (vgs_grid_advance_bbox); only a rank whose cloud leaves the step open scans its points on the GPU and broadcasts the state --
 // except rank 0, whose box starts at its first point: it scans first and its state travels with its bounding box.
-static vgs_status chain_grid(vgs_tiles* t) {
+// `carry`: see TCARRY -- a local failure travels as a status word of the next collective.
+static vgs_status chain_grid(vgs_tiles* t, vgs_status& carry) {
   Comm& c = *t->comm;
   float bb[6] = {0, 0, 0, 0, 0, 0};
   int64_t nf = 0;
-  TCTX(vgs_points_bbox(t->ctx, bb, &nf));
+  if (t->fail_phase == 1) { carry = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=grid"; }
+  TCARRY(vgs_points_bbox(t->ctx, bb, &nf));
   auto pack = [](const vgs_grid_state& g, double* v) { for (int a = 0; a < 3; ++a) { v[a] = g.min[a]; v[3 + a] = (double)g.shift[a]; } v[6] = g.depth; v[7] = g.defined; };
   auto unpack = [](vgs_grid_state& g, const double* v) { for (int a = 0; a < 3; ++a) { g.min[a] = v[a]; g.shift[a] = (uint64_t)v[3 + a]; } g.depth = (int32_t)v[6]; g.defined = (int32_t)v[7]; };
   vgs_grid_state g0;
   vgs_grid_state_init(&g0);
-  if (c.rank == 0 && nf > 0) TCTX(vgs_grid_advance(t->ctx, &g0));
-  double mine[15];
+  if (c.rank == 0 && nf > 0) TCARRY(vgs_grid_advance(t->ctx, &g0));
+  double mine[16];
   for (int a = 0; a < 6; ++a) mine[a] = (double)bb[a];
   mine[6] = (double)nf;
   pack(g0, mine + 7);
-  std::vector<double> all((size_t)15 * c.world);
+  mine[15] = (double)carry;   // status word
+  std::vector<double> all((size_t)16 * c.world);
   TCOMM(c.all_gather(mine, all.data(), sizeof(mine)));
+  {
+    int bad = -1;
+    for (int r = 0; r < c.world && bad < 0; ++r) if (all[(size_t)16 * r + 15] != 0.0) bad = r;
+    vgs_status a = agreed(t, carry, bad, "grid");
+    if (a != VGS_OK) return a;
+  }
   vgs_grid_state g;
   vgs_grid_state_init(&g);
   for (int r = 0; r < c.world; ++r) {
-    const double* v = all.data() + (size_t)15 * r;
+    const double* v = all.data() + (size_t)16 * r;
     if (v[6] == 0) continue;   // no finite point: the cloud changes nothing
     if (r == 0) { unpack(g, v + 7); continue; }
     float box[6];
     for (int a = 0; a < 6; ++a) box[a] = (float)v[a];   // float values, exactly as gathered
     int32_t need = 0;
-    vgs_status s = vgs_grid_advance_bbox(&g, (double)t->P.voxel_size, box, &need);
+    vgs_status s = vgs_grid_advance_bbox(&g, (double)t->P.voxel_size, box, &need);   // host arithmetic on gathered values: fails on every rank alike
     if (s != VGS_OK) return tfail(t, s, "vgs_grid_advance_bbox");
     if (!need) continue;
-    double buf[8] = {0};
-    if (c.rank == r) { TCTX(vgs_grid_advance(t->ctx, &g)); pack(g, buf); }
+    double buf[9] = {0};
+    if (c.rank == r) { TCARRY(vgs_grid_advance(t->ctx, &g)); pack(g, buf); buf[8] = (double)carry; }
     TCOMM(c.bcast(buf, sizeof(buf), r));
+    if (buf[8] != 0.0) return agreed(t, carry, r, "grid");
     unpack(g, buf);
   }
-  TCTX(vgs_set_grid(t->ctx, &g));
+  TCARRY(vgs_set_grid(t->ctx, &g));   // a failure here travels with the boundary records
   return VGS_OK;
 }
 
 vgs_status vgs_tiles_run(vgs_tiles* t) {
   if (!t) return VGS_E_ARG;
   Comm& c = *t->comm;
-  vgs_status s = chain_grid(t);
+  vgs_status carry = VGS_OK;
+  double t0 = now_ms();
+  vgs_status s = chain_grid(t, carry);
   if (s != VGS_OK) return s;
-  TCTX(vgs_voxelize(t->ctx)); TCTX(vgs_features(t->ctx)); TCTX(vgs_adjacency(t->ctx)); TCTX(vgs_segment(t->ctx));
+  double t1 = now_ms();
+  t->times[VGS_TILES_T_GRID] = t1 - t0;
+  if (t->fail_phase == 2 && carry == VGS_OK) { carry = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=stages"; }
+  TCARRY(vgs_voxelize(t->ctx)); TCARRY(vgs_features(t->ctx)); TCARRY(vgs_adjacency(t->ctx)); TCARRY(vgs_segment(t->ctx));
+  double t2 = now_ms();
+  t->times[VGS_TILES_T_STAGES] = t2 - t1;
   // only the border leaves the GPU: unique boundary voxels (code, local root, owned voxels of that root) and the number of
   // components that are local to this tile
   int64_t n = 0, nkl = 0;
-  TCTX(vgs_get_boundary_roots(t->ctx, &n, nullptr, nullptr, nullptr, &nkl));
+  TCARRY(vgs_get_boundary_roots(t->ctx, &n, nullptr, nullptr, nullptr, &nkl));
+  if (carry != VGS_OK) { n = 0; nkl = 0; }
   RankRecords mine;
   mine.code.resize((size_t)std::max<int64_t>(n, 1)); mine.root.resize(mine.code.size()); mine.cnt.resize(mine.code.size());
-  if (n > 0) TCTX(vgs_get_boundary_roots(t->ctx, &n, mine.code.data(), mine.root.data(), mine.cnt.data(), &nkl));
+  if (n > 0) TCARRY(vgs_get_boundary_roots(t->ctx, &n, mine.code.data(), mine.root.data(), mine.cnt.data(), &nkl));
+  if (carry != VGS_OK) { n = 0; nkl = 0; }
   mine.code.resize((size_t)n); mine.root.resize((size_t)n); mine.cnt.resize((size_t)n);
   t->n_records = n;
-  // the one data-path exchange: header (record count, local segment count) + records, 3 words each
-  std::vector<int64_t> payload((size_t)(2 + 3 * n));
-  payload[0] = n; payload[1] = nkl;
-  for (int64_t k = 0; k < n; ++k) { payload[(size_t)(2 + k)] = (int64_t)mine.code[(size_t)k]; payload[(size_t)(2 + n + k)] = mine.root[(size_t)k]; payload[(size_t)(2 + 2 * n + k)] = mine.cnt[(size_t)k]; }
+  double t3 = now_ms();
+  t->times[VGS_TILES_T_RECORDS] = t3 - t2;
+  // the one data-path exchange: header (record count, local segment count, this rank's status) + records, 3 words each
+  constexpr size_t HDR = 3;
+  std::vector<int64_t> payload(HDR + 3 * (size_t)n);
+  payload[0] = n; payload[1] = nkl; payload[2] = (int64_t)carry;
+  for (int64_t k = 0; k < n; ++k) { payload[HDR + (size_t)k] = (int64_t)mine.code[(size_t)k]; payload[HDR + (size_t)(n + k)] = mine.root[(size_t)k]; payload[HDR + (size_t)(2 * n + k)] = mine.cnt[(size_t)k]; }
   // one collective of a fixed size when every rank's payload fits; the gathered headers tell every rank alike when not
-  const size_t cap = 3 * 8192 + 2;
+  const size_t cap = 3 * 8192 + HDR;
   std::vector<std::vector<int64_t>> gathered((size_t)c.world);
   {
     std::vector<int64_t> fixed(cap, 0), all(cap * (size_t)c.world);
     std::copy(payload.begin(), payload.begin() + (ptrdiff_t)std::min(payload.size(), cap), fixed.begin());
     TCOMM(c.all_gather(fixed.data(), all.data(), cap * sizeof(int64_t)));
+    {
+      int bad = -1;
+      for (int r = 0; r < c.world && bad < 0; ++r) if (all[cap * (size_t)r + 2] != 0) bad = r;
+      vgs_status a = agreed(t, carry, bad, "stages");
+      if (a != VGS_OK) return a;
+    }
     bool fits = true;
-    for (int r = 0; r < c.world; ++r) fits = fits && (size_t)(2 + 3 * all[cap * (size_t)r]) <= cap;
-    if (fits) for (int r = 0; r < c.world; ++r) gathered[(size_t)r].assign(all.begin() + (ptrdiff_t)(cap * (size_t)r), all.begin() + (ptrdiff_t)(cap * (size_t)r + 2 + 3 * (size_t)all[cap * (size_t)r]));
+    for (int r = 0; r < c.world; ++r) fits = fits && (HDR + 3 * (size_t)all[cap * (size_t)r]) <= cap;
+    if (fits) for (int r = 0; r < c.world; ++r) gathered[(size_t)r].assign(all.begin() + (ptrdiff_t)(cap * (size_t)r), all.begin() + (ptrdiff_t)(cap * (size_t)r + HDR + 3 * (size_t)all[cap * (size_t)r]));
     else TCOMM(all_gather_varlen(c, payload, gathered));
   }
+  double t4 = now_ms();
+  t->times[VGS_TILES_T_EXCHANGE] = t4 - t3;
   std::vector<RankRecords> rec((size_t)c.world);
   std::vector<int64_t> kept_local((size_t)c.world);
   for (int r = 0; r < c.world; ++r) {
@@ -364,15 +476,22 @@ vgs_status vgs_tiles_run(vgs_tiles* t) {
     kept_local[(size_t)r] = gr[1];
     RankRecords& R = rec[(size_t)r];
     R.code.resize((size_t)m); R.root.resize((size_t)m); R.cnt.resize((size_t)m);
-    for (int64_t k = 0; k < m; ++k) { R.code[(size_t)k] = (uint64_t)gr[(size_t)(2 + k)]; R.root[(size_t)k] = (int32_t)gr[(size_t)(2 + m + k)]; R.cnt[(size_t)k] = (int32_t)gr[(size_t)(2 + 2 * m + k)]; }
+    for (int64_t k = 0; k < m; ++k) { R.code[(size_t)k] = (uint64_t)gr[HDR + (size_t)k]; R.root[(size_t)k] = (int32_t)gr[HDR + (size_t)(m + k)]; R.cnt[(size_t)k] = (int32_t)gr[HDR + (size_t)(2 * m + k)]; }
   }
   std::vector<int64_t> base;
   std::vector<std::vector<int32_t>> uroot, ulabel;
   merge_boundary_compact(rec, kept_local, t->P.voxels_min, base, uroot, ulabel, t->kept);
+  double t5 = now_ms();
+  t->times[VGS_TILES_T_MERGE] = t5 - t4;
   std::vector<int32_t>& br = uroot[(size_t)c.rank];
   std::vector<int32_t>& bl = ulabel[(size_t)c.rank];
   int32_t dummy = 0;
+  // (a failure here is local and the run's last collective is behind us: this rank returns it, the caller's process exits
+  // non-zero, and the peers -- whose results are complete -- meet that at their next collective or at the launcher)
   TCTX(vgs_apply_tile_labels(t->ctx, (int32_t)base[(size_t)c.rank], br.empty() ? &dummy : br.data(), bl.empty() ? &dummy : bl.data(), (int64_t)br.size()));
+  double t6 = now_ms();
+  t->times[VGS_TILES_T_LABELS] = t6 - t5;
+  t->times[VGS_TILES_T_TOTAL] = t6 - t0;
   return VGS_OK;
 }
 
