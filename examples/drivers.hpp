@@ -17,7 +17,7 @@ struct DriverSummary { long points = 0, voxels = 0, supervoxels = 0, clusters = 
 // <prefix>_voxels.ply, <prefix>_clustered_voxels.ply, <prefix>_normals.ply
 inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>& input_vector,
                            std::vector<std::vector<int>>& clusters_points_idx, DriverSummary* sum = nullptr,
-                           const std::string& debug_prefix = std::string()) {
+                           const std::string& debug_prefix = std::string(), double ctor_resolution = 0.0) {
   float voxel_size = 0.15f, graph_size = 0.5f, sig_p = 0.2f, sig_n = 0.2f, sig_o = 0.2f, sig_e = 0.2f, sig_c = 0.2f, sig_w = 2.0f,
         cut_thred = 0.3f;
   int points_min = 10, adjacency_min = 3, voxels_min = 3;
@@ -30,7 +30,8 @@ inline int segmentationVGS(PCXYZPtr input_cloud, const std::vector<std::string>&
   double min_x = 0, min_y = 0, min_z = 0, max_x = 0, max_y = 0, max_z = 0;
 
   // Voxelization (test:51-57)
-  pcl::VoxelBasedSegmentation<pcl::PointXYZ> voxel_structure(voxel_size);
+  // (ctor_resolution: tests only -- an octree resolution that differs from the one setVoxelSize is given afterwards)
+  pcl::VoxelBasedSegmentation<pcl::PointXYZ> voxel_structure(ctor_resolution > 0.0 ? ctor_resolution : (double)voxel_size);
   voxel_structure.setInputCloud(input_cloud);
   voxel_structure.getCloudPointNum(input_cloud);
   voxel_structure.addPointsFromInputCloud();

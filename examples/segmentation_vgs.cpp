@@ -1,6 +1,7 @@
 // examples/segmentation_vgs.cpp -- runs the reference's driver segmentationVGS (examples/drivers.hpp, reference
 // `test`:9-86) on a raw float32 xyz file.
-//   usage: segmentation_vgs <points.f32> [Task_File_VGS.txt]
+//   usage: segmentation_vgs <points.f32> [Task_File_VGS.txt] [--ctor-res R]
+// --ctor-res: construct the class with resolution R and let setVoxelSize set the task file's afterwards (tests)
 // Prints "<points> <voxels> <all clusters> <kept clusters> <labelled points>".
 #include <cstdio>
 #include <cstdlib>
@@ -27,11 +28,15 @@ int main(int argc, char** argv) {
   cloud->points.resize(raw.size() / 3);
   for (size_t i = 0; i < cloud->points.size(); ++i) cloud->points[i] = pcl::PointXYZ(raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]);
   vector<string> task;
-  if (argc > 2) task = inputTaskTxtFile(argv[2]);
+  double ctor_res = 0.0;
+  for (int a = 2; a < argc; ++a) {
+    if (string(argv[a]) == "--ctor-res" && a + 1 < argc) ctor_res = std::atof(argv[++a]);
+    else task = inputTaskTxtFile(argv[a]);
+  }
   DriverSummary sum;
   vector<vector<int>> clusters;
   try {
-    segmentationVGS(cloud, task, clusters, &sum);
+    segmentationVGS(cloud, task, clusters, &sum, string(), ctor_res);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

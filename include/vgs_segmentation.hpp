@@ -115,6 +115,7 @@ class VoxelBasedSegmentation {
     if (!cloud_) throw std::runtime_error("addPointsFromInputCloud before setInputCloud");
     chk(vgs_set_points(ctx(), &cloud_->points[0].x, (int64_t)cloud_->points.size(), (int32_t)sizeof(PointT)), "vgs_set_points");
     chk(vgs_voxelize(ctx()), "vgs_voxelize");
+    voxelized_res_ = p_.voxel_size;
     adj_off_.clear(); adj_idx_.clear();
   }
   void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {
@@ -124,7 +125,7 @@ class VoxelBasedSegmentation {
   }
 
   int getCloudPointNum(const PCXYZPtr& input_data) { cloud_ = input_data; return (int)input_data->points.size(); }  // VS:94
-  int getVoxelNum() { return (int)count(VGS_N_VOXELS); }                                  // VS:104
+  int getVoxelNum() { ensure_voxels(); return (int)count(VGS_N_VOXELS); }                 // VS:104
   int getClusterNum() { return (int)count(VGS_N_CLUSTERS); }                              // VS:111
   std::vector<std::vector<int>> getClusterIdx() {                                        // VS:117
     std::vector<std::vector<int>> out;
@@ -146,7 +147,10 @@ class VoxelBasedSegmentation {
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
   }
   void setBoundingBox(double, double, double, double, double, double) {}                 // VS:133 (the engine keeps the octree's box)
-  void setVoxelCenters() {}                                                              // VS:146 (done by addPointsFromInputCloud)
+  // VS:146.  The voxel table is built by addPointsFromInputCloud; a setVoxelSize() with another resolution in between (the reference
+  // only stores the value, VS:124-131, and would go on with an octree of the old size) rolls the context back to its points, so the
+  // table is rebuilt here at the new size -- as the Python mirror does (api.py) -- instead of failing later with VGS_E_STATE.
+  void setVoxelCenters() { ensure_voxels(); }
   std::vector<PointXYZ> getVoxelCenters() {                                              // VS:191
     const int64_t v = count(VGS_N_VOXELS);
     std::vector<float> c((size_t)v * 3 + 1);
@@ -155,7 +159,7 @@ class VoxelBasedSegmentation {
     for (int64_t i = 0; i < v; ++i) out[(size_t)i] = PointXYZ(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
     return out;
   }
-  void calcualteVoxelCloudAttributes(const PCXYZPtr&) { chk(vgs_features(ctx()), "vgs_features"); }  // VS:290 (sic)
+  void calcualteVoxelCloudAttributes(const PCXYZPtr&) { ensure_voxels(); chk(vgs_features(ctx()), "vgs_features"); }  // VS:290 (sic)
   void findAllVoxelAdjacency(float graph_size) {                                         // VS:223
     p_.graph_size = graph_size;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
@@ -209,6 +213,14 @@ class VoxelBasedSegmentation {
   std::unique_ptr<vgs_ctx, vgs_detail::CtxDeleter> ctx_;
   PCXYZPtr cloud_;
   bool drawn_ = false;
+  float voxelized_res_ = -1.0f;    // resolution the voxel table was built with (addPointsFromInputCloud / ensure_voxels)
+  void ensure_voxels() {
+    if (voxelized_res_ >= 0.0f && voxelized_res_ != p_.voxel_size) {   // setVoxelSize changed the resolution: the context is back at its points
+      chk(vgs_voxelize(ctx()), "vgs_voxelize");
+      voxelized_res_ = p_.voxel_size;
+      adj_off_.clear(); adj_idx_.clear();
+    }
+  }
   std::vector<int64_t> adj_off_;   // getOneVoxelAdjacency's copy of the lists
   std::vector<int32_t> adj_idx_;
 };

@@ -32,6 +32,19 @@ def test_cpp_driver_matches_python_engine(gpu, tmp_path):
     assert labelled == int((eng.point_labels() >= 0).sum())
 
 
+@pytest.mark.gpu
+def test_set_voxel_size_after_the_octree_was_built(gpu, tmp_path):
+    """setVoxelSize() with a resolution other than the constructor's (the reference only stores it, voxel_segmentation.h:124-131):
+    the mirror rebuilds the voxel table at the new size in setVoxelCenters() -- round 3 threw VGS_E_STATE in the next call."""
+    subprocess.check_call(["make", "-C", CSRC, "-s", "example"])
+    xyz = gpu.scenes.town_scene(40_000)
+    f = tmp_path / "pts.f32"
+    xyz.tofile(f)
+    want = subprocess.check_output([EXE, str(f)], text=True).split()
+    got = subprocess.check_output([EXE, str(f), "--ctor-res", "0.4"], text=True).split()
+    assert got == want
+
+
 RUN = os.path.join(ROOT, "examples", "vgs_run")
 
 

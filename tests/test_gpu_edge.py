@@ -130,6 +130,27 @@ def test_limits_are_reported_not_silently_wrong(gpu):
         eng2.run()
 
 
+def test_tables_that_cannot_fit_are_refused_with_an_estimate(gpu):
+    """The adjacency / connect tables are dense (used voxels x lattice offsets of the ball x 12 B): 6.2 M used voxels seen through a
+    ball of ten voxels would need 310 GB.  The adjacency stage says so -- VGS_E_NOMEM with the numbers and what to change -- before
+    it allocates anything, and the context stays usable."""
+    side = 2500
+    ij = np.stack(np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32), indexing="ij"), -1).reshape(-1, 2)
+    cell = np.concatenate([ij * 0.05 + 0.0125, ij * 0.05 + 0.0375])                  # two points in every voxel of a 125 m sheet
+    xyz = np.concatenate([cell, np.full((cell.shape[0], 1), 1.02, np.float32)], axis=1).astype(np.float32)
+    eng = gpu.Engine(gpu.default_params(2, voxel_size=0.05, graph_size=0.5, points_min=1))
+    eng.set_points(xyz)
+    eng.voxelize(); eng.features()
+    assert eng.counts()["used"] > 6_000_000
+    with pytest.raises(gpu.VgsError) as e:
+        eng.adjacency()
+    assert "VGS_E_NOMEM" in str(e.value) and "tables need" in str(e.value) and "GB" in str(e.value), str(e.value)
+    p2 = gpu.default_params(2, voxel_size=0.05, graph_size=0.15, points_min=1)       # a ball of three voxels fits
+    eng.set_params(p2)
+    eng.run()
+    assert eng.counts()["kept"] >= 1
+
+
 def test_neighbourhoods_above_2048_voxels(gpu, oracle):
     """A solid block seen through a ball of eight voxels: 275 voxels have more than 2048 used neighbours.  The reference sizes its
     matrix to any n (voxel_segmentation.h:1815-1818, 1913-1933); until round 3 one such voxel ended the run with VGS_E_UNSUPPORTED.

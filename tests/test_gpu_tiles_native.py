@@ -114,7 +114,8 @@ def test_strict_region_refuses_points_outside_the_rank(gpu):
     n_per = 60_000
     pitch = 50.0 * np.sqrt(n_per / 10_000_000)
     parts = [gpu.scenes.tiled_urban_scene(n_per * 2, tiles=(2, 1), tile_index=r) for r in range(2)]
-    parts[1] = np.concatenate([parts[1], parts[0][:100]])        # rank 1 also holds a few of rank 0's points
+    parts = [parts[0][parts[0][:, 0] < 0.0], parts[1][parts[1][:, 0] >= 0.0]]   # loaded by region (2 x 1 tiles about x = 0) ...
+    parts[1] = np.concatenate([parts[1], parts[0][:100]])        # ... except that rank 1 also holds a few of rank 0's points
 
     def strict(r, t, xyz):
         t.set_option(tn.OPT_STRICT_REGION, 1)
@@ -129,4 +130,4 @@ def test_strict_region_refuses_points_outside_the_rank(gpu):
         t.run()
         return t.info()["n_outside"], t.times()
     out = _two_rank_threads(gpu, parts, pitch, lenient)
-    assert out[1][0] >= 100 and out[0][1]["total"] > 0 and out[0][1]["exchange"] >= 0, out
+    assert out[1][0] == 100 and out[0][0] == 0 and out[0][1]["total"] > 0 and out[0][1]["exchange"] >= 0, out

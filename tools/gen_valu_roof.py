@@ -44,6 +44,38 @@ VARIANTS = [
     ("fma_3banks_16_prio3", body("v_fma_f32 v{d}, v{d}, v81, v82", ev, 4), "fma_3banks_16 behind s_setprio 3"),
     ("fma_4chains", body("v_fma_f32 v{d}, v{d}, v81, v82", [16, 20, 24, 28], 16), "v_fma_f32, 4 chains: dependent-issue latency"),
     ("fma_1chain", body("v_fma_f32 v{d}, v{d}, v81, v82", [16], 64), "v_fma_f32, ONE chain: latency of a dependent v_fma"),
+    # ---- the instruction kinds the local-cut kernels are made of, sources in different banks ----
+    ("cmp_vcc", body("v_cmp_lt_f32 vcc, v81, v{d}", ev, 4), "v_cmp_lt_f32 vcc, a, d (VOPC)"),
+    ("cmp_sgpr", body("v_cmp_lt_f32 s[26:27], v81, v{d}", ev, 4), "v_cmp_lt_f32 s[26:27], a, d (VOP3 form)"),
+    ("cmp_u32_vcc", body("v_cmp_lt_u32 vcc, v81, v{d}", ev, 4), "v_cmp_lt_u32 vcc, a, d"),
+    ("cmp_u64_vcc", body("v_cmp_lt_u64 vcc, v[82:83], v[{d}:{d1}]", ev, 4), "v_cmp_lt_u64 vcc, a2, d2 (the edge-key compare)"),
+    ("cndmask_vcc", body("v_cndmask_b32 v{d}, v81, v{d}, vcc", ev, 4), "v_cndmask_b32 d, a, d, vcc (VOP2)"),
+    ("cndmask_sgpr", body("v_cndmask_b32 v{d}, v81, v{d}, s[26:27]", ev, 4), "v_cndmask_b32 d, a, d, s[26:27] (VOP3)"),
+    ("cmp_cndmask", sum((["v_cmp_lt_f32 vcc, v81, v{d}".format(d=d), "v_cndmask_b32 v{d}, v82, v{d}, vcc".format(d=d)] for d in ev * 2), []), "v_cmp_lt_f32 vcc + v_cndmask_b32 .. vcc, alternating (a select)"),
+    ("mov_dpp", body("v_mov_b32_dpp v{d}, v81 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", ev, 4), "v_mov_b32_dpp quad_perm"),
+    ("mov_dpp_row_shr", body("v_mov_b32_dpp v{d}, v81 row_shr:1 row_mask:0xf bank_mask:0xf", ev, 4), "v_mov_b32_dpp row_shr:1"),
+    ("add_dpp", body("v_add_f32_dpp v{d}, v81, v{d} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", ev, 4), "v_add_f32_dpp (an ALU op with a DPP source)"),
+    ("permlane32_swap", body("v_permlane32_swap_b32 v{d}, v{d1}", ev, 4), "v_permlane32_swap_b32 d, d+1"),
+    ("readlane", body("v_readlane_b32 s28, v{d}, 3", ev, 4), "v_readlane_b32 s28, d, 3"),
+    ("readfirstlane", body("v_readfirstlane_b32 s28, v{d}", ev, 4), "v_readfirstlane_b32"),
+    ("and_or", body("v_and_or_b32 v{d}, v{d}, v81, v82", ev, 4), "v_and_or_b32 d, d, a, b (VOP3 integer, three banks)"),
+    ("lshlrev", body("v_lshlrev_b32 v{d}, 1, v{d}", ev, 4), "v_lshlrev_b32 d, 1, d (VOP2)"),
+    ("and_b32", body("v_and_b32 v{d}, v81, v{d}", ev, 4), "v_and_b32 d, a, d (VOP2)"),
+    ("bfe_u32", body("v_bfe_u32 v{d}, v{d}, 3, 5", ev, 4), "v_bfe_u32 d, d, 3, 5 (VOP3, inline constants)"),
+    ("mul_lo_u32", body("v_mul_lo_u32 v{d}, v{d}, v81", ev, 4), "v_mul_lo_u32 d, d, a"),
+    ("mad_u32_u24", body("v_mad_u32_u24 v{d}, v{d}, v81, v82", ev, 4), "v_mad_u32_u24 d, d, a, b (three banks)"),
+    ("mbcnt", body("v_mbcnt_lo_u32_b32 v{d}, v81, v{d}", ev, 4), "v_mbcnt_lo_u32_b32 d, a, d"),
+    ("bcnt", body("v_bcnt_u32_b32 v{d}, v81, v{d}", ev, 4), "v_bcnt_u32_b32 d, a, d"),
+    ("exp_f32", body("v_exp_f32 v{d}, v81", ev, 4), "v_exp_f32 d, a (transcendental)"),
+    ("rcp_f32", body("v_rcp_f32 v{d}, v81", ev, 4), "v_rcp_f32 d, a"),
+    ("sqrt_f32", body("v_sqrt_f32 v{d}, v81", ev, 4), "v_sqrt_f32 d, a"),
+    ("cvt_f32_u32", body("v_cvt_f32_u32 v{d}, v81", ev, 4), "v_cvt_f32_u32 d, a"),
+    ("lds_read_b32", body("ds_read_b32 v{d}, v84", ev, 4) + ["s_waitcnt lgkmcnt(0)"], "ds_read_b32 d, addr (lane * 4), one s_waitcnt per 64"),
+    ("lds_read_b64", body("ds_read_b64 v[{d}:{d1}], v85", ev, 4) + ["s_waitcnt lgkmcnt(0)"], "ds_read_b64 d2, addr (lane * 8)"),
+    ("lds_write_b32", body("ds_write_b32 v84, v{d}", ev, 4) + ["s_waitcnt lgkmcnt(0)"], "ds_write_b32 addr, d"),
+    ("lds_bpermute", body("ds_bpermute_b32 v{d}, v84, v{d1}", ev, 4) + ["s_waitcnt lgkmcnt(0)"], "ds_bpermute_b32 d, addr, d+1"),
+    ("lds_min_u32", body("ds_min_u32 v84, v{d}", ev, 4) + ["s_waitcnt lgkmcnt(0)"], "ds_min_u32 addr, d (the merge loop's claim)"),
+    ("lds_read_dep", ["ds_read_b32 v16, v16", "s_waitcnt lgkmcnt(0)"] * 64, "ds_read_b32 v16, v16 + s_waitcnt, 64 dependent round trips per trip (address 0 holds 0)"),
 ]
 
 HEAD = r'''// tools/valu_roof.hip -- GENERATED by tools/gen_valu_roof.py (edit that, not this).  See its docstring.
@@ -67,6 +99,8 @@ template <int V> __device__ __forceinline__ void loop_body();
 KERNEL = r'''
 template <int V>
 __global__ __launch_bounds__(256) void k_roof(unsigned long long* rec) {
+  __shared__ unsigned int lds[1024];   // the LDS variants address bytes [0, 512) of it; zero: the dependent-read chain stays at address 0
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = 0u;
   unsigned int hw, xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -120,11 +154,15 @@ static Res run(int cus, int wg_per_cu, unsigned long long* d_rec) {
 
 
 def main():
-    regs = [f'"v{r}"' for r in range(CH0, 88)] + ['"s20"', '"s24"', '"s25"', '"scc"', '"vcc"']
+    regs = [f'"v{r}"' for r in range(CH0, 88)] + ['"s20"', '"s24"', '"s25"', '"s26"', '"s27"', '"s28"', '"scc"', '"vcc"', '"memory"']
     out = [HEAD % (ITER, ", ".join(regs))]
     for k, (name, lines, note) in enumerate(VARIANTS):
         init = [f"v_mov_b32 v{r}, 1.0" for r in range(CH0, 80)] + [f"v_mov_b32 v{r}, 0.5" for r in range(80, 88)] + \
-               ["s_mov_b32 s24, 0.5", "s_mov_b32 s25, 0.5", f"s_mov_b32 s20, {ITER}"]
+               ["s_mov_b32 s24, 0.5", "s_mov_b32 s25, 0.5", f"s_mov_b32 s20, {ITER}", "s_mov_b64 s[26:27], -1"]
+        if name.startswith("lds_"):
+            init += ["v_mbcnt_lo_u32_b32 v84, -1, 0", "v_mbcnt_hi_u32_b32 v84, -1, v84", "v_lshlrev_b32 v85, 3, v84", "v_lshlrev_b32 v84, 2, v84"]
+            if name == "lds_read_dep":
+                init += ["v_mov_b32 v16, 0"]
         if "prio3" in name:
             init.append("s_setprio 3")
         loop = ["1:"] + lines + ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 1b"]

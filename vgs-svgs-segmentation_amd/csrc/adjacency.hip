@@ -14,6 +14,7 @@
 // the full neighbour count (closestCheck needs it: VS:2201, VS:2243).  The full lists of the reference's
 // getOneVoxelAdjacency are produced on demand by the FULL instantiation (vgs_get_lists).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -504,6 +505,23 @@ vgs_status vgs_stage_adjacency(vgs_ctx* c) {
   c->adj_r2 = r2;
   if (U == 0) return VGS_OK;
   c->adj_pruned = vgs_unused_are_inert(c->P);
+  {
+    // The row tables are dense: U rows x (lattice offsets of the search ball) slots -- sorted keys 8 B, lattice offsets 2 B and the
+    // connect / mutual flags of the local-cut stage 2 B per slot.  2.6 GB at the 10 M-point config, but U x 4189 x 12 B at
+    // a ball of ten voxels: say so BEFORE allocating, in terms the caller can act on, instead of failing inside some hipMalloc.
+    const double need = (double)U * (double)c->adj_stride * 12.0;
+    const double held = (double)c->adj_key.cap * 8.0 + (double)c->adj_off.cap * 2.0 + (double)c->conn.cap;
+    size_t free_b = 0, total_b = 0;
+    VGS_HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    if (need > held + (double)free_b * 0.97) {
+      char msg[512];
+      snprintf(msg, sizeof(msg), "adjacency / connect tables need %.1f GB (%lld used voxels x %d lattice offsets of a search ball of %.1f voxels x 12 B) "
+               "but %.1f GB are free on the device (%.1f GB in all): lower graph_size / voxel_size, or split the cloud into spatial tiles (include/vgs_tiles.h)",
+               need / 1e9, (long long)U, c->adj_stride, (double)(c->P.graph_size / c->P.voxel_size), ((double)free_b + held) / 1e9, (double)total_b / 1e9);
+      c->err = msg;
+      return VGS_E_NOMEM;
+    }
+  }
   VGS_HIP_TRY(c, c->adj_key.ensure((size_t)U * c->adj_stride));
   VGS_HIP_TRY(c, c->adj_cnt.ensure(U)); VGS_HIP_TRY(c, c->adj_mused.ensure(U));
   st = vgs_run_adjacency(c, !c->adj_pruned, c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, r2);

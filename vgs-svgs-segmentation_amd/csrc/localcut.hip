@@ -664,7 +664,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   static_assert(LW_HO_BINS == 4, "four 32-bit list lengths in counter words 14-15");
 
   constexpr int WAVE_A = 96, WAVE_B = 128, WAVE_C = 512;
-  constexpr int LCAP_A = 448, LCAP_B = 312, LCAP_C = 2048;
+#ifndef LW_LCAP_C
+#define LW_LCAP_C 2048
+#endif
+  constexpr int LCAP_A = 448, LCAP_B = 312, LCAP_C = LW_LCAP_C;
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
   constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)

@@ -72,6 +72,9 @@
 #ifndef LW_NEAR_GROUPS
 #define LW_NEAR_GROUPS 2
 #endif
+#ifndef LW_MASTER_ROT
+#define LW_MASTER_ROT 0
+#endif
 
 struct LwParams {
   LcParams lc;
@@ -177,7 +180,15 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   };
 
   int lane = threadIdx.x & 63;   // (not const: see the top of the shell loop)
+  // NW > 1: the wavefront that runs the sequential parts ("wavefront 0" below) is a different hardware wavefront from workgroup to
+  // workgroup (LW_MASTER_ROT): the workgroups of one CU then keep their busy wavefronts on different SIMDs instead of all on the
+  // SIMD that hosts every workgroup's first wavefront -- one wavefront alone issues a VALU instruction every 5.6 cycles, a SIMD one
+  // every 2.2 (tools/valu_roof.hip), so three such wavefronts on one SIMD already wait for each other.
+#if LW_MASTER_ROT
+  const int wave = NW > 1 ? (int)(((threadIdx.x >> 6) + blockIdx.x) & (unsigned)(NW - 1)) : 0;
+#else
   const int wave = threadIdx.x >> 6;
+#endif
   auto blk_sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_sync(); };
   // workgroup b runs on XCD b % 8 (observed; used for speed only): give every XCD one contiguous eighth of the
   // Morton-ordered work list so that neighbouring voxels share their L2

@@ -246,6 +246,7 @@ struct vgs_ctx {
     hipError_t _e = (expr);                                                                          \
     if (_e != hipSuccess) {                                                                          \
       (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                \
+      if (_e == hipErrorOutOfMemory) { (void)hipGetLastError(); return VGS_E_NOMEM; }                \
       return VGS_E_HIP;                                                                              \
     }                                                                                                \
   } while (0)
