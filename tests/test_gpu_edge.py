@@ -131,12 +131,12 @@ def test_limits_are_reported_not_silently_wrong(gpu):
 
 
 def test_tables_that_cannot_fit_are_refused_with_an_estimate(gpu):
-    """The adjacency / connect tables are dense (used voxels x lattice offsets of the ball x 12 B): 6.2 M used voxels seen through a
-    ball of ten voxels would need 310 GB.  The adjacency stage says so -- VGS_E_NOMEM with the numbers and what to change -- before
+    """The adjacency / connect tables are dense (used voxels x lattice offsets of the ball x 12 B): more than six million used voxels seen through a
+    ball of ten voxels would need over 300 GB.  The adjacency stage says so -- VGS_E_NOMEM with the numbers and what to change -- before
     it allocates anything, and the context stays usable."""
-    side = 2500
+    side = 3200
     ij = np.stack(np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32), indexing="ij"), -1).reshape(-1, 2)
-    cell = np.concatenate([ij * 0.05 + 0.0125, ij * 0.05 + 0.0375])                  # two points in every voxel of a 125 m sheet
+    cell = np.concatenate([ij * 0.05 + 0.0125, ij * 0.05 + 0.0375])                  # two points in every voxel of a 160 m sheet
     xyz = np.concatenate([cell, np.full((cell.shape[0], 1), 1.02, np.float32)], axis=1).astype(np.float32)
     eng = gpu.Engine(gpu.default_params(2, voxel_size=0.05, graph_size=0.5, points_min=1))
     eng.set_points(xyz)

@@ -147,6 +147,7 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
     g_create_err = "vgs_create: voxel_size, graph_size must be > 0, sig_w != 0, method 2 or 3";
     return VGS_E_ARG;
   }
+  if (p->vccs_mode != 0 && p->vccs_mode != 1) { g_create_err = "vgs_create: vccs_mode must be 0 (synchronous variant) or 1 (PCL's order)"; return VGS_E_ARG; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -225,6 +226,7 @@ vgs_status vgs_set_params(vgs_ctx* c, const vgs_params* p) {
   if (!c || !p) return VGS_E_ARG;
   if (!(p->voxel_size > 0.f) || !(p->graph_size > 0.f) || !(p->sig_w != 0.f)) { c->err = "vgs_set_params: voxel_size, graph_size > 0, sig_w != 0"; return VGS_E_ARG; }
   if (p->method != c->P.method || p->device != c->P.device) { c->err = "vgs_set_params: method and device are fixed at vgs_create"; return VGS_E_ARG; }
+  if (p->vccs_mode != 0 && p->vccs_mode != 1) { c->err = "vgs_set_params: vccs_mode must be 0 (synchronous variant) or 1 (PCL's order)"; return VGS_E_ARG; }
   int keep = ST_SEGMENTED;
   const vgs_params& o = c->P;
   if (p->cut_thred != o.cut_thred || p->sig_p != o.sig_p || p->sig_n != o.sig_n || p->sig_o != o.sig_o || p->sig_e != o.sig_e ||

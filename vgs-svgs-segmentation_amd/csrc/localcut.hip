@@ -1031,7 +1031,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   {
     unsigned long long pr[16];
     VGS_HIP_TRY(c, hipMemcpy(pr, cnt + 16, sizeof(pr), hipMemcpyDeviceToHost));
-    const char* nm[16] = {"gather", "enumerate", "evaluate", "sort", "merge", "carry", "phaseB", "merge_iterations", "rounds", "sorted_keys", "phaseB_voxels", "voxels", "merges", "sum_m", "walk_steps(max per iteration)", "merge_steps"};
+    const char* nm[16] = {"gather", "enumerate_near", "evaluate", "sort", "merge", "carry", "phaseB", "merge_iterations", "rounds", "sorted_keys", "general_rounds", "voxels", "merges", "sum_m", "enumerate_general", "merge_steps"};
     fprintf(stderr, "[vgs-prof]");
     for (int k = 0; k < 16; ++k) fprintf(stderr, " %s=%.3g", nm[k], (double)pr[k]);
     fprintf(stderr, "\n");

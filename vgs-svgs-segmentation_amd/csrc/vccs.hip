@@ -612,15 +612,23 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
       hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
-      for (int sweep = 0; sweep < 4096; ++sweep) {   // fixed point of the live flags: the recursion is on smaller labels, so it ends
-        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
-                           live[lc ^ 1], d_changed);
-        lc ^= 1;
-        unsigned int ch = 0;
-        VGS_READBACK(c, &ch, d_changed, 4);
-        if (!ch) break;
+      // fixed point of the live flags: the recursion is on smaller labels, so it ends -- a sweep that changes nothing is the proof.
+      // Sweeps go out in pairs with one read-back per pair (a sweep at the fixed point changes nothing, so a spare one is harmless):
+      // half the host round trips.  Leaving the loop without that proof would give labels that differ from the sequential
+      // order silently: it is an error.
+      bool settled = false;
+      for (int sweep = 0; sweep < 4096 && !settled; sweep += 2) {
+        unsigned int ch[2] = {1u, 1u};
+        for (int k = 0; k < 2; ++k) {
+          VGS_HIP_TRY(c, hipMemsetAsync(d_changed + k, 0, 4, c->stream));
+          hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
+                             live[lc ^ 1], d_changed + k);
+          lc ^= 1;
+        }
+        VGS_READBACK(c, ch, d_changed, 8);
+        settled = !ch[0] || !ch[1];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
       }
+      if (!settled) { c->err = "svgs_supervoxels (vccs_mode 1): the live flags did not reach their fixed point in 4096 sweeps"; return VGS_E_STATE; }
       hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                          own[cur ^ 1], dst[cur ^ 1]);
       cur ^= 1;
