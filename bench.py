@@ -38,9 +38,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-# measured on this pool with tools/valu_rate.hip (profiles/r03_valu_rate.txt): a SIMD issues one wave64 VALU instruction
-# per 1.23 ns at best (2-operand VOP2, two or more wavefronts per SIMD; 1.94 ns for 3-operand VOP3 such as v_fma_f32)
-VALU_NS_PER_WAVE_INSTR = 1.23
+# measured on this pool with tools/valu_roof.hip (hand-placed registers; profiles/r04_valu_roof.txt): a SIMD issues one wave64 VALU
+# instruction per 2.2 cycles = 0.92 ns at 2.39 GHz for the full-rate classes (v_add/mul/fmac/mov/and, v_fma_f32 with its sources in
+# three VGPR banks) -- the guide's 2 cycles -- and one per 4.08 cycles = 1.71 ns for the half-rate ones (every v_cmp, v_cndmask with an
+# SGPR mask, DPP moves, v_readlane, shifts, v_bfe, v_mul_lo, v_mad_u32_u24, v_cvt, any VOP3 with two sources in one bank or an SGPR
+# source).  Round 3's 1.23 ns came from compiler-placed registers with bank conflicts.  The kernel's instructions are a mix of both
+# classes and the counters do not separate them (SQ_ACTIVE_INST_VALU books one quad-cycle per instruction whatever it costs), so the
+# issue utilisation is reported as a range: every instruction at the full rate (lower bound) and at the half rate (upper bound).
+VALU_NS_PER_WAVE_INSTR = 0.92
+VALU_NS_PER_WAVE_INSTR_HALF_RATE = 1.71
 N_SIMD = 1024
 
 
@@ -132,7 +138,7 @@ def profiled_traffic(n_points):
     (profiles/rNN_traffic.json, written by tools/collect_profiles.sh from FETCH_SIZE + WRITE_SIZE of the same bench command);
     None if the profile is missing or was taken on another workload."""
     prof = os.path.join(ROOT, "profiles")
-    for tag in ("r03", "r02", "r01"):   # the newest round's profile that exists
+    for tag in ("r04", "r03", "r02", "r01"):   # the newest round's profile that exists
         try:
             with open(os.path.join(prof, f"{tag}_traffic.json")) as f:
                 t = json.load(f)
@@ -477,6 +483,7 @@ def main():
         traffic, valu, traffic_src = profiled_traffic(N) if (world == 1 and not native) else (None, None, None)
         # the kernel works on-chip (VALU issue + LDS latency): its VALU wave instructions at the measured issue peak of a SIMD
         valu_frac = (valu * VALU_NS_PER_WAVE_INSTR * 1e-9 / N_SIMD) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
+        valu_frac_hi = (valu * VALU_NS_PER_WAVE_INSTR_HALF_RATE * 1e-9 / N_SIMD) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
         sm = sorted(step_ms)
         out = {
             "metric": "segmented points/sec (end-to-end VGS)",
@@ -501,6 +508,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
                          "valu_issue_frac": valu_frac, "valu_peak_ns_per_wave_instr_per_simd": VALU_NS_PER_WAVE_INSTR,
+                         "valu_issue_frac_if_all_half_rate": valu_frac_hi,
                          "algorithmic_bytes_per_step": alg_run,
                          "end_to_end_frac": alg_run / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "pair_evals_per_s": c["pairs"] / (k_avg_ms * 1e-3) if k_avg_ms > 0 else 0.0},

@@ -105,6 +105,15 @@ __device__ __forceinline__ int lw_ho_bin(int m) { return m > 112 ? 0 : (m > 96 ?
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
+// v_writelane_b32: lane `l` of `old` becomes `value` (both wave-uniform).  This clang has no builtin for it; two SGPR operands break
+// gfx9's constant-bus rule, so the lane select travels in M0 (which nothing else in these kernels uses: gfx9 LDS needs no M0).
+__device__ __forceinline__ int lw_writelane(int old, int value, int l) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(l) : "m0");
+#pragma clang diagnostic pop
+  return old;
+}
 
 // LDS diet.  The kernel is bound by dependent LDS/L2 latency, not by issue slots (measured: time ~ 2.9 ms + 99 ms /
 // (wavefronts per CU) on URB10M), so the footprint is cut to 5 KB per wavefront = the 32-wavefronts-per-CU cap:
@@ -798,9 +807,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           const int keep = (t1 >= t2) ? xa : xb;   // VS:1972-1983: the segment with the larger threshold survives
           const int gone = xa ^ xb ^ keep;
           const float tn = wi - cut / (float)(nsz > 0 ? nsz : 1);   // = vm_cut_threshold(w, cut, nsz): seg_int = w (VS:1988)
-          if (gone & 1) PB = __builtin_amdgcn_writelane(keep, gone >> 1, PB); else PA = __builtin_amdgcn_writelane(keep, gone >> 1, PA);
-          if (keep & 1) { TB = __int_as_float(__builtin_amdgcn_writelane(__float_as_int(tn), keep >> 1, __float_as_int(TB))); ZB = __builtin_amdgcn_writelane(nsz, keep >> 1, ZB); }
-          else { TA = __int_as_float(__builtin_amdgcn_writelane(__float_as_int(tn), keep >> 1, __float_as_int(TA))); ZA = __builtin_amdgcn_writelane(nsz, keep >> 1, ZA); }
+          const int tn_bits = __builtin_amdgcn_readfirstlane(__float_as_int(tn));   // (uniform: into an SGPR for v_writelane)
+          if (gone & 1) PB = lw_writelane(PB, keep, gone >> 1); else PA = lw_writelane(PA, keep, gone >> 1);
+          if (keep & 1) { TB = __int_as_float(lw_writelane(__float_as_int(TB), tn_bits, keep >> 1)); ZB = lw_writelane(ZB, nsz, keep >> 1); }
+          else { TA = __int_as_float(lw_writelane(__float_as_int(TA), tn_bits, keep >> 1)); ZA = lw_writelane(ZA, nsz, keep >> 1); }
           ++merges;
         }
         // the step's result goes back to LDS: the lane that gave a segment its local id writes it.  A segment that was absorbed
