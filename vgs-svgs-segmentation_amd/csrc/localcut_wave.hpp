@@ -75,9 +75,9 @@
 #ifndef LW_MASTER_ROT
 #define LW_MASTER_ROT 0
 #endif
-// multi-wavefront classes: the merge as a sequential scan with its state in registers (merge_list_seq) instead of claim iterations
-#ifndef LW_SEQ_MERGE
-#define LW_SEQ_MERGE 1
+// merge loop: program order instead of fences between the wavefront's own LDS accesses (see merge_list)
+#ifndef LW_MERGE_ORDER_ONLY
+#define LW_MERGE_ORDER_ONLY 1
 #endif
 
 struct LwParams {
@@ -105,16 +105,6 @@ __device__ __forceinline__ int lw_ho_bin(int m) { return m > 112 ? 0 : (m > 96 ?
 __device__ __forceinline__ float lw_readlane_f(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
-// v_writelane_b32: lane `l` of `old` becomes `value` (both wave-uniform).  This clang has no builtin for it; two SGPR operands break
-// gfx9's constant-bus rule, so the lane select travels in M0 (which nothing else in these kernels uses: gfx9 LDS needs no M0).
-__device__ __forceinline__ int lw_writelane(int old, int value, int l) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(l) : "m0");
-#pragma clang diagnostic pop
-  return old;
-}
-
 // LDS diet.  The kernel is bound by dependent LDS/L2 latency, not by issue slots (measured: time ~ 2.9 ms + 99 ms /
 // (wavefronts per CU) on URB10M), so the footprint is cut to 5 KB per wavefront = the 32-wavefronts-per-CU cap:
 // centroids SoA without a flag word (an unusable position is a NaN x), one-byte vertex/segment indices up to 256
@@ -745,101 +735,20 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       return cut / (float)(nsz > 0 ? nsz : 1);
     }
   };
-  // The same merge for the multi-wavefront classes (LW_SEQ_MERGE), where ONE wavefront per voxel runs it beside three or seven that
-  // wait: there the claim iterations above are pure latency -- four dependent LDS round trips of 100-250 cycles each for the two or
-  // three edges an iteration decides (profiles/r04_c2_*: 1626 cycles per iteration, 42 % of the class's time on config 2).  Here a
-  // step's 64 edges are first resolved to their current roots in parallel (as above; edges inside one segment die there), the
-  // roots of the surviving edges get LOCAL ids through one round of claims (id = 2 * lane + end of the first edge that names the
-  // segment), their thresholds and sizes are read into registers, and then the edges are scanned ONE BY ONE in the reference's
-  // order with the whole state in registers: lane x >> 1 holds local id x's parent, threshold and size (x & 1 picks the register),
-  // read and written with v_readlane / v_writelane at about five cycles an instruction -- no LDS traffic until the step's result
-  // goes back to LDS in one round.  Sequential semantics by construction (VS:1956-2000), ~60 instructions per merging edge.
-  auto merge_list_seq = [&](int cnt, float level) -> int {
-    int pos = 0;
-    bool reached = false;
-    while (pos < cnt && !reached) {
-      const int e = pos + lane;
-      float w = 0.f;
-      int sa = 0, sb = 0;
-      bool alive = false;
-      if (e < cnt) {
-        const uint64_t key = lk[e];
-        w = vm_from_bits((uint32_t)(key >> 32));
-        alive = w > level;
-        const uint32_t pid = PCOMP - (uint32_t)key;
-        sa = seg[pid >> PSH];
-        sb = seg[pid & PMASK];
-      }
-      const int nproc = __popcll(__ballot(alive));  // sorted: the processable edges are a prefix of the step
-      if (alive) {
-        int rb = rep[sb], r = rep[sa];
-        while (r != sa || rb != sb) { sa = r; sb = rb; r = rep[sa]; rb = rep[sb]; }
-        alive = sa != sb;  // inside one segment: skipped now and for ever
-      }
-      unsigned long long todo = __ballot(alive);
-      if (todo != 0ull) {
-        if (alive) { atomicMin(&claim[sa], 2u * (uint32_t)lane); atomicMin(&claim[sb], 2u * (uint32_t)lane + 1u); }
-        wave_sync();
-        int la = 0, lb = 0, za = 0, zb = 0;
-        float ta = 0.f, tb = 0.f;
-        if (alive) { la = (int)claim[sa]; lb = (int)claim[sb]; ta = thr[sa]; tb = thr[sb]; za = (int)ssz[sa]; zb = (int)ssz[sb]; }
-        wave_sync();
-        if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
-        // local forest: parent / threshold / size of local id x live in lane x >> 1, register A (x even) or B (x odd)
-        int PA = 2 * lane, PB = 2 * lane + 1, ZA = za, ZB = zb;
-        float TA = ta, TB = tb;
-        auto rd = [&](int a, int b, int x) -> int {   // (x uniform)
-          const int va = __builtin_amdgcn_readlane(a, x >> 1), vb = __builtin_amdgcn_readlane(b, x >> 1);
-          return (x & 1) ? vb : va;
-        };
-        auto rdf = [&](float a, float b, int x) -> float { return __int_as_float(rd(__float_as_int(a), __float_as_int(b), x)); };
-        while (todo != 0ull) {
-          const int i = __ffsll((long long)todo) - 1;
-          todo &= todo - 1ull;
-          int xa = __builtin_amdgcn_readlane(la, i), xb = __builtin_amdgcn_readlane(lb, i);
-          for (int p2 = rd(PA, PB, xa); p2 != xa; p2 = rd(PA, PB, xa)) xa = p2;
-          for (int p2 = rd(PA, PB, xb); p2 != xb; p2 = rd(PA, PB, xb)) xb = p2;
-          if (xa == xb) continue;   // joined earlier in this step
-          const float wi = lw_readlane_f(w, i);
-          const float t1 = rdf(TA, TB, xa), t2 = rdf(TA, TB, xb);
-          if (!((wi > t1) && (wi > t2))) continue;   // rejected: the state stays as it is
-          const int nsz = rd(ZA, ZB, xa) + rd(ZA, ZB, xb);
-          const int keep = (t1 >= t2) ? xa : xb;   // VS:1972-1983: the segment with the larger threshold survives
-          const int gone = xa ^ xb ^ keep;
-          const float tn = wi - cut / (float)(nsz > 0 ? nsz : 1);   // = vm_cut_threshold(w, cut, nsz): seg_int = w (VS:1988)
-          const int tn_bits = __builtin_amdgcn_readfirstlane(__float_as_int(tn));   // (uniform: into an SGPR for v_writelane)
-          if (gone & 1) PB = lw_writelane(PB, keep, gone >> 1); else PA = lw_writelane(PA, keep, gone >> 1);
-          if (keep & 1) { TB = __int_as_float(lw_writelane(__float_as_int(TB), tn_bits, keep >> 1)); ZB = lw_writelane(ZB, nsz, keep >> 1); }
-          else { TA = __int_as_float(lw_writelane(__float_as_int(TA), tn_bits, keep >> 1)); ZA = lw_writelane(ZA, nsz, keep >> 1); }
-          ++merges;
-        }
-        // the step's result goes back to LDS: the lane that gave a segment its local id writes it.  A segment that was absorbed
-        // points at the segment that absorbed it (not necessarily the final root: the walk above follows chains)
-        const int ga_of_pa = __shfl(sa, PA >> 1, 64), gb_of_pa = __shfl(sb, PA >> 1, 64);   // (all lanes: a cross-lane read returns 0 from a lane that is switched off)
-        const int ga_of_pb = __shfl(sa, PB >> 1, 64), gb_of_pb = __shfl(sb, PB >> 1, 64);
-        if (alive && la == 2 * lane) {
-          if (PA != 2 * lane) { rep[sa] = (idx_t)((PA & 1) ? gb_of_pa : ga_of_pa); ssz[sa] = 0; }
-          else { thr[sa] = TA; ssz[sa] = (idx_t)ZA; }
-        }
-        if (alive && lb == 2 * lane + 1) {
-          if (PB != 2 * lane + 1) { rep[sb] = (idx_t)((PB & 1) ? gb_of_pb : ga_of_pb); ssz[sb] = 0; }
-          else { thr[sb] = TB; ssz[sb] = (idx_t)ZB; }
-        }
-        wave_sync();
-      }
-      LW_CNT(15, 1);
-      if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
-      if (merges >= m - 1) break;  // one segment left
-    }
-    for (int c = lane; c < m; c += 64) {
-      int s2 = seg[c];
-      while (rep[s2] != s2) s2 = rep[s2];
-      seg[c] = (idx_t)s2;
-    }
+  // Between the accesses of ONE wavefront the LDS needs no fence: its DS instructions execute in program order (that is what lets
+  // lgkmcnt count them), so "every lane's atomic before any lane's read of the claims", "reads before the reset", "this iteration's
+  // stores before the next one's reads" hold by instruction order alone.  msync() therefore only stops the COMPILER from moving LDS
+  // accesses across it; the hardware waits (s_waitcnt) remain where a register needs a loaded value -- two per iteration instead
+  // of four (round 4; LW_MERGE_ORDER_ONLY=0 restores the fences).  During the merge no other wavefront touches these arrays.
+  auto msync = [&]() {
+#if LW_MERGE_ORDER_ONLY
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#else
     wave_sync();
-    return pos;
+#endif
   };
-  auto merge_list_par = [&](int cnt, float level) -> int {
+  auto merge_list = [&](int cnt, float level) -> int {
     int pos = 0;
     bool reached = false;
     while (pos < cnt && !reached) {
@@ -872,7 +781,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
 #endif
         if (__ballot(alive) == 0ull) break;
         if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
-        wave_sync();
+        msync();
         bool decided = false;
         float ta = 0.f, tb = 0.f;
         int nsz = 1;
@@ -882,7 +791,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           ta = thr[sa]; tb = thr[sb];
           nsz = (int)ssz[sa] + (int)ssz[sb];
         }
-        wave_sync();
+        msync();
         if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
         const float co = cut_over(nsz);
         const bool pass = decided && (w > ta) && (w > tb);
@@ -896,7 +805,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         }
         merges += __popcll(__ballot(pass));
         alive = alive && !decided;
-        wave_sync();
+        msync();
       }
       LW_CNT(15, 1);
       if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
@@ -910,11 +819,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     wave_sync();
     return pos;
   };
-  auto merge_list = [&](int cnt, float level) -> int {
-    if constexpr (NW > 1 && LW_SEQ_MERGE != 0) return merge_list_seq(cnt, level);
-    else return merge_list_par(cnt, level);
-  };
-
   // ---- can the voxel itself ever merge?  While it is a singleton it needs an incident edge heavier than thr0.  On
   // surfaces vertex 0 joins a segment in the first shell, so the test is only made when it has not (after shell one):
   // the cheap bound first, the full weight for the pairs it lets through -- at most m - 1 evaluations that save a voxel

@@ -515,8 +515,13 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
   hipLaunchKernelGGL(k_voxel_labels, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, keep_flag, c->kept_rank.p, V, c->vox_label.p,
                      (unsigned int*)(mcnt + 3));
-  hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
-                     N, c->pt_label.p);
+  if (c->P.method == 2 && c->bricks_for_voxels && !c->K.no_direct_labels) {
+    vgs_status sl = vgs_point_labels_direct(c, c->vox_label.p, c->pt_label.p);   // input order, coalesced (voxelize.hip)
+    if (sl != VGS_OK) return sl;
+  } else {
+    hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
+                       N, c->pt_label.p);
+  }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   VGS_HIP_TRY(c, hipGetLastError());
   // one read-back: words 1-3 = re-attachments, roots, kept segments

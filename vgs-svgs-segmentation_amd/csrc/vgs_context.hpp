@@ -90,6 +90,7 @@ struct VgsKnobs {
   bool no_overlap = false;   // VGS_NO_OVERLAP
   bool no_near = false;      // VGS_NO_NEAR
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
+  bool no_direct_labels = false;  // VGS_NO_DIRECT_LABELS: per-point labels through the sorted order (the scatter kernel)
   bool debug = false;        // VGS_DEBUG
 };
 
@@ -148,6 +149,7 @@ struct vgs_ctx {
   DevBuf<uint64_t> hkey;
   DevBuf<uint32_t> hval;
   uint32_t hbits = 0;
+  bool bricks_for_voxels = false;   // the brick table in hkey was built from the current voxel table with the voxels as nodes (method 2's adjacency stage)
   DevBuf<int32_t> offsets;  // packed dx,dy,dz
   DevBuf<uint64_t> adj_masks;  // ball cells per (voxel position in its brick, brick offset): k_adjacency_masks
   int adj_mask_nb = 0;         // bricks per axis the ball can touch (0 = no mask table)
@@ -270,6 +272,7 @@ void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only
 
 // stage implementations (one .hip file each)
 vgs_status vgs_stage_voxelize(vgs_ctx* c);
+vgs_status vgs_point_labels_direct(vgs_ctx* c, const int32_t* vox_label, int32_t* label);   // voxelize.hip; needs c->bricks_for_voxels
 vgs_status vgs_stage_features(vgs_ctx* c);
 vgs_status vgs_stage_adjacency(vgs_ctx* c);
 vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2, const uint32_t* ids = nullptr,
