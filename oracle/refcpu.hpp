@@ -129,6 +129,8 @@ struct SvgsResult {
 void run_svgs_from_labels(const float* xyz, int64_t n, int stride_floats, const int* sv_label, int max_label,
                           const Params& P, SvgsResult& R);
 void vccs_supervoxels(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
+// the same steps in double precision with libm and an eigen-solver of its own: shares no arithmetic with the device (refcpu_vccs_ref.cpp)
+void vccs_supervoxels_refmath(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
 // vccs_mode 1: pcl::SupervoxelClustering's steps in PCL's order (sequential owners, 2-ring normals, seed rejection); unpinned
 void vccs_pcl_supervoxels(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
 

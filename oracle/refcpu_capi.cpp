@@ -68,6 +68,14 @@ int ref_vccs(const float* xyz, int64_t n, int stride_floats, const RefParamsC* p
   return max_label;
 }
 
+int ref_vccs_refmath(const float* xyz, int64_t n, int stride_floats, const RefParamsC* p, int* labels) {
+  std::vector<int> lab;
+  int max_label = 0;
+  vccs_supervoxels_refmath(xyz, n, stride_floats, to_params(p), lab, max_label);
+  std::memcpy(labels, lab.data(), lab.size() * sizeof(int));
+  return max_label;
+}
+
 int ref_vccs_pcl(const float* xyz, int64_t n, int stride_floats, const RefParamsC* p, int* labels) {
   std::vector<int> lab;
   int max_label = 0;

@@ -43,7 +43,7 @@ def svgs_params(**kw):
 
 def build(force=False):
     so = os.path.join(_HERE, "librefcpu.so")
-    srcs = [os.path.join(_HERE, f) for f in ("refcpu.cpp", "refcpu_vccs.cpp", "refcpu_capi.cpp", "refcpu.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("refcpu.cpp", "refcpu_vccs.cpp", "refcpu_vccs_ref.cpp", "refcpu_capi.cpp", "refcpu.hpp")]
     srcs.append(os.path.join(_HERE, "..", "vgs-svgs-segmentation_amd", "csrc", "vgs_math.h"))
     srcs.append(os.path.join(_HERE, "..", "vgs-svgs-segmentation_amd", "csrc", "vccs_common.h"))
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
@@ -64,6 +64,8 @@ def lib():
         L.ref_voxelize.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
         L.ref_vccs.restype = C.c_int
         L.ref_vccs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
+        L.ref_vccs_refmath.restype = C.c_int
+        L.ref_vccs_refmath.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_vccs_pcl.restype = C.c_int
         L.ref_vccs_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_free.argtypes = [C.c_void_p]
@@ -183,6 +185,15 @@ def vccs(xyz, params):
     xyz = _xyz(xyz)
     lab = np.zeros(xyz.shape[0], dtype=np.int32)
     mx = lib().ref_vccs(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
+    return lab, int(mx)
+
+
+def vccs_refmath(xyz, params):
+    """The same supervoxel steps as `vccs` in double precision with libm and an eigen-solver of its own (refcpu_vccs_ref.cpp): the
+    leg that shares no arithmetic with the device; compared with a tolerance."""
+    xyz = _xyz(xyz)
+    lab = np.zeros(xyz.shape[0], dtype=np.int32)
+    mx = lib().ref_vccs_refmath(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
     return lab, int(mx)
 
 

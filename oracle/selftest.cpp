@@ -46,6 +46,11 @@ int main() {
     std::vector<int> lab; int mx = 0;
     vccs_supervoxels(xyz.data(), n, 3, P, lab, mx);
     if (mx <= 0 || (int64_t)lab.size() != n) { std::printf("vccs_supervoxels: no labels\n"); ++fails; }
+    {   // the independent (double, libm) leg of the same steps: same supervoxel count
+      std::vector<int> lab2; int mx2 = 0;
+      vccs_supervoxels_refmath(xyz.data(), n, 3, P, lab2, mx2);
+      if (mx2 != mx || (int64_t)lab2.size() != n) { std::printf("vccs_supervoxels_refmath: %d supervoxels, expected %d\n", mx2, mx); ++fails; }
+    }
     for (int math = 0; math < 2; ++math) {
       P.math = math;
       SvgsResult S;

@@ -365,7 +365,6 @@ bool vgs_unused_are_inert(const vgs_params& p) {
 
 static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   vgs_status bs = vgs_build_bricks(c, c->node.p);
-  c->bricks_for_voxels = (bs == VGS_OK && c->P.method == 2);   // (SVGS: the nodes are supervoxels, not the octree's voxels)
   if (bs != VGS_OK) return bs;
   // ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps)
   const double r = (double)c->P.graph_size;

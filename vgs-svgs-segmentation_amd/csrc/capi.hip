@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include <rocprofiler-sdk-roctx/roctx.h>
+#include <dlfcn.h>
 
 #include "vgs_context.hpp"
 
@@ -17,9 +17,28 @@ static thread_local std::string g_create_err;
 
 static const char* const VGS_STAGE_NAMES[VGS_T_COUNT] = {"vgs:voxelize", "vgs:features", "vgs:adjacency", "vgs:localcut", "vgs:merge", "vgs:labels",
                                                          "vgs:total", "vgs:localcut_kernel", "vgs:supervoxels", "vgs:localcut_bulk", "", ""};
-struct RoctxRange {   // a stage = one roctx range (rocprofv3 --marker-trace shows the stages on the host timeline)
-  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
-  ~RoctxRange() { roctxRangePop(); }
+// A stage = one roctx range (rocprofv3 --marker-trace shows the stages on the host timeline).  The marker library is looked up at
+// run time (dlopen: the profiler SDK's own library, the older libroctx64 otherwise): a host without it still builds and loads the
+// engine, and the ranges are then no-ops.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+static const RoctxApi& roctx_api() { static const RoctxApi api; return api; }
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name); }
+  ~RoctxRange() { if (on) roctx_api().pop(); }
 };
 
 // Time a stage with HIP events on the context's stream.  The stage is NOT waited for here (round 3): a stage function waits where
@@ -62,7 +81,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
   k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
   k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m); k.dbg_xl_from = geti("VGS_DBG_XL_FROM", k.dbg_xl_from);
   k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
-  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_direct_labels = has("VGS_NO_DIRECT_LABELS");
+  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS");
   k.debug = has("VGS_DEBUG");
 }
 
@@ -175,7 +194,7 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
             hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_d2h, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < 14; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  for (int i = 0; ok && i < 16; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
   for (int i = 0; ok && i < VGS_T_COUNT; ++i) ok = hipEventCreate(&c->tev[i][0]) == hipSuccess && hipEventCreate(&c->tev[i][1]) == hipSuccess;
   if (!ok) { g_create_err = "vgs_create: hipStreamCreate/hipEventCreate failed"; vgs_destroy(c); return VGS_E_HIP; }   // frees what exists
   vgs_read_env_knobs(c);
@@ -209,7 +228,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->bnd_code2.release(); c->bnd_root2.release(); c->bnd_cnt.release(); c->broot.release();
   c->kept_rank.release(); c->vox_label.release(); c->pt_label.release(); c->counters.release(); c->work_ids.release();
   if (c->pin) (void)hipHostFree(c->pin);
-  for (int i = 0; i < 14; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 16; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < VGS_T_COUNT; ++i) for (int k = 0; k < 2; ++k) if (c->tev[i][k]) (void)hipEventDestroy(c->tev[i][k]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -692,7 +711,9 @@ vgs_status vgs_get_point_labels_async(vgs_ctx* c, int32_t* labels) {
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   if (c->d2h_open) { VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }   // one download in flight per context
   if (c->N == 0) return VGS_OK;
-  // the stages have completed on the host's side (every stage ends with a wait), so the copy stream may start at once
+  // device-side order: the copy follows the kernel that wrote the labels (ev[15], recorded behind it on the context's stream by the
+  // merge stage and by vgs_apply_*_labels), whatever the host has or has not waited for
+  if (c->labels_event_valid) VGS_HIP_TRY(c, hipStreamWaitEvent(c->s_d2h, c->ev[15], 0));
   VGS_HIP_TRY(c, hipMemcpyAsync(labels, c->pt_label.p, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->s_d2h));
   VGS_HIP_TRY(c, hipEventRecord(c->ev_d2h, c->s_d2h));
   c->d2h_open = true; c->d2h_src = c->pt_label.p;

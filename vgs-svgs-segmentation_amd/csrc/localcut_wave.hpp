@@ -75,10 +75,6 @@
 #ifndef LW_MASTER_ROT
 #define LW_MASTER_ROT 0
 #endif
-// merge loop: program order instead of fences between the wavefront's own LDS accesses (see merge_list)
-#ifndef LW_MERGE_ORDER_ONLY
-#define LW_MERGE_ORDER_ONLY 1
-#endif
 
 struct LwParams {
   LcParams lc;
@@ -735,19 +731,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       return cut / (float)(nsz > 0 ? nsz : 1);
     }
   };
-  // Between the accesses of ONE wavefront the LDS needs no fence: its DS instructions execute in program order (that is what lets
-  // lgkmcnt count them), so "every lane's atomic before any lane's read of the claims", "reads before the reset", "this iteration's
-  // stores before the next one's reads" hold by instruction order alone.  msync() therefore only stops the COMPILER from moving LDS
-  // accesses across it; the hardware waits (s_waitcnt) remain where a register needs a loaded value -- two per iteration instead
-  // of four (round 4; LW_MERGE_ORDER_ONLY=0 restores the fences).  During the merge no other wavefront touches these arrays.
-  auto msync = [&]() {
-#if LW_MERGE_ORDER_ONLY
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#else
-    wave_sync();
-#endif
-  };
   auto merge_list = [&](int cnt, float level) -> int {
     int pos = 0;
     bool reached = false;
@@ -781,7 +764,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
 #endif
         if (__ballot(alive) == 0ull) break;
         if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
-        msync();
+        wave_sync();
         bool decided = false;
         float ta = 0.f, tb = 0.f;
         int nsz = 1;
@@ -791,7 +774,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           ta = thr[sa]; tb = thr[sb];
           nsz = (int)ssz[sa] + (int)ssz[sb];
         }
-        msync();
+        wave_sync();
         if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
         const float co = cut_over(nsz);
         const bool pass = decided && (w > ta) && (w > tb);
@@ -805,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
         }
         merges += __popcll(__ballot(pass));
         alive = alive && !decided;
-        msync();
+        wave_sync();
       }
       LW_CNT(15, 1);
       if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;

@@ -502,7 +502,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
   // cluster filter + labels (VGS_T_LABELS: this tail of the stage, measured on its own; it is part of VGS_T_MERGE)
-  VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));   // ev[2], ev[3]: free again once vgs_localcut_finish has run
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[14], c->stream));   // ev[14], ev[15]: this tail's own pair
   uint32_t* keep_flag = c->head_flag.p;  // >= N >= V entries, free after features
   VGS_HIP_TRY(c, c->head_flag.ensure(V + 1));
   keep_flag = c->head_flag.p;
@@ -515,19 +515,18 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, bytes, keep_flag, c->kept_rank.p, 0u, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
   hipLaunchKernelGGL(k_voxel_labels, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, keep_flag, c->kept_rank.p, V, c->vox_label.p,
                      (unsigned int*)(mcnt + 3));
-  if (c->P.method == 2 && c->bricks_for_voxels && !c->K.no_direct_labels) {
-    vgs_status sl = vgs_point_labels_direct(c, c->vox_label.p, c->pt_label.p);   // input order, coalesced (voxelize.hip)
-    if (sl != VGS_OK) return sl;
-  } else {
-    hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
-                       N, c->pt_label.p);
-  }
-  VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+  // (Round 4 measured the scatter-free alternative -- the point's octree key formed again from its coordinates, its voxel from the
+  // brick table, label[p] written in input order: 0.26 ms against this kernel's 0.14 ms at 10 M points.  PCL's key arithmetic is
+  // double precision -- three fp64 divisions per point -- and that costs more than the 4-byte scatter saves.)
+  hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
+                     N, c->pt_label.p);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));
+  c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());
   // one read-back: words 1-3 = re-attachments, roots, kept segments
   uint64_t hm[4] = {0, 0, 0, 0};
   VGS_READBACK(c, hm, mcnt, sizeof(hm));
-  { float lms = 0.f; if (hipEventElapsedTime(&lms, c->ev[2], c->ev[3]) == hipSuccess) c->times[VGS_T_LABELS] = lms; }
+  { float lms = 0.f; if (hipEventElapsedTime(&lms, c->ev[14], c->ev[15]) == hipSuccess) c->times[VGS_T_LABELS] = lms; }
   const unsigned int n_roots = (unsigned int)hm[2];
   if (U > 0 && n_cand > 0) n_succ = (unsigned int)hm[1];
   c->counts[VGS_N_REATTACHED] = n_succ;

@@ -427,6 +427,8 @@ vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* 
   if (!c || (n_roots > 0 && (!root || !label))) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED || c->bnd_unique < 0) { c->err = "vgs_apply_tile_labels: vgs_get_boundary_roots first"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
+  // these kernels rewrite pt_label in place: a download that was opened on it must be through first
+  if (c->d2h_open && c->d2h_src == c->pt_label.p) { VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }
   const int64_t V = c->V, N = c->N;
   if (V == 0) return VGS_OK;
   const int TB = 256;
@@ -453,6 +455,8 @@ vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* 
                      c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));   // label downloads order themselves behind this (vgs_get_point_labels_async)
+  c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->bnd_unique = -1;  // bnd_root2 was reused
@@ -483,6 +487,8 @@ vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t* root, const int32_t*
   if (!c || (n_roots > 0 && (!root || !label))) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED) { c->err = "vgs_apply_root_labels: segment first"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
+  // these kernels rewrite pt_label in place: a download that was opened on it must be through first
+  if (c->d2h_open && c->d2h_src == c->pt_label.p) { VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }
   const int64_t V = c->V, N = c->N;
   if (V == 0) return VGS_OK;
   std::vector<int32_t> map((size_t)V, -1);
@@ -497,6 +503,8 @@ vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t* root, const int32_t*
                      c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));   // label downloads order themselves behind this (vgs_get_point_labels_async)
+  c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VGS_OK;

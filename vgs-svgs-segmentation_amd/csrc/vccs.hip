@@ -537,7 +537,6 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->counters.ensure(64));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
-  c->bricks_for_voxels = false;
   // the 26-neighbour table (its 1-ring normals are overwritten by the 2-ring ones)
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
                      c->vc_nbr.p, nrm.p);

@@ -90,7 +90,6 @@ struct VgsKnobs {
   bool no_overlap = false;   // VGS_NO_OVERLAP
   bool no_near = false;      // VGS_NO_NEAR
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
-  bool no_direct_labels = false;  // VGS_NO_DIRECT_LABELS: per-point labels through the sorted order (the scatter kernel)
   bool debug = false;        // VGS_DEBUG
 };
 
@@ -117,6 +116,7 @@ struct vgs_ctx {
   bool staged = false;         // a cloud is on its way into xyz_buf[1 - xyz_cur]
   int64_t staged_n = 0;
   int staged_stride = 12;
+  bool labels_event_valid = false;   // ev[15] has been recorded behind the last kernel that wrote pt_label
   bool d2h_open = false;       // vgs_get_point_labels_async has a copy in flight ...
   const int32_t* d2h_src = nullptr;   // ... out of this buffer
   int64_t N = 0;
@@ -149,7 +149,6 @@ struct vgs_ctx {
   DevBuf<uint64_t> hkey;
   DevBuf<uint32_t> hval;
   uint32_t hbits = 0;
-  bool bricks_for_voxels = false;   // the brick table in hkey was built from the current voxel table with the voxels as nodes (method 2's adjacency stage)
   DevBuf<int32_t> offsets;  // packed dx,dy,dz
   DevBuf<uint64_t> adj_masks;  // ball cells per (voxel position in its brick, brick offset): k_adjacency_masks
   int adj_mask_nb = 0;         // bricks per axis the ball can touch (0 = no mask table)
@@ -205,7 +204,7 @@ struct vgs_ctx {
 
   int64_t counts[VGS_N_COUNTS] = {0};
   double times[VGS_T_COUNT] = {0};
-  hipEvent_t ev[14] = {nullptr};
+  hipEvent_t ev[16] = {nullptr};   // 14, 15: the label tail of the merge stage (VGS_T_LABELS); 15 also orders label downloads behind the label kernel
   hipEvent_t tev[VGS_T_COUNT][2] = {{nullptr}};   // stage timers: begin / end of every stage, read lazily (capi.hip: timed)
   bool tev_pending[VGS_T_COUNT] = {false};
 
@@ -272,7 +271,6 @@ void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only
 
 // stage implementations (one .hip file each)
 vgs_status vgs_stage_voxelize(vgs_ctx* c);
-vgs_status vgs_point_labels_direct(vgs_ctx* c, const int32_t* vox_label, int32_t* label);   // voxelize.hip; needs c->bricks_for_voxels
 vgs_status vgs_stage_features(vgs_ctx* c);
 vgs_status vgs_stage_adjacency(vgs_ctx* c);
 vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t* out_cnt, uint32_t* out_nall, float r2, const uint32_t* ids = nullptr,

@@ -253,43 +253,6 @@ __global__ void k_gather_points(const float* __restrict__ xyz, int stride_f, con
 
 __global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 
-// Per-point labels in INPUT order without a scatter: the point's octree key is formed again from its coordinates (as k_make_codes
-// does), the voxel in that lattice cell comes from the brick table of the adjacency stage (a few MB, L2 resident: one probe + a
-// popcount), its label from vox_label -- 12 B read and 4 B written per point, both coalesced.  The sorted-order kernel it replaces
-// (label[perm[j]] = vox_label[pt_vox[j]]) wrote every label into a cache line of its own: 0.142 ms for 10 M points.
-#include "brick_table.hpp"
-__global__ void k_point_labels_direct(const float* __restrict__ xyz, int stride_f, int64_t n, const GrowState* __restrict__ gs, double res,
-                                      const Brick* __restrict__ bricks, uint32_t hbits, const int32_t* __restrict__ vox_label,
-                                      int32_t* __restrict__ label) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = xyz + i * stride_f;
-  const float x = p[0], y = p[1], z = p[2];
-  int32_t out = -1;
-  if (finite3(x, y, z)) {
-    int e = gs->n_epochs - 1;
-    while (e > 0 && i < gs->epochs[e].first) --e;
-    const Epoch& ep = gs->epochs[e];
-    const uint32_t kx = vm_axis_key(x, ep.min[0], res) + (uint32_t)(gs->shift[0] - ep.shift[0]);
-    const uint32_t ky = vm_axis_key(y, ep.min[1], res) + (uint32_t)(gs->shift[1] - ep.shift[1]);
-    const uint32_t kz = vm_axis_key(z, ep.min[2], res) + (uint32_t)(gs->shift[2] - ep.shift[2]);
-    bool used_flag;
-    const int v = brick_find(bricks, hbits, kx, ky, kz, &used_flag);
-    if (v >= 0) out = vox_label[v];
-  }
-  label[i] = out;
-}
-
-// merge stage (method 2): labels of the points the voxel table was built from; the brick table must be the voxels' (bricks_for_voxels)
-vgs_status vgs_point_labels_direct(vgs_ctx* c, const int32_t* vox_label, int32_t* label) {
-  const int64_t N = c->N;
-  if (N == 0) return VGS_OK;
-  const int TB = 256;
-  hipLaunchKernelGGL(k_point_labels_direct, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N,
-                     (const GrowState*)c->grow_state.p, c->box.res, (const Brick*)c->hkey.p, c->hbits, vox_label, label);
-  return VGS_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------------
@@ -395,7 +358,6 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
 vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   const int64_t N = c->N;
   c->V = 0; c->Nf = 0; c->U = 0;
-  c->bricks_for_voxels = false;   // a new voxel table: the brick table (if any) belongs to the last one
   vgs_status st = grow_box(c);
   if (st != VGS_OK) return st;
   if (c->n_epochs == 0) {  // no finite point at all
