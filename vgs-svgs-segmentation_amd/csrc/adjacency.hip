@@ -419,6 +419,19 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   }
   std::vector<int32_t> packed(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
+  {
+    // packed 15-bit offset (dx+16) | (dy+16) << 5 | (dz+16) << 10, as the rows' adj_off holds it -> index in the ball (conn_bits)
+    std::vector<uint16_t> lut(32768, (uint16_t)0xffffu);
+    if (R <= 15)
+      for (size_t k = 0; k < offs.size(); ++k) {
+        const int32_t pk = offs[k].second;
+        const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
+        lut[(size_t)((dx + 16) | ((dy + 16) << 5) | ((dz + 16) << 10))] = (uint16_t)k;
+      }
+    VGS_HIP_TRY(c, c->off2idx.ensure(lut.size()));
+    VGS_HIP_TRY(c, hipMemcpy(c->off2idx.p, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->cb_words = ((int)offs.size() + 31) / 32;
+  }
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
   VGS_HIP_TRY(c, hipMemcpy(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   c->adj_stride = c->n_off;

@@ -509,6 +509,27 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 #define DN_SMALL 128, LD_SMALL_LCAP, 2048, 256   // hand-overs of the one-wavefront classes
 #define DN_LARGE 512, 4096, 2048, 512   // hand-overs of classes C and D up to 512 neighbours
 
+// Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
+// per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
+__global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pending, int64_t U, const uint32_t* __restrict__ adj_cnt, int adj_stride,
+                                                  const uint8_t* __restrict__ conn, const uint16_t* __restrict__ adj_off,
+                                                  const uint16_t* __restrict__ off2idx, int cb_words, uint32_t* __restrict__ cbits) {
+  __shared__ uint32_t cb[256];
+  const int64_t u = (int64_t)blockIdx.x;
+  if (u >= U || !pending[u]) return;
+  const int lane = threadIdx.x;
+  for (int k = lane; k < cb_words; k += 64) cb[k] = 0u;
+  __syncthreads();
+  const int n = (int)adj_cnt[u];
+  const uint8_t* crow = conn + u * adj_stride;
+  const uint16_t* orow = adj_off + u * adj_stride;
+  if (orow[0] != 0xffffu)
+    for (int c = lane; c < n; c += 64)
+      if (crow[c]) { const uint32_t idx = off2idx[orow[c]]; if (idx != 0xffffu) atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
+  __syncthreads();
+  for (int k = lane; k < cb_words; k += 64) cbits[(size_t)u * (size_t)cb_words + k] = cb[k];
+}
+
 // split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.
 // Class A (the bulk) is split once more: voxels with few heavy near pairs of their own (short near-pair list) are the
 // ones the lazy schedule works on for long or gives up on, so they form class A1, the part of the bulk launch that is
@@ -725,6 +746,13 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.pending = c->lc_pending.p;
   const bool dense = !c->K.no_dense;   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
   WP.near_min_own = c->K.near_min_own;
+  // connect bits for crossValidation's lattice lookup: voxel lattice (method 2), rows with lattice offsets, a ball that fits the LUT
+  c->cb_enabled = c->P.method == 2 && c->adj_have_off && c->cb_words > 0 && c->cb_words <= 256 && c->adj_R <= 15 && !c->K.no_connbits;
+  WP.cbits = nullptr; WP.off2idx = nullptr; WP.cb_words = 0;
+  if (c->cb_enabled) {
+    VGS_HIP_TRY(c, c->conn_bits.ensure((size_t)U * (size_t)c->cb_words));
+    WP.cbits = c->conn_bits.p; WP.off2idx = c->off2idx.p; WP.cb_words = c->cb_words;
+  }
   WP.ho_bins = dense ? LW_HO_BINS : 1;
   WP.ho_stride = (int)U;
   {
@@ -849,6 +877,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   if (c->K.no_overlap) {   // diagnostics: the merge stage starts behind the hand-over kernels
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
+    if (c->cb_enabled)   // (the pending marks are about to go: the handed-over voxels' connect bits now; what vgs_localcut_finish still sends on falls back to the search)
+      hipLaunchKernelGGL(k_conn_bits, dim3((unsigned)U), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
+                         c->off2idx.p, c->cb_words, c->conn_bits.p);
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
   c->lc_tail.grid_f = grid_f;
@@ -958,6 +989,12 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     VGS_HIP_TRY(c, hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->lc_diag[8] = (int64_t)n_xl;
+  }
+  if (c->cb_enabled && (nf > 0 || c->K.dbg_max_m > 0)) {
+    // the hand-over kernels are through: their voxels' connect bits (a grid over all rows; all but the pending ones leave at once)
+    hipLaunchKernelGGL(k_conn_bits, dim3((unsigned)U), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
+                       c->off2idx.p, c->cb_words, c->conn_bits.p);
+    VGS_HIP_TRY(c, hipGetLastError());
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
   c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;

@@ -91,6 +91,10 @@ struct LwParams {
   int near_min_own; // multi-wavefront classes: first shells from the near-pair lists only if the vertices' lists hold this many entries on average
   int ho_bins;      // one-wavefront classes: hand-over lists by neighbourhood size (LW_HO_BINS, largest first) or 1
   int ho_stride;    // distance between those lists in the hand-over array (= the number of used voxels)
+  // the connect list once more as a bit per ball offset, for crossValidation's lattice lookup (vgs_context.hpp: conn_bits); null: off
+  uint32_t* cbits;
+  const uint16_t* off2idx;
+  int cb_words;
 };
 
 // The hand-over kernel's cost grows with the square of the neighbourhood size and its launch ends with the slowest voxel:
@@ -1090,6 +1094,21 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   {
     const int s0 = seg[0];
     for (int c = lane; c < m; c += 64) crow[c] = ((int)seg[c] == s0) ? 1 : 0;   // the whole row: nobody zeroes the table first
+    if (P.cbits) {
+      // ... and as bits by ball offset (the edge list's LDS is free now): all words of the row are written, zeros when the row
+      // carries no lattice offsets (bit 0 -- the voxel itself, always a member -- then says "no bits": the reader searches instead)
+      uint32_t* const cb = (uint32_t*)lk;
+      static_assert(sizeof(uint64_t) * LCAP >= 4 * 256, "the bit row (<= 8192 offsets) fits the edge list");
+      wave_sync();
+      for (int k = lane; k < P.cb_words; k += 64) cb[k] = 0u;
+      wave_sync();
+      if (orow != nullptr && orow[0] != 0xffffu)
+        for (int c = lane; c < m; c += 64)
+          if ((int)seg[c] == s0) { const uint32_t idx = P.off2idx[orow[c]]; if (idx != 0xffffu) atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
+      wave_sync();
+      uint32_t* const out = P.cbits + (size_t)u * (size_t)P.cb_words;
+      for (int k = lane; k < P.cb_words; k += 64) out[k] = cb[k];
+    }
   }
   if (lane == 0) evals_out[u] = n_evals;  // summed on the host on request: no same-address atomics on the hot path
 #ifdef VGS_PROF

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               uint32_t* __restrict__ csize, uint32_t* __restrict__ parent,
                                               const uint16_t* __restrict__ gtab, int gstride, const uint8_t* __restrict__ nrank, float inv_res2,
                                               const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
-                                              unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work) {
+                                              unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work,
+                                              const uint16_t* __restrict__ adj_off, const uint16_t* __restrict__ off2idx,
+                                              const uint32_t* __restrict__ cbits, int cb_words) {
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
   // (work != null): the rows put off.
@@ -76,6 +78,11 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   for (int k = sub; k < n; k += W) len += crow[k] ? 1 : 0;
   for (int o = W / 2; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);   // xor with o < W stays inside the row's lanes
   const bool own_tab = gtab && gtab[u * gstride] != 0xffffu;
+  // lattice lookup (round 4): the neighbour t sits at ball offset o from i, so "i in L0(t)" is the bit of the NEGATED offset in t's row
+  // of connect bits -- two dependent loads (t's row index, the word) instead of the chain rank -> group table -> binary search over
+  // 8-byte keys -> flag.  A row without lattice offsets (its own, or t's: bit 0 clear) takes the search below.
+  const uint16_t* orow = (cbits != nullptr && adj_off != nullptr) ? adj_off + u * adj_stride : nullptr;
+  const bool own_bits = orow != nullptr && orow[0] != 0xffffu;
   int kept = 0;
   uint32_t best = i;  // first hook of the union-find (see k_cc_init): smallest mutual neighbour below i
   for (int k = sub; k < n; k += W) {
@@ -87,7 +94,21 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
         mflag = 1;
       } else {
         const uint32_t ut = used_rank[t];
-        if (ut != 0xffffffffu) {
+        bool by_bits = false;
+        if (ut != 0xffffffffu && own_bits) {
+          const uint32_t p = orow[k];
+          const uint32_t pn = (32u - (p & 31u)) | ((32u - ((p >> 5) & 31u)) << 5) | ((32u - ((p >> 10) & 31u)) << 10);   // the offset negated, field by field
+          const uint32_t idx = off2idx[pn & 0x7fffu];
+          const uint32_t* trow_bits = cbits + (size_t)ut * (size_t)cb_words;
+          const uint32_t w0 = trow_bits[0];
+          if ((w0 & 1u) && idx != 0xffffu) {
+            by_bits = true;
+            if (pending && pending[ut]) touches_pending = true;
+            const uint32_t wd = (idx >> 5) == 0u ? w0 : trow_bits[idx >> 5];
+            mflag = (uint8_t)((wd >> (idx & 31u)) & 1u);
+          }
+        }
+        if (ut != 0xffffffffu && !by_bits) {
           if (pending && pending[ut]) touches_pending = true;
           const uint64_t want = (key & 0xffffffff00000000ull) | (uint64_t)i;
           const uint64_t* trow = adj_key + (int64_t)ut * adj_stride;
@@ -449,11 +470,17 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     const float inv_res2 = 1.0f / (c->P.voxel_size * c->P.voxel_size);
     uint32_t* cross_parent = c->have_region ? nullptr : c->parent.p;
     unsigned int* d_ndefer = (unsigned int*)(c->counters.p + 13);   // zeroed with the local cut's counters
+    // connect bits of the cuts (method 2, rows with lattice offsets): the lattice lookup of k_cross
+    const bool use_bits = c->cb_enabled && c->P.method == 2 && c->adj_have_off;
+    const uint16_t* cb_off = use_bits ? c->adj_off.p : (const uint16_t*)nullptr;
+    const uint16_t* cb_lut = use_bits ? c->off2idx.p : (const uint16_t*)nullptr;
+    const uint32_t* cb_bits = use_bits ? c->conn_bits.p : (const uint32_t*)nullptr;
     // crossValidation starts while the hand-over kernels of the local cut still run (vgs_stage_localcut): rows that touch a
     // handed-over voxel are put off, ...
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
-                       c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0);
+                       c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0,
+                       cb_off, cb_lut, cb_bits, c->cb_words);
     // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
     unsigned int n_defer = 0;
     {
@@ -463,7 +490,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     if (n_defer > 0)
       hipLaunchKernelGGL(k_cross, dim3((n_defer + CX_ROWS - 1) / CX_ROWS), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
-                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer);
+                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words);
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
     unsigned int* d_ncand = (unsigned int*)(mcnt + 0);

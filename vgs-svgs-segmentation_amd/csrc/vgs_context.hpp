@@ -90,6 +90,7 @@ struct VgsKnobs {
   bool no_overlap = false;   // VGS_NO_OVERLAP
   bool no_near = false;      // VGS_NO_NEAR
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
+  bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool debug = false;        // VGS_DEBUG
 };
 
@@ -167,6 +168,14 @@ struct vgs_ctx {
   DevBuf<uint64_t> adj_key;
   DevBuf<uint16_t> adj_off;   // per row entry: packed lattice offset from the row's voxel, (dx+16) | (dy+16) << 5 | (dz+16) << 10; row[0] = 0xffff: none
   bool adj_have_off = false;
+  // crossValidation through the lattice (round 4): every cut also leaves its connect list as a BIT per ball offset (conn_bits: U rows
+  // of cb_words words, bit k = the neighbour at ball offset k is in the list; bit 0 = the voxel itself = "this row has bits"), so
+  // "is i in L0(k)?" is one bit of k's row at the index of the negated offset instead of a search in k's 8-byte keys.
+  // off2idx: packed 15-bit lattice offset (adj_off's format) -> ball index (0xffff: not in the ball)
+  DevBuf<uint16_t> off2idx;
+  DevBuf<uint32_t> conn_bits;
+  int cb_words = 0;
+  bool cb_enabled = false;     // the cuts of this run wrote conn_bits
   DevBuf<uint32_t> adj_cnt, adj_mused;  // per used voxel: stored row length, number of ALL neighbours
   bool adj_pruned = false;              // rows hold used neighbours only
   float adj_r2 = 0.f;
