@@ -30,7 +30,7 @@ def _native(tmp_path, parts, mode, tiles, pitch, env=None):
     return world, kept, labels, nrec
 
 
-@pytest.mark.parametrize("tiles,n_per", [((2, 1), 150_000), ((2, 2), 120_000)], ids=["2x1", "2x2"])
+@pytest.mark.parametrize("tiles,n_per", [((2, 1), 150_000), ((2, 2), 120_000), ((4, 2), 60_000)], ids=["2x1", "2x2", "4x2"])
 def test_native_driver_equals_the_python_twin(gpu, tmp_path, tiles, n_per):
     world = tiles[0] * tiles[1]
     pitch = 50.0 * np.sqrt(n_per / 10_000_000)

@@ -9,8 +9,12 @@
 
 // NLB_G voxels per wavefront: the candidates of all of them that pass the cheap tests (lattice reach, centroid distance)
 // are queued in LDS, so that the expensive part -- the weight -- runs on full wavefronts (a voxel alone fills a third of one).
+#ifndef NLB_G
 #define NLB_G 8
+#endif
+#ifndef NLB_QCAP
 #define NLB_QCAP 512
+#endif
 __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                    const uint32_t* __restrict__ adj_cnt, int adj_stride, const NodeRec* __restrict__ node,
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
