@@ -511,12 +511,20 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
+// lists != null: workgroup b takes entry b of the concatenation of the (up to 5) hand-over lists; otherwise every pending row of [0, U)
+struct CbLists { const uint32_t* ids[5]; unsigned int end[5]; };   // end[k] = number of entries in lists 0 .. k
 __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pending, int64_t U, const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                   const uint8_t* __restrict__ conn, const uint16_t* __restrict__ adj_off,
-                                                  const uint16_t* __restrict__ off2idx, int cb_words, uint32_t* __restrict__ cbits) {
+                                                  const uint16_t* __restrict__ off2idx, int cb_words, uint32_t* __restrict__ cbits, CbLists L, int use_lists) {
   __shared__ uint32_t cb[256];
-  const int64_t u = (int64_t)blockIdx.x;
-  if (u >= U || !pending[u]) return;
+  int64_t u = (int64_t)blockIdx.x;
+  if (use_lists) {
+    const unsigned int b = blockIdx.x;
+    int k = 0;
+    while (k < 4 && b >= L.end[k]) ++k;
+    if (b >= L.end[k]) return;
+    u = (int64_t)L.ids[k][b - (k ? L.end[k - 1] : 0u)];
+  } else if (u >= U || !pending[u]) return;
   const int lane = threadIdx.x;
   for (int k = lane; k < cb_words; k += 64) cb[k] = 0u;
   __syncthreads();
@@ -877,9 +885,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   if (c->K.no_overlap) {   // diagnostics: the merge stage starts behind the hand-over kernels
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
-    if (c->cb_enabled)   // (the pending marks are about to go: the handed-over voxels' connect bits now; what vgs_localcut_finish still sends on falls back to the search)
+    if (c->cb_enabled)   // (the pending marks are about to go: the handed-over voxels' connect bits now)
       hipLaunchKernelGGL(k_conn_bits, dim3((unsigned)U), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
-                         c->off2idx.p, c->cb_words, c->conn_bits.p);
+                         c->off2idx.p, c->cb_words, c->conn_bits.p, CbLists{}, 0);
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
   c->lc_tail.grid_f = grid_f;
@@ -990,10 +998,16 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->lc_diag[8] = (int64_t)n_xl;
   }
-  if (c->cb_enabled && (nf > 0 || c->K.dbg_max_m > 0)) {
-    // the hand-over kernels are through: their voxels' connect bits (a grid over all rows; all but the pending ones leave at once)
-    hipLaunchKernelGGL(k_conn_bits, dim3((unsigned)U), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
-                       c->off2idx.p, c->cb_words, c->conn_bits.p);
+  if (c->cb_enabled && nf > 0) {
+    // the hand-over kernels are through: their voxels' connect bits, one workgroup per entry of the hand-over lists (whatever was
+    // sent on to the general or the extra-large kernel is in these lists too)
+    CbLists L;
+    const unsigned int nb4[4] = {(unsigned int)(hc[14] & 0xffffffffull), (unsigned int)(hc[14] >> 32), (unsigned int)(hc[15] & 0xffffffffull), (unsigned int)(hc[15] >> 32)};
+    unsigned int at = 0;
+    for (int k = 0; k < 4; ++k) { L.ids[k] = ids_f + (size_t)k * U; at += nb4[k]; L.end[k] = at; }
+    L.ids[4] = ids_g; at += nfg[1]; L.end[4] = at;
+    hipLaunchKernelGGL(k_conn_bits, dim3(at), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
+                       c->off2idx.p, c->cb_words, c->conn_bits.p, L, 1);
     VGS_HIP_TRY(c, hipGetLastError());
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels

@@ -229,6 +229,7 @@ struct vgs_ctx {
   // VCCS-style supervoxel stage
   DevBuf<float> vc_cen, vc_nrm, vc_dist, vc_state;
   DevBuf<int32_t> vc_nbr, vc_label;
+  DevBuf<int16_t> vc_nbr16;   // vc_nbr as 16-bit rank differences (vccs.hip: k_vccs_neighbours)
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
   DevBuf<uint32_t> vc_count;
