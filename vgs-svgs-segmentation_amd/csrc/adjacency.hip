@@ -364,8 +364,11 @@ bool vgs_unused_are_inert(const vgs_params& p) {
 }
 
 static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
-  vgs_status bs = vgs_build_bricks(c, c->node.p);
-  if (bs != VGS_OK) return bs;
+  if (!c->bricks_ready) {   // (the features stage usually has queued it behind its read-back)
+    vgs_status bs = vgs_build_bricks(c, c->node.p);
+    if (bs != VGS_OK) return bs;
+  }
+  c->bricks_ready = false;   // good for one adjacency stage: a later one (new graph_size, tiles) builds its own
   // ball of lattice offsets, ascending integer d2 (a superset of what the float predicate keeps)
   const double r = (double)c->P.graph_size;
   const double res = (double)c->P.voxel_size;
@@ -420,17 +423,15 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
   std::vector<int32_t> packed(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) packed[k] = offs[k].second;
   {
-    // packed 15-bit offset (dx+16) | (dy+16) << 5 | (dz+16) << 10, as the rows' adj_off holds it -> index in the ball (conn_bits)
-    std::vector<uint16_t> lut(32768, (uint16_t)0xffffu);
-    if (R <= 15)
-      for (size_t k = 0; k < offs.size(); ++k) {
-        const int32_t pk = offs[k].second;
-        const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
-        lut[(size_t)((dx + 16) | ((dy + 16) << 5) | ((dz + 16) << 10))] = (uint16_t)k;
-      }
-    VGS_HIP_TRY(c, c->off2idx.ensure(lut.size()));
-    VGS_HIP_TRY(c, hipMemcpy(c->off2idx.p, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    c->cb_words = ((int)offs.size() + 31) / 32;
+    // connect bits (vgs_context.hpp): one bit per cell of the cube of side 2 Rm + 1 around a voxel, Rm = the ball's largest offset
+    int Rm = 0;
+    for (const auto& o : offs) {
+      const int32_t pk = o.second;
+      Rm = std::max(Rm, std::max(std::abs((int)(int8_t)(pk & 0xff)), std::max(std::abs((int)(int8_t)((pk >> 8) & 0xff)), std::abs((int)(int8_t)((pk >> 16) & 0xff)))));
+    }
+    c->cb_R = Rm;
+    const int D = 2 * Rm + 1;
+    c->cb_words = (D * D * D + 31) / 32;
   }
   VGS_HIP_TRY(c, c->offsets.ensure(packed.size()));
   VGS_HIP_TRY(c, hipMemcpy(c->offsets.p, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -193,7 +193,8 @@ vgs_status vgs_create(const vgs_params* p, vgs_ctx** out) {
   bool ok = hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&c->ev_d2h, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&c->ev_d2h, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < 16; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
   for (int i = 0; ok && i < VGS_T_COUNT; ++i) ok = hipEventCreate(&c->tev[i][0]) == hipSuccess && hipEventCreate(&c->tev[i][1]) == hipSuccess;
   if (!ok) { g_create_err = "vgs_create: hipStreamCreate/hipEventCreate failed"; vgs_destroy(c); return VGS_E_HIP; }   // frees what exists
@@ -220,7 +221,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_off.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->nl_cnt.release(); c->nl_tot.release(); c->nl_ent.release(); c->lc_ctab.release();
   c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
-  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr16.release(); c->vc_label.release();
+  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_label.release();
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release(); c->vc_accu.release(); c->vc_live.release(); c->vc_alive.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();
@@ -237,6 +238,7 @@ void vgs_destroy(vgs_ctx* c) {
   if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
   if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
   if (c->ev_h2d) (void)hipEventDestroy(c->ev_h2d);
+  if (c->ev_rb) (void)hipEventDestroy(c->ev_rb);
   if (c->ev_d2h) (void)hipEventDestroy(c->ev_d2h);
   delete c;
 }

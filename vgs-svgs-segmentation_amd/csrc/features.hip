@@ -13,6 +13,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "vgs_context.hpp"
+#include "brick_table.hpp"
 
 #define FEAT_TB 256
 #define FEAT_TILE 2048
@@ -133,7 +134,17 @@ vgs_status vgs_stage_features(vgs_ctx* c) {
   unsigned long long* d_nu = (unsigned long long*)(c->counters.p + 36);
   hipLaunchKernelGGL(k_compact_used, dim3(nb), dim3(FEAT_TB), 0, c->stream, used_flag, excl, V, c->used_ids.p, c->used_rank.p, d_nu);
   unsigned long long nu = 0;
-  VGS_READBACK(c, &nu, d_nu, 8);
+  c->bricks_ready = false;
+  if (c->P.method == 2 && vgs_can_split_readback(c)) {
+    // the brick table of the adjacency stage needs the voxel codes and the used flags, not the count: it is built while the host
+    // fetches the count (vgs_stage_adjacency finds bricks_ready and skips its own build)
+    { vgs_status sb = vgs_readback_begin(c, d_nu, 8); if (sb != VGS_OK) return sb; }
+    { vgs_status bs = vgs_build_bricks(c, c->node.p); if (bs != VGS_OK) return bs; }
+    c->bricks_ready = true;
+    { vgs_status se = vgs_readback_end(c, &nu, 8); if (se != VGS_OK) return se; }
+  } else {
+    VGS_READBACK(c, &nu, d_nu, 8);
+  }
   VGS_HIP_TRY(c, hipGetLastError());
   c->U = (int64_t)nu;
   c->counts[VGS_N_USED] = c->U;

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 struct CbLists { const uint32_t* ids[5]; unsigned int end[5]; };   // end[k] = number of entries in lists 0 .. k
 __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pending, int64_t U, const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                   const uint8_t* __restrict__ conn, const uint16_t* __restrict__ adj_off,
-                                                  const uint16_t* __restrict__ off2idx, int cb_words, uint32_t* __restrict__ cbits, CbLists L, int use_lists) {
+                                                  int cb_R, int cb_words, uint32_t* __restrict__ cbits, CbLists L, int use_lists) {
   __shared__ uint32_t cb[256];
   int64_t u = (int64_t)blockIdx.x;
   if (use_lists) {
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
   const uint16_t* orow = adj_off + u * adj_stride;
   if (orow[0] != 0xffffu)
     for (int c = lane; c < n; c += 64)
-      if (crow[c]) { const uint32_t idx = off2idx[orow[c]]; if (idx != 0xffffu) atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
+      if (crow[c]) { const uint32_t idx = vgs_cb_index(orow[c], cb_R); atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
   __syncthreads();
   for (int k = lane; k < cb_words; k += 64) cbits[(size_t)u * (size_t)cb_words + k] = cb[k];
 }
@@ -575,6 +575,24 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
   uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1};
   for (int k = 0; k < LC_NCLASS; ++k)
     if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
+}
+
+// Class sizes alone (A and A1 together): what the host needs to size the launches does not depend on the near-pair lists, so it is
+// counted BEFORE they are built and fetched while they are (vgs_stage_localcut).
+__global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restrict__ adj_cnt, int64_t U, int max_a, int max_b, int max_c,
+                                                        unsigned int* __restrict__ n_cls /* 4 */) {
+  __shared__ unsigned int s_cnt[4];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int cls = -1;
+  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3)); }
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long mk = __ballot(cls == k);
+    if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_cnt[k], (unsigned int)__popcll(mk));
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // Smallest squared distance (to the bisection's resolution) whose weight bound is at or below a singleton's threshold:
@@ -702,6 +720,20 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
     constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
+  // The host sizes the launches from the class sizes; only the split of the bulk class into A1 / A needs the near-pair lists.  So
+  // the sizes are counted first and fetched WHILE the lists are built (0.4 ms), and the bulk launch reads its split on the device
+  // (round 4: the read-back behind k_classify left the GPU idle for 50 us in front of the bulk kernel).
+#ifdef VGS_PROF
+  const bool early_sizes = false;   // (VGS_ONLY_CLASS edits the host's counts)
+#else
+  const bool early_sizes = vgs_can_split_readback(c);
+#endif
+  unsigned int* d_ncls = (unsigned int*)(c->counters.p + 44);   // words 44-45: A + A1, B, C, D
+  if (early_sizes) {
+    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, d_ncls);
+    vgs_status sb = vgs_readback_begin(c, d_ncls, 16);
+    if (sb != VGS_OK) return sb;
+  }
   {
     // near-pair lists for the shells of the one-wavefront classes closest to the voxel (nearlist.hip); built on the main
     // stream before the classes are formed (the split of class A reads the list lengths) and before the side streams fork
@@ -713,7 +745,17 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                      0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, c->nl_tot.p, a1_max, ids_a, ids_b, ids_c,
                      ids_d, ids_a1, d_nabc);
   unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
-  VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
+  unsigned int n_bulk = 0;   // A + A1
+  if (early_sizes) {
+    unsigned int ncls[4] = {0, 0, 0, 0};
+    vgs_status se = vgs_readback_end(c, ncls, 16);
+    if (se != VGS_OK) return se;
+    n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3];
+    nabc[0] = n_bulk; nabc[4] = 0;   // (host-side bookkeeping only: the kernel reads the split from d_nabc)
+  } else {
+    VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
+    n_bulk = nabc[0] + nabc[4];
+  }
 #ifdef VGS_PROF
   if (c->K.only_class >= 0) {  // diagnostics: run a single class (results are incomplete)
     for (int k = 0; k < LC_NCLASS; ++k) if (k != c->K.only_class) nabc[k] = 0;
@@ -756,10 +798,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   WP.near_min_own = c->K.near_min_own;
   // connect bits for crossValidation's lattice lookup: voxel lattice (method 2), rows with lattice offsets, a ball that fits the LUT
   c->cb_enabled = c->P.method == 2 && c->adj_have_off && c->cb_words > 0 && c->cb_words <= 256 && c->adj_R <= 15 && !c->K.no_connbits;
-  WP.cbits = nullptr; WP.off2idx = nullptr; WP.cb_words = 0;
+  WP.cbits = nullptr; WP.cb_R = 0; WP.cb_words = 0;
+  WP.n_first_dev = nullptr; WP.n_main_dev = nullptr;
   if (c->cb_enabled) {
     VGS_HIP_TRY(c, c->conn_bits.ensure((size_t)U * (size_t)c->cb_words));
-    WP.cbits = c->conn_bits.p; WP.off2idx = c->off2idx.p; WP.cb_words = c->cb_words;
+    WP.cbits = c->conn_bits.p; WP.cb_R = c->cb_R; WP.cb_words = c->cb_words;
   }
   WP.ho_bins = dense ? LW_HO_BINS : 1;
   WP.ho_stride = (int)U;
@@ -853,9 +896,16 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // long-running wavefronts start first, the light ones fill the tail.  (Running A1 as a launch of its own with its
   // hand-overs on a side stream was measured: the 34 KB workgroups of the hand-over kernel starve beside the bulk.  So was
   // a 1024-edge list for A1: 40 % fewer hand-overs, but the step gets slower.)
-  if (nabc[0] + nabc[4] > 0)
-    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0])), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
-                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
+  if (n_bulk > 0) {
+    LwParams WPA = WP;
+    unsigned int grid_a = vgs_xcd_grid(nabc[4]) + vgs_xcd_grid(nabc[0]);
+    if (early_sizes) {   // the two list lengths are on the device: roundup8(a) + roundup8(b) <= roundup8(a + b) + 8
+      WPA.n_first_dev = d_nabc + 4; WPA.n_main_dev = d_nabc + 0;
+      grid_a = vgs_xcd_grid(n_bulk) + 8u;
+    }
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_A, LCAP_A>), dim3(grid_a), dim3(64), 0, c->stream, ids_a1, (int)nabc[4],
+                       ids_a, (int)nabc[0], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WPA, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
+  }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
   // trip before the launch); the host checks the length afterwards (vgs_localcut_finish).  The kernel runs on the side
@@ -887,7 +937,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
     if (c->cb_enabled)   // (the pending marks are about to go: the handed-over voxels' connect bits now)
       hipLaunchKernelGGL(k_conn_bits, dim3((unsigned)U), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
-                         c->off2idx.p, c->cb_words, c->conn_bits.p, CbLists{}, 0);
+                         c->cb_R, c->cb_words, c->conn_bits.p, CbLists{}, 0);
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
   c->lc_tail.grid_f = grid_f;
@@ -1007,7 +1057,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     for (int k = 0; k < 4; ++k) { L.ids[k] = ids_f + (size_t)k * U; at += nb4[k]; L.end[k] = at; }
     L.ids[4] = ids_g; at += nfg[1]; L.end[4] = at;
     hipLaunchKernelGGL(k_conn_bits, dim3(at), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
-                       c->off2idx.p, c->cb_words, c->conn_bits.p, L, 1);
+                       c->cb_R, c->cb_words, c->conn_bits.p, L, 1);
     VGS_HIP_TRY(c, hipGetLastError());
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels

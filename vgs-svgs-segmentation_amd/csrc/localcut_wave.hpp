@@ -93,8 +93,11 @@ struct LwParams {
   int ho_stride;    // distance between those lists in the hand-over array (= the number of used voxels)
   // the connect list once more as a bit per ball offset, for crossValidation's lattice lookup (vgs_context.hpp: conn_bits); null: off
   uint32_t* cbits;
-  const uint16_t* off2idx;
+  int cb_R;
   int cb_words;
+  // bulk launch: lengths of the first and the main work list read on the device (the host launches with a grid for their sum); null: n_first / n_work
+  const unsigned int* n_first_dev;
+  const unsigned int* n_main_dev;
 };
 
 // The hand-over kernel's cost grows with the square of the neighbourhood size and its launch ends with the slowest voxel:
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // A hand-over list is launched with a fixed grid while its length is still on the device (n_work_dev).
   // It is taken in plain order, so that a list longer than the grid leaves a suffix for the caller.
   if (n_work_dev) n_work = (int)*n_work_dev;
+  if (P.n_first_dev) { n_first = (int)*P.n_first_dev; n_work = (int)*P.n_main_dev; }
   const unsigned int nb_first = ((unsigned int)n_first + 7u) & ~7u;
   const bool first = blockIdx.x < nb_first;
   const unsigned int bidx = first ? blockIdx.x : blockIdx.x - nb_first;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   const int per_xcd = (n_mine + 7) >> 3;
   const int widx = n_work_dev ? (int)bidx : (int)(bidx & 7u) * per_xcd + (int)(bidx >> 3);
   if (widx >= n_mine) return;
+  if (!n_work_dev && (int)(bidx >> 3) >= per_xcd) return;   // a grid sized for an upper bound of the list (lengths read on the device): surplus workgroups must not wrap into another XCD's share
   const uint32_t u = (first ? work_first : work)[widx];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + (int64_t)u * adj_stride;
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
     for (int c = lane; c < m; c += 64) crow[c] = ((int)seg[c] == s0) ? 1 : 0;   // the whole row: nobody zeroes the table first
     if (P.cbits) {
       // ... and as bits by ball offset (the edge list's LDS is free now): all words of the row are written, zeros when the row
-      // carries no lattice offsets (bit 0 -- the voxel itself, always a member -- then says "no bits": the reader searches instead)
+      // carries no lattice offsets (the centre bit -- the voxel itself, always a member -- then says "no bits": the reader searches instead)
       uint32_t* const cb = (uint32_t*)lk;
       static_assert(sizeof(uint64_t) * LCAP >= 4 * 256, "the bit row (<= 8192 offsets) fits the edge list");
       wave_sync();
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       wave_sync();
       if (orow != nullptr && orow[0] != 0xffffu)
         for (int c = lane; c < m; c += 64)
-          if ((int)seg[c] == s0) { const uint32_t idx = P.off2idx[orow[c]]; if (idx != 0xffffu) atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
+          if ((int)seg[c] == s0) { const uint32_t idx = vgs_cb_index(orow[c], P.cb_R); atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
       wave_sync();
       uint32_t* const out = P.cbits + (size_t)u * (size_t)P.cb_words;
       for (int k = lane; k < P.cb_words; k += 64) out[k] = cb[k];

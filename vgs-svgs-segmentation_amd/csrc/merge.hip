@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint16_t* __restrict__ gtab, int gstride, const uint8_t* __restrict__ nrank, float inv_res2,
                                               const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
                                               unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work,
-                                              const uint16_t* __restrict__ adj_off, const uint16_t* __restrict__ off2idx,
+                                              const uint16_t* __restrict__ adj_off, int cb_R,
                                               const uint32_t* __restrict__ cbits, int cb_words) {
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
@@ -96,15 +96,15 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
         const uint32_t ut = used_rank[t];
         bool by_bits = false;
         if (ut != 0xffffffffu && own_bits) {
-          const uint32_t p = orow[k];
-          const uint32_t pn = (32u - (p & 31u)) | ((32u - ((p >> 5) & 31u)) << 5) | ((32u - ((p >> 10) & 31u)) << 10);   // the offset negated, field by field
-          const uint32_t idx = off2idx[pn & 0x7fffu];
+          const int D = 2 * cb_R + 1;
+          const uint32_t centre = (uint32_t)((cb_R * D + cb_R) * D + cb_R);
+          const uint32_t idx = (uint32_t)(D * D * D - 1) - vgs_cb_index(orow[k], cb_R);   // the negated offset: point symmetry of the cube
           const uint32_t* trow_bits = cbits + (size_t)ut * (size_t)cb_words;
-          const uint32_t w0 = trow_bits[0];
-          if ((w0 & 1u) && idx != 0xffffu) {
+          const uint32_t wc = trow_bits[centre >> 5];
+          if ((wc >> (centre & 31u)) & 1u) {   // t's row has bits (its own voxel is always a member)
             by_bits = true;
             if (pending && pending[ut]) touches_pending = true;
-            const uint32_t wd = (idx >> 5) == 0u ? w0 : trow_bits[idx >> 5];
+            const uint32_t wd = (idx >> 5) == (centre >> 5) ? wc : trow_bits[idx >> 5];
             mflag = (uint8_t)((wd >> (idx & 31u)) & 1u);
           }
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64) void k_cc_init(const uint32_t* __restrict__ use
 __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
-                                                     const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent) {
+                                                     const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent, int do_attach) {
   constexpr int W = 64 / UM_ROWS;
   // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
   const int64_t u = (int64_t)blockIdx.x * UM_ROWS + (threadIdx.x / W);
@@ -309,10 +309,21 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
       uf_union(parent, i, t);
     }
   }
-  if (sub == 0) {
+  if (sub == 0 && do_attach) {
     const int32_t t = attach[i];
     if (t >= 0 && (!owned || owned[i])) uf_union(parent, i, (uint32_t)t);
   }
+}
+
+// the re-attachment edges on their own (closestCheck's candidates only): used when the mutual edges were united while the host
+// was still fetching closestCheck's fixed-point flag
+__global__ void k_union_attach(const uint32_t* __restrict__ cand, int n_cand, const uint32_t* __restrict__ used_ids, const int32_t* __restrict__ attach,
+                               uint32_t* __restrict__ parent) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cand) return;
+  const uint32_t i = used_ids[cand[j]];
+  const int32_t t = attach[i];
+  if (t >= 0) uf_union(parent, i, (uint32_t)t);
 }
 
 // pointer jumping between the first hook and the union pass: every later find starts one hop from a root
@@ -463,6 +474,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   hipLaunchKernelGGL(k_merge_init, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, c->csize.p, c->attach.p, c->cc_flags.p, c->csz.p, V);
   uint8_t* mutual = nullptr;
   unsigned int n_cand = 0, n_succ = 0;
+  bool compressed = false, united = false;   // k_compress / the mutual unions already ran behind a read-back of closestCheck
   if (U > 0) {
     if (c->conn.cap < 2 * (size_t)U * c->adj_stride) { c->err = "connect buffer missing (local cut stage not run)"; return VGS_E_STATE; }
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
@@ -473,7 +485,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     // connect bits of the cuts (method 2, rows with lattice offsets): the lattice lookup of k_cross
     const bool use_bits = c->cb_enabled && c->P.method == 2 && c->adj_have_off;
     const uint16_t* cb_off = use_bits ? c->adj_off.p : (const uint16_t*)nullptr;
-    const uint16_t* cb_lut = use_bits ? c->off2idx.p : (const uint16_t*)nullptr;
+    const int cb_lut = c->cb_R;
     const uint32_t* cb_bits = use_bits ? c->conn_bits.p : (const uint32_t*)nullptr;
     // crossValidation starts while the hand-over kernels of the local cut still run (vgs_stage_localcut): rows that touch a
     // handed-over voxel are put off, ...
@@ -497,7 +509,20 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     unsigned int* d_changed = (unsigned int*)(mcnt + 1);
     hipLaunchKernelGGL(k_cc_candidates, dim3((unsigned)((U + TB - 1) / TB)), dim3(TB), 0, c->stream, c->used_ids.p, U, c->adj_mused.p,
                        c->csize.p, MP.adjacency_min, c->cc_flags.p, c->work_ids.p, d_ncand);
-    VGS_READBACK(c, &n_cand, d_ncand, 4);
+    // Two host round trips of closestCheck (the number of candidates, the fixed-point flag) hide behind work that does not depend
+    // on it: the pointer jumping over the first hooks, and the unions of the mutual edges (round 4; single-context runs only --
+    // a tile's unions depend on ownership, which is computed behind closestCheck)
+    const bool hide = !c->have_region && vgs_can_split_readback(c);
+    if (hide) {
+      vgs_status sb = vgs_readback_begin(c, d_ncand, 4);
+      if (sb != VGS_OK) return sb;
+      hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+      compressed = true;
+      vgs_status se = vgs_readback_end(c, &n_cand, 4);
+      if (se != VGS_OK) return se;
+    } else {
+      VGS_READBACK(c, &n_cand, d_ncand, 4);
+    }
     if (n_cand > 0) {
       // fixed point of "re-attachment succeeds": passes are queued four at a time, each with its own change counter, and
       // only the last counter is read back (a pass after the fixed point changes nothing and costs microseconds; a host
@@ -509,7 +534,17 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
           hipLaunchKernelGGL((k_cc_pass<false>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p,
                              c->adj_key.p, c->adj_cnt.p, c->adj_mused.p, c->adj_stride, c->node.p, c->csize.p, c->cc_flags.p, MP, c->attach.p, d_chg4 + q);
         unsigned int ch = 0;
-        VGS_READBACK(c, &ch, d_chg4 + 3, 4);
+        if (hide && !united) {
+          vgs_status sb = vgs_readback_begin(c, d_chg4 + 3, 4);
+          if (sb != VGS_OK) return sb;
+          hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+                             c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0);
+          united = true;
+          vgs_status se = vgs_readback_end(c, &ch, 4);
+          if (se != VGS_OK) return se;
+        } else {
+          VGS_READBACK(c, &ch, d_chg4 + 3, 4);
+        }
         if (!ch) break;
       }
       hipLaunchKernelGGL((k_cc_pass<true>), dim3(n_cand), dim3(64), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->adj_key.p,
@@ -523,10 +558,12 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0 && c->have_region)
     hipLaunchKernelGGL(k_cc_init, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
-  if (U > 0) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
-  if (U > 0)
+  if (U > 0 && !compressed) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+  if (U > 0 && !united)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
+                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1);
+  else if (U > 0 && n_cand > 0)
+    hipLaunchKernelGGL(k_union_attach, dim3((n_cand + TB - 1) / TB), dim3(TB), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->attach.p, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
   // cluster filter + labels (VGS_T_LABELS: this tail of the stage, measured on its own; it is part of VGS_T_MERGE)
   VGS_HIP_TRY(c, hipEventRecord(c->ev[14], c->stream));   // ev[14], ev[15]: this tail's own pair

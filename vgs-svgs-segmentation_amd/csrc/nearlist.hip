@@ -13,7 +13,7 @@
 #define NLB_G 8
 #endif
 #ifndef NLB_QCAP
-#define NLB_QCAP 256
+#define NLB_QCAP 128
 #endif
 __global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                    const uint32_t* __restrict__ adj_cnt, int adj_stride, const NodeRec* __restrict__ node,

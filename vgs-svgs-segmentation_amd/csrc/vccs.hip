@@ -39,18 +39,12 @@ __global__ void k_vccs_centroid(const float* __restrict__ xs, const float* __res
 
 // 26-neighbour table (offset order of vccs_common.h) and the voxel normal from the neighbourhood's centroids.
 // Neighbours are looked up in the brick table (a few MB, L2 resident) instead of a per-voxel hash.
-// nbr16 (optional): the same table as 16-bit rank differences t - v -- voxels are in Morton order, so a spatial neighbour is almost
-// always within +-32 k ranks; VX_NONE = no voxel there, VX_ESC = too far for 16 bits (the reader takes the id from nbr).  The
-// expansion rounds read this table 54 times: 52 instead of 104 bytes per voxel and round.
-#define VX_NONE (-32768)
-#define VX_ESC 32767
-#ifndef VX_USE_NBR16
-#define VX_USE_NBR16 1
-#endif
 __global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t V, int depth, const Brick* __restrict__ bricks, uint32_t hbits,
-                                  const float* __restrict__ cen, int32_t* __restrict__ nbr, float* __restrict__ nrm, int16_t* __restrict__ nbr16) {
+                                  const float* __restrict__ cen, int32_t* __restrict__ nbr, float* __restrict__ nrm, int4* __restrict__ nbr4) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
+  int quad[28];
+  for (int k = 26; k < 28; ++k) quad[k] = -1;
   const uint64_t code = vox_code[v];
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
   const uint32_t lim = 1u << depth;
@@ -65,15 +59,16 @@ __global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t
     int t = -1;
     if (nx < lim && ny < lim && nz < lim) { bool unused_flag; t = brick_find(bricks, hbits, nx, ny, nz, &unused_flag); }
     nbr[(int64_t)o * V + v] = t;   // [26][V]: a wavefront reads one offset of 64 consecutive voxels
-    if (nbr16) {
-      const int64_t d = (int64_t)t - v;
-      nbr16[(int64_t)o * V + v] = t < 0 ? (int16_t)VX_NONE : ((d > -32767 && d < 32767) ? (int16_t)d : (int16_t)VX_ESC);
-    }
+    quad[o] = t;
     if (t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
   }
   float n[3];
   vccs_normal_from_points(pts, np, n);
   nrm[3 * v] = n[0]; nrm[3 * v + 1] = n[1]; nrm[3 * v + 2] = n[2];
+  // the same table four entries to a load ([7][V] of int4: the expansion rounds read it 54 times and are bound by their number of
+  // vector-memory instructions, not by bytes)
+  if (nbr4)
+    for (int k = 0; k < 7; ++k) nbr4[(int64_t)k * V + v] = make_int4(quad[4 * k], quad[4 * k + 1], quad[4 * k + 2], quad[4 * k + 3]);
 }
 
 // ---------------------------------------------------------------- seeding
@@ -146,7 +141,7 @@ __global__ void k_vccs_plant(const unsigned long long* __restrict__ seed_key, in
 // label and only the table goes to memory: one global atomic per (workgroup, supervoxel, component) instead of fourteen
 // per voxel that changes -- the contended 64-bit atomics were half of the stage's time.  Integer sums: any order, same result.
 #define VX_SLOTS 128
-__global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int32_t* __restrict__ nbr, const int16_t* __restrict__ nbr16, const float* __restrict__ cen,
+__global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int4* __restrict__ nbr4, const float* __restrict__ cen,
                               const float* __restrict__ nrm, const int32_t* __restrict__ label_in, const float* __restrict__ dist_in,
                               const VccsState* __restrict__ st, float w_s_over_seed, float w_n, int32_t* __restrict__ label_out,
                               float* __restrict__ dist_out, long long* __restrict__ sums, unsigned int* __restrict__ count) {
@@ -168,13 +163,14 @@ __global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int32_t* _
     // all 26 neighbour ids, then all 26 labels: independent loads in flight together (the serial walk was latency bound)
     int nl[26];
 #pragma unroll
-    for (int o = 0; o < 26; ++o) {
-#if VX_USE_NBR16
-      const int d16 = (int)nbr16[(int64_t)o * V + v];
-      nl[o] = d16 == VX_NONE ? -1 : (d16 == VX_ESC ? nbr[(int64_t)o * V + v] : (int)(v + d16));
-#else
-      nl[o] = nbr[(int64_t)o * V + v];
-#endif
+    // (Round 4 measured this table as 16-bit rank differences -- voxels are in Morton order, a spatial neighbour is almost always
+    // within +-32 k ranks; 52 instead of 104 bytes per voxel and round: the stage went from 12.6 to 16.9 ms.  The kernel is bound by
+    // its 52 vector-memory instructions per thread, not by HBM bytes; the escape path for far neighbours adds 26 masked loads.)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int4 q = nbr4[(int64_t)k * V + v];
+      nl[4 * k] = q.x; nl[4 * k + 1] = q.y;
+      if (k < 6) { nl[4 * k + 2] = q.z; nl[4 * k + 3] = q.w; }
     }
 #pragma unroll
     for (int o = 0; o < 26; ++o) nl[o] = nl[o] >= 0 ? label_in[nl[o]] : -1;
@@ -558,7 +554,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
   // the 26-neighbour table (its 1-ring normals are overwritten by the 2-ring ones)
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, nrm.p, (int16_t*)nullptr);
+                     c->vc_nbr.p, nrm.p, (int4*)nullptr);
   hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p);
   hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p);
   // ---- seeds ----
@@ -686,9 +682,9 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
-  VGS_HIP_TRY(c, c->vc_nbr16.ensure(26 * (size_t)V));
+  VGS_HIP_TRY(c, c->vc_nbr4.ensure(28 * (size_t)V));
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, nrm.p, c->vc_nbr16.p);
+                     c->vc_nbr.p, nrm.p, (int4*)c->vc_nbr4.p);
   // ---- seeds: one per occupied seed_res cell, snapped to the voxel nearest to the cell centre ----
   const float seed = c->P.seed_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
@@ -731,7 +727,7 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
     hipLaunchKernelGGL(k_vccs_reset, dim3(nbV), dim3(TB), 0, c->stream, V, lab[cur], dst[cur]);
     hipLaunchKernelGGL(k_vccs_plant, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, cen.p, nrm.p, lab[cur], dst[cur], state, c->vc_sums.p, c->vc_count.p);
     for (int it = 0; it < T; ++it) {
-      hipLaunchKernelGGL(k_vccs_expand, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, c->vc_nbr16.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
+      hipLaunchKernelGGL(k_vccs_expand, dim3(nbV), dim3(TB), 0, c->stream, V, (const int4*)c->vc_nbr4.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
                          lab[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
       cur ^= 1;
       hipLaunchKernelGGL(k_vccs_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state);

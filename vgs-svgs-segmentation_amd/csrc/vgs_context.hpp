@@ -114,6 +114,9 @@ struct vgs_ctx {
   int xyz_cur = 0;
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // copy streams: uploads of the next cloud, downloads of the last labels
   hipEvent_t ev_h2d = nullptr, ev_d2h = nullptr;
+  hipEvent_t ev_rb = nullptr;    // split read-backs (vgs_readback_begin / _end)
+  bool gathered = false;         // voxelize: the leaf-order gather was queued behind the count read-back
+  bool bricks_ready = false;     // the features stage has already queued the brick table of this voxel table (behind its read-back)
   bool staged = false;         // a cloud is on its way into xyz_buf[1 - xyz_cur]
   int64_t staged_n = 0;
   int staged_stride = 12;
@@ -168,13 +171,12 @@ struct vgs_ctx {
   DevBuf<uint64_t> adj_key;
   DevBuf<uint16_t> adj_off;   // per row entry: packed lattice offset from the row's voxel, (dx+16) | (dy+16) << 5 | (dz+16) << 10; row[0] = 0xffff: none
   bool adj_have_off = false;
-  // crossValidation through the lattice (round 4): every cut also leaves its connect list as a BIT per ball offset (conn_bits: U rows
-  // of cb_words words, bit k = the neighbour at ball offset k is in the list; bit 0 = the voxel itself = "this row has bits"), so
-  // "is i in L0(k)?" is one bit of k's row at the index of the negated offset instead of a search in k's 8-byte keys.
-  // off2idx: packed 15-bit lattice offset (adj_off's format) -> ball index (0xffff: not in the ball)
-  DevBuf<uint16_t> off2idx;
+  // crossValidation through the lattice (round 4): every cut also leaves its connect list as a BIT per lattice offset (conn_bits: U
+  // rows of cb_words words; bit = vgs_cb_index(offset) in the cube of side 2 cb_R + 1 around the voxel, cb_R = the ball's largest
+  // offset per axis; the centre bit -- the voxel itself, always a member -- says "this row has bits"), so "is i in L0(k)?" is one
+  // bit of k's row, at the index of the negated offset = cube size - 1 - index, instead of a search in k's 8-byte keys.
   DevBuf<uint32_t> conn_bits;
-  int cb_words = 0;
+  int cb_words = 0, cb_R = 0;
   bool cb_enabled = false;     // the cuts of this run wrote conn_bits
   DevBuf<uint32_t> adj_cnt, adj_mused;  // per used voxel: stored row length, number of ALL neighbours
   bool adj_pruned = false;              // rows hold used neighbours only
@@ -229,7 +231,7 @@ struct vgs_ctx {
   // VCCS-style supervoxel stage
   DevBuf<float> vc_cen, vc_nrm, vc_dist, vc_state;
   DevBuf<int32_t> vc_nbr, vc_label;
-  DevBuf<int16_t> vc_nbr16;   // vc_nbr as 16-bit rank differences (vccs.hip: k_vccs_neighbours)
+  DevBuf<int32_t> vc_nbr4;    // vc_nbr once more as [7][V] int4 (28 entries per voxel, two unused): four neighbours to a load for the expansion rounds
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
   DevBuf<uint32_t> vc_count;
@@ -274,7 +276,31 @@ static inline vgs_status vgs_readback(vgs_ctx* c, void* dst, const void* src_dev
   memcpy(dst, c->pin, bytes);
   return VGS_OK;
 }
+// bit of the lattice offset p (packed (dx+16) | (dy+16) << 5 | (dz+16) << 10, as the rows' adj_off holds it) in a row of connect bits
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t vgs_cb_index(uint32_t p, int R) {
+  const int D = 2 * R + 1;
+  const int dx = (int)(p & 31u) - 16 + R, dy = (int)((p >> 5) & 31u) - 16 + R, dz = (int)((p >> 10) & 31u) - 16 + R;
+  return (uint32_t)((dz * D + dy) * D + dx);
+}
+#endif
 #define VGS_READBACK(ctx, dst, src, bytes) do { vgs_status _s = vgs_readback((ctx), (dst), (src), (bytes)); if (_s != VGS_OK) return _s; } while (0)
+
+// The same in two halves (round 4): the copy is queued NOW, the host collects it LATER.  Kernels launched in between that do not need
+// the number run while the host makes its round trip (20-30 us of an idle GPU per read-back otherwise: profiles/r04_step_timeline.txt).
+// Uses the upper half of the pinned scratch, so that a plain vgs_readback in between does not overwrite it.
+static inline vgs_status vgs_readback_begin(vgs_ctx* c, const void* src_dev, size_t bytes) {
+  if (bytes > 2048 || !c->pin || !c->ev_rb) return VGS_E_ARG;
+  VGS_HIP_TRY(c, hipMemcpyAsync((char*)c->pin + 2048, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  VGS_HIP_TRY(c, hipEventRecord(c->ev_rb, c->stream));
+  return VGS_OK;
+}
+static inline vgs_status vgs_readback_end(vgs_ctx* c, void* dst, size_t bytes) {
+  VGS_HIP_TRY(c, hipEventSynchronize(c->ev_rb));
+  memcpy(dst, (char*)c->pin + 2048, bytes);
+  return VGS_OK;
+}
+static inline bool vgs_can_split_readback(const vgs_ctx* c) { return c->pin != nullptr && c->ev_rb != nullptr; }
 
 vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host);   // cutorder.hip
 void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only

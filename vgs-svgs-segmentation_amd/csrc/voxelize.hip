@@ -342,7 +342,17 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
   VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
   hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
   unsigned long long h2[2] = {0, 0};
-  VGS_READBACK(c, h2, d_cnt, sizeof(h2));
+  if (vgs_can_split_readback(c)) {
+    // the leaf-order gather of the points needs the sorted order only, not the counts: it runs while the host fetches them.  All N
+    // positions are gathered (the non-finite points sit at the tail of the order; their slots are never read).
+    { vgs_status sb = vgs_readback_begin(c, d_cnt, sizeof(h2)); if (sb != VGS_OK) return sb; }
+    VGS_HIP_TRY(c, c->xs.ensure(N + 1)); VGS_HIP_TRY(c, c->ys.ensure(N + 1)); VGS_HIP_TRY(c, c->zs.ensure(N + 1));
+    hipLaunchKernelGGL(k_gather_points, dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, c->perm_b.p, N, c->xs.p, c->ys.p, c->zs.p);
+    c->gathered = true;
+    { vgs_status se = vgs_readback_end(c, h2, sizeof(h2)); if (se != VGS_OK) return se; }
+  } else {
+    VGS_READBACK(c, h2, d_cnt, sizeof(h2));
+  }
   const unsigned long long nf = h2[0];
   const uint32_t v_total = (uint32_t)h2[1];
   c->Nf = (int64_t)nf;
@@ -371,10 +381,11 @@ vgs_status vgs_stage_voxelize(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->perm_a.ensure(N)); VGS_HIP_TRY(c, c->perm_b.ensure(N));
   VGS_HIP_TRY(c, c->head_flag.ensure(N)); VGS_HIP_TRY(c, c->pt_vox.ensure(N));
   const int TB = 256;
+  c->gathered = false;
   st = (c->code_bits + 1 <= 32) ? voxelize_sorted_table<uint32_t>(c) : voxelize_sorted_table<uint64_t>(c);
   if (st != VGS_OK) return st;
-  VGS_HIP_TRY(c, c->xs.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->ys.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->zs.ensure(c->Nf + 1));
-  if (c->Nf > 0) {
+  if (!c->gathered) { VGS_HIP_TRY(c, c->xs.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->ys.ensure(c->Nf + 1)); VGS_HIP_TRY(c, c->zs.ensure(c->Nf + 1)); }
+  if (c->Nf > 0 && !c->gathered) {
     const unsigned nbf = (unsigned)((c->Nf + TB - 1) / TB);
     hipLaunchKernelGGL(k_gather_points, dim3(nbf), dim3(TB), 0, c->stream, c->xyz, c->stride_f, c->perm_b.p, c->Nf, c->xs.p, c->ys.p,
                        c->zs.p);
