@@ -162,7 +162,6 @@ __global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int4* __re
     const int own = best_l;
     // all 26 neighbour ids, then all 26 labels: independent loads in flight together (the serial walk was latency bound)
     int nl[26];
-#pragma unroll
     // (Round 4 measured this table as 16-bit rank differences -- voxels are in Morton order, a spatial neighbour is almost always
     // within +-32 k ranks; 52 instead of 104 bytes per voxel and round: the stage went from 12.6 to 16.9 ms.  The kernel is bound by
     // its 52 vector-memory instructions per thread, not by HBM bytes; the escape path for far neighbours adds 26 masked loads.)
