@@ -119,6 +119,7 @@ class VoxelBasedSegmentation {
     adj_off_.clear(); adj_idx_.clear();
   }
   void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {
+    ensure_voxels();   // (test:56 calls this right behind setVoxelSize)
     double b[6];
     chk(vgs_get_bbox(ctx(), b), "vgs_get_bbox");
     min_x = b[0]; min_y = b[1]; min_z = b[2]; max_x = b[3]; max_y = b[4]; max_z = b[5];
@@ -152,6 +153,7 @@ class VoxelBasedSegmentation {
   // table is rebuilt here at the new size -- as the Python mirror does (api.py) -- instead of failing later with VGS_E_STATE.
   void setVoxelCenters() { ensure_voxels(); }
   std::vector<PointXYZ> getVoxelCenters() {                                              // VS:191
+    ensure_voxels();
     const int64_t v = count(VGS_N_VOXELS);
     std::vector<float> c((size_t)v * 3 + 1);
     chk(vgs_get_voxel_centers(ctx(), c.data()), "vgs_get_voxel_centers");
@@ -161,6 +163,7 @@ class VoxelBasedSegmentation {
   }
   void calcualteVoxelCloudAttributes(const PCXYZPtr&) { ensure_voxels(); chk(vgs_features(ctx()), "vgs_features"); }  // VS:290 (sic)
   void findAllVoxelAdjacency(float graph_size) {                                         // VS:223
+    ensure_voxels();
     p_.graph_size = graph_size;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
     chk(vgs_adjacency(ctx()), "vgs_adjacency");
