@@ -90,6 +90,7 @@ struct VgsKnobs {
   bool no_overlap = false;   // VGS_NO_OVERLAP
   bool no_near = false;      // VGS_NO_NEAR
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
+  bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool debug = false;        // VGS_DEBUG
 };

@@ -191,7 +191,7 @@ __global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* 
 // depth 10) -- the radix sort then moves 8 instead of 12 bytes per point and pass -- uint64_t otherwise.
 template <typename KeyT>
 __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_t n, const GrowState* __restrict__ gs,
-                             double res, int code_bits, KeyT* __restrict__ code, uint32_t* __restrict__ perm) {
+                             double res, int code_bits, KeyT* __restrict__ code, uint32_t* __restrict__ perm, int pack_shift) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = xyz + i * stride_f;
@@ -207,25 +207,31 @@ __global__ void k_make_codes(const float* __restrict__ xyz, int stride_f, int64_
     uint32_t kz = vm_axis_key(z, ep.min[2], res) + (uint32_t)(gs->shift[2] - ep.shift[2]);
     c = (1ull << code_bits) | vm_morton(kx, ky, kz);
   }
+  // pack_shift > 0 (64-bit keys with room below the code): the point index travels in the key's low bits and the sort moves keys
+  // only -- 8 instead of 12 bytes per point and pass; the sort looks at the bits from pack_shift up, so equal codes keep their
+  // ascending index order exactly as the stable pair sort keeps it
+  if (pack_shift > 0) { code[i] = (KeyT)((c << pack_shift) | (uint64_t)i); return; }
   code[i] = (KeyT)c;
   perm[i] = (uint32_t)i;
 }
 
 // run heads in the sorted code array (invalid codes == 0 sit at the tail of the descending order)
 template <typename KeyT>
-__global__ void k_heads(const KeyT* __restrict__ code, int64_t n, uint32_t* __restrict__ head) {
+__global__ void k_heads(const KeyT* __restrict__ code, int64_t n, uint32_t* __restrict__ head, int pack_shift, uint32_t* __restrict__ perm_out) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
-    KeyT c = code[j];
-    head[j] = (c != 0 && (j == 0 || code[j - 1] != c)) ? 1u : 0u;
+    const uint64_t raw = (uint64_t)code[j];
+    const uint64_t c = raw >> pack_shift;
+    head[j] = (c != 0 && (j == 0 || ((uint64_t)code[j - 1] >> pack_shift) != c)) ? 1u : 0u;
+    if (pack_shift > 0) perm_out[j] = (uint32_t)(raw & ((1ull << pack_shift) - 1ull));   // the sorted order, unpacked for everybody downstream
   }
 }
 
 // number of valid (non-zero) codes = index of the first zero in the descending array
 template <typename KeyT>
-__global__ void k_count_valid(const KeyT* __restrict__ code, int64_t n, unsigned long long* __restrict__ n_valid) {
+__global__ void k_count_valid(const KeyT* __restrict__ code, int64_t n, unsigned long long* __restrict__ n_valid, int pack_shift) {
   int64_t lo = 0, hi = n;
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (code[mid] != 0) lo = mid + 1; else hi = mid; }
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (((uint64_t)code[mid] >> pack_shift) != 0) lo = mid + 1; else hi = mid; }
   *n_valid = (unsigned long long)lo;
 }
 __global__ void k_copy_last(const uint32_t* __restrict__ scan, int64_t n, unsigned long long* __restrict__ out) { *out = (unsigned long long)scan[n - 1]; }
@@ -233,10 +239,10 @@ __global__ void k_copy_last(const uint32_t* __restrict__ scan, int64_t n, unsign
 template <typename KeyT>
 __global__ void k_voxel_table(const KeyT* __restrict__ code, const uint32_t* __restrict__ head,
                               const uint32_t* __restrict__ scan, int64_t n, uint64_t mask, uint32_t* __restrict__ pt_vox,
-                              uint64_t* __restrict__ vox_code, uint32_t* __restrict__ vox_start) {
+                              uint64_t* __restrict__ vox_code, uint32_t* __restrict__ vox_start, int pack_shift) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  uint64_t c = (uint64_t)code[j];
+  uint64_t c = (uint64_t)code[j] >> pack_shift;
   if (c == 0) { pt_vox[j] = 0xffffffffu; return; }
   uint32_t v = scan[j] - 1u;
   pt_vox[j] = v;
@@ -311,8 +317,13 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
   const unsigned nb = (unsigned)((N + TB - 1) / TB);
   KeyT* code_a = (KeyT*)c->code_a.p;   // the 64-bit buffers hold either key width
   KeyT* code_b = (KeyT*)c->code_b.p;
+  // 64-bit keys with room below the code (34 key bits + 24 index bits at 10 M points): index packed into the key, keys-only sort
+  const unsigned key_bits = (unsigned)(c->code_bits + 1);
+  int idx_bits = 1;
+  while (idx_bits < 32 && ((int64_t)1 << idx_bits) < N) ++idx_bits;
+  const int pack_shift = (sizeof(KeyT) == 8 && (int)key_bits + idx_bits <= 64 && !c->K.no_packed_sort) ? idx_bits : 0;
   hipLaunchKernelGGL((k_make_codes<KeyT>), dim3(nb), dim3(TB), 0, c->stream, c->xyz, c->stride_f, N, (const GrowState*)c->grow_state.p, c->box.res,
-                     c->code_bits, code_a, c->perm_a.p);
+                     c->code_bits, code_a, c->perm_a.p, pack_shift);
 
   // stable LSD radix sort, descending code (= PCL LeafNodeIterator order: children visited 7 -> 0),
   // ascending point index inside a leaf (stability)
@@ -321,9 +332,11 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
   using nine_bits = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 6>, rocprim::kernel_config<1024, 6>, 9,
                                                                                    rocprim::block_radix_rank_algorithm::match>>;
-  const unsigned key_bits = (unsigned)(c->code_bits + 1);
   const bool use9 = (key_bits + 8) / 9 < (key_bits + 7) / 8;
   auto sort_pairs = [&](void* tmp, size_t& bytes) -> hipError_t {
+    if (pack_shift > 0)
+      return use9 ? rocprim::radix_sort_keys_desc<nine_bits>(tmp, bytes, code_a, code_b, (size_t)N, (unsigned)pack_shift, (unsigned)pack_shift + key_bits, c->stream)
+                  : rocprim::radix_sort_keys_desc(tmp, bytes, code_a, code_b, (size_t)N, (unsigned)pack_shift, (unsigned)pack_shift + key_bits, c->stream);
     return use9 ? rocprim::radix_sort_pairs_desc<nine_bits>(tmp, bytes, code_a, code_b, c->perm_a.p, c->perm_b.p, (size_t)N, 0, key_bits, c->stream)
                 : rocprim::radix_sort_pairs_desc(tmp, bytes, code_a, code_b, c->perm_a.p, c->perm_b.p, (size_t)N, 0, key_bits, c->stream);
   };
@@ -336,8 +349,8 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
   // sorted: code_b, perm_b
   unsigned long long* d_cnt = (unsigned long long*)c->counters.p;
   VGS_HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL((k_heads<KeyT>), dim3(nb), dim3(TB), 0, c->stream, code_b, N, c->head_flag.p);
-  hipLaunchKernelGGL((k_count_valid<KeyT>), dim3(1), dim3(1), 0, c->stream, code_b, N, d_cnt);
+  hipLaunchKernelGGL((k_heads<KeyT>), dim3(nb), dim3(TB), 0, c->stream, code_b, N, c->head_flag.p, pack_shift, c->perm_b.p);
+  hipLaunchKernelGGL((k_count_valid<KeyT>), dim3(1), dim3(1), 0, c->stream, code_b, N, d_cnt, pack_shift);
   uint32_t* scan = c->perm_a.p;  // perm_a is free after the sort
   VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes, c->head_flag.p, scan, (size_t)N, rocprim::plus<uint32_t>(), c->stream));
   hipLaunchKernelGGL(k_copy_last, dim3(1), dim3(1), 0, c->stream, scan, N, d_cnt + 1);   // number of voxels next to the number of finite points
@@ -360,7 +373,7 @@ static vgs_status voxelize_sorted_table(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->vox_code.ensure(c->V + 1)); VGS_HIP_TRY(c, c->vox_start.ensure(c->V + 1));
   const uint64_t mask = (c->code_bits >= 64) ? ~0ull : ((1ull << c->code_bits) - 1ull);
   hipLaunchKernelGGL((k_voxel_table<KeyT>), dim3(nb), dim3(TB), 0, c->stream, code_b, c->head_flag.p, scan, N, mask, c->pt_vox.p,
-                     c->vox_code.p, c->vox_start.p);
+                     c->vox_code.p, c->vox_start.p, pack_shift);
   hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, c->vox_start.p + c->V, (uint32_t)c->Nf);
   return VGS_OK;
 }
