@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
                                               unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work,
                                               const uint16_t* __restrict__ adj_off, int cb_R,
-                                              const uint32_t* __restrict__ cbits, int cb_words) {
+                                              const uint32_t* __restrict__ cbits, int cb_words, uint8_t* __restrict__ defer_flag) {
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
   // (work != null): the rows put off.
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
     u = g * CX_ROWS + grp;
     if (g >= ngroups || u >= U) return;
   }
-  if (pending && pending[u]) { if (sub == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; return; }
+  if (pending && pending[u]) { if (sub == 0) { defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; if (defer_flag) defer_flag[u] = 1; } return; }
   bool touches_pending = false;
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
@@ -143,9 +143,10 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
   if (pending) {   // what was written to a row that is put off is overwritten by the second pass
     const unsigned long long mine = (W == 64) ? ~0ull : (((1ull << W) - 1ull) << (grp * W));
     if ((__ballot(touches_pending) & mine) != 0ull) {
-      if (sub == 0) defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u;
+      if (sub == 0) { defer_list[atomicAdd(n_defer, 1u)] = (uint32_t)u; if (defer_flag) defer_flag[u] = 1; }
       return;
     }
+    if (defer_flag && sub == 0) defer_flag[u] = 0;   // every row of the first pass writes its flag: nobody zeroes the array
   }
   for (int o = W / 2; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
   if (sub == 0) csize[i] = (uint32_t)kept;
@@ -287,12 +288,15 @@ __global__ __launch_bounds__(64) void k_cc_init(const uint32_t* __restrict__ use
 __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
-                                                     const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent, int do_attach) {
+                                                     const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent, int do_attach,
+                                                     const uint8_t* __restrict__ skip, const uint32_t* __restrict__ work, int n_work) {
   constexpr int W = 64 / UM_ROWS;
   // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
-  const int64_t u = (int64_t)blockIdx.x * UM_ROWS + (threadIdx.x / W);
+  int64_t u = (int64_t)blockIdx.x * UM_ROWS + (threadIdx.x / W);
   const int sub = threadIdx.x % W;
+  if (work) { if (u >= n_work) return; u = (int64_t)work[u]; }   // the rows of a list (the second pass of crossValidation)
   if (u >= U) return;
+  if (skip && skip[u]) return;                                     // rows whose mutual flags are not final yet
   const uint32_t i = used_ids[u];
   const int n = (int)adj_cnt[u];
   const uint64_t* row = adj_key + u * adj_stride;
@@ -482,6 +486,9 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     const float inv_res2 = 1.0f / (c->P.voxel_size * c->P.voxel_size);
     uint32_t* cross_parent = c->have_region ? nullptr : c->parent.p;
     unsigned int* d_ndefer = (unsigned int*)(c->counters.p + 13);   // zeroed with the local cut's counters
+    // single-context runs whose hand-over kernels are still running: the unions of the final rows go beside them (see below)
+    const bool early_union = !c->have_region && c->lc_tail.open && !c->K.no_overlap && !c->K.no_early_union;
+    if (early_union) VGS_HIP_TRY(c, c->lc_defer_flag.ensure((size_t)U));
     // connect bits of the cuts (method 2, rows with lattice offsets): the lattice lookup of k_cross
     const bool use_bits = c->cb_enabled && c->P.method == 2 && c->adj_have_off;
     const uint16_t* cb_off = use_bits ? c->adj_off.p : (const uint16_t*)nullptr;
@@ -492,17 +499,31 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                        c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0,
-                       cb_off, cb_lut, cb_bits, c->cb_words);
+                       cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr);
+    if (early_union) {
+      // The unions of the rows that are final go here, beside the hand-over kernels of the local cut (which leave most of the GPU
+      // idle and end the critical path of the stage): pointer jumping over the first hooks, then every mutual edge of a row that
+      // was not put off.  The rows put off follow behind their second crossValidation pass, without a first hook (their parents
+      // may have moved by then).
+      hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
+      hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0);
+      compressed = true; united = true;
+    }
     // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
     unsigned int n_defer = 0;
     {
       vgs_status sf = vgs_localcut_finish(c, &n_defer);
       if (sf != VGS_OK) return sf;
     }
-    if (n_defer > 0)
+    if (n_defer > 0) {
       hipLaunchKernelGGL(k_cross, dim3((n_defer + CX_ROWS - 1) / CX_ROWS), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
-                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words);
+                         c->adj_stride, c->conn.p, mutual, c->csize.p, early_union ? (uint32_t*)nullptr : cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
+                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr);
+      if (early_union)
+        hipLaunchKernelGGL(k_union_mutual, dim3((n_defer + UM_ROWS - 1) / UM_ROWS), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+                           c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, c->lc_defer.p, (int)n_defer);
+    }
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
     unsigned int* d_ncand = (unsigned int*)(mcnt + 0);
@@ -512,7 +533,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     // Two host round trips of closestCheck (the number of candidates, the fixed-point flag) hide behind work that does not depend
     // on it: the pointer jumping over the first hooks, and the unions of the mutual edges (round 4; single-context runs only --
     // a tile's unions depend on ownership, which is computed behind closestCheck)
-    const bool hide = !c->have_region && vgs_can_split_readback(c);
+    const bool hide = !c->have_region && vgs_can_split_readback(c) && !early_union;
     if (hide) {
       vgs_status sb = vgs_readback_begin(c, d_ncand, 4);
       if (sb != VGS_OK) return sb;
@@ -538,7 +559,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
           vgs_status sb = vgs_readback_begin(c, d_chg4 + 3, 4);
           if (sb != VGS_OK) return sb;
           hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                             c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0);
+                             c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0);
           united = true;
           vgs_status se = vgs_readback_end(c, &ch, 4);
           if (se != VGS_OK) return se;
@@ -561,7 +582,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0 && !compressed) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0 && !united)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1);
+                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0);
   else if (U > 0 && n_cand > 0)
     hipLaunchKernelGGL(k_union_attach, dim3((n_cand + TB - 1) / TB), dim3(TB), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->attach.p, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);

@@ -91,6 +91,7 @@ struct VgsKnobs {
   bool no_near = false;      // VGS_NO_NEAR
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
+  bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool debug = false;        // VGS_DEBUG
 };
@@ -197,6 +198,7 @@ struct vgs_ctx {
   // hand-overs of the local cut run on a side stream while the merge stage already cross-validates the rows they cannot
   // touch: per used voxel "handed over, connect row not final yet", the rows put off, and what vgs_localcut_finish needs
   DevBuf<uint8_t> lc_pending;
+  DevBuf<uint8_t> lc_defer_flag;   // per row: the first pass of crossValidation put it off (written by every row of that pass)
   DevBuf<uint32_t> lc_defer;
   struct { bool open = false; bool dense = true; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
   int64_t lc_diag[16] = {0};   // vgs_get_schedule_counters[_ex]
