@@ -79,7 +79,6 @@ struct GrowState {
   unsigned long long found;      // search word of the running scan (smallest violating index, ~0 = none)
   long long start;               // next scan starts here
   int depth, defined, done, n_epochs, record, overflow;
-  unsigned int blocks_done, pad_;   // k_first_violation: workgroups through with their scan (the last one replays the growth)
   Epoch epochs[VGS_MAX_EPOCHS];
 };
 
@@ -90,31 +89,9 @@ __device__ __forceinline__ bool fv_outside(float x, float y, float z, const BoxD
          (double)y >= g.max[1] || (double)z < g.min[2] || (double)z >= g.max[2];
 }
 
-__device__ void grow_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned);
-__device__ __forceinline__ void fv_scan(const float* __restrict__ xyz, int stride_f, int64_t n, GrowState* __restrict__ gs);
-
-// One growth step = one launch (round 4; it was a scan kernel and a one-thread kernel, sixteen launches per cloud of which the
-// second halves were pure launch latency): every workgroup scans, and the LAST one to finish -- a ticket counter behind a fence --
-// replays PCL's growth rule for the point that was found.
-__global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t n, GrowState* __restrict__ gs, int pinned) {
-  __shared__ int s_last;
-  const bool done = gs->done != 0;   // (uniform; written by an earlier launch only)
-  if (!done) fv_scan(xyz, stride_f, n, gs);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(&gs->blocks_done, 1u) == gridDim.x - 1u ? 1 : 0;
-  }
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    gs->blocks_done = 0u;
-    if (!done) grow_adopt(xyz, stride_f, gs, pinned);
-  }
-}
-
 // Packed xyz (12-byte points) is read as three 16-byte loads per four points; the running answer is polled once per trip.
-__device__ __forceinline__ void fv_scan(const float* __restrict__ xyz, int stride_f, int64_t n, GrowState* __restrict__ gs) {
+__global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, int64_t n, GrowState* __restrict__ gs) {
+  if (gs->done) return;
   BoxD box;   // a private copy: the search word below lives in the same structure
   for (int a = 0; a < 3; ++a) { box.min[a] = gs->min[a]; box.max[a] = gs->max[a]; }
   box.defined = gs->defined;
@@ -161,9 +138,9 @@ __device__ __forceinline__ void fv_scan(const float* __restrict__ xyz, int strid
 }
 
 // one thread: OctreeBox::adopt for the point the scan found (the same statements in the same order, double arithmetic)
-__device__ void grow_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned) {
+__global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned) {
   if (g->done) return;
-  const unsigned long long idx = __hip_atomic_load(&g->found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long idx = g->found;
   g->found = ~0ull;
   if (idx == ~0ull) { g->done = 1; return; }
   if (pinned) { g->done = 2; return; }   // a point outside a pinned grid: the host reports it
@@ -309,8 +286,10 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, (int64_t)c->K.fv_blocks));
   for (int batch = 0; batch < 64; ++batch) {
     // a scene grows its box about log2(extent / voxel) times; pairs queued after the last growth return at once
-    for (int k = 0; k < 8; ++k)
-      hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g, pinned);
+    for (int k = 0; k < 8; ++k) {
+      hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g);
+      hipLaunchKernelGGL(k_adopt, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_g, pinned);
+    }
     VGS_READBACK(c, &h, d_g, offsetof(GrowState, epochs));   // the epochs stay on the device
     if (h.done) break;
   }
