@@ -279,7 +279,18 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
     e.first = 0;
     for (int a = 0; a < 3; ++a) { e.min[a] = box.min[a]; e.shift[a] = box.shift[a]; }
   }
-  VGS_HIP_TRY(c, hipMemcpyAsync(d_g, &h, offsetof(GrowState, epochs) + sizeof(Epoch), hipMemcpyHostToDevice, c->stream));   // header + the epoch a pinned grid starts with
+  {
+    // header + the epoch a pinned grid starts with; through the pinned scratch when there is one (a copy out of pageable memory is
+    // staged by the runtime and holds the stream's first kernel back by tens of microseconds)
+    const size_t hb = offsetof(GrowState, epochs) + sizeof(Epoch);
+    static_assert(offsetof(GrowState, epochs) + sizeof(Epoch) <= 1024, "the growth header fits its slot of the pinned scratch");
+    const void* src = &h;
+    if (c->pin) { memcpy((char*)c->pin + 1024, &h, hb); src = (char*)c->pin + 1024; }
+    VGS_HIP_TRY(c, hipMemcpyAsync(d_g, src, hb, hipMemcpyHostToDevice, c->stream));
+  }
+  // (Round 4 measured the scan and the one-thread growth kernel as ONE launch -- the last workgroup through its scan replays the
+  // growth: eight launches instead of sixteen, but the double-precision growth code inflates the scan kernel's registers and the
+  // scans take twice as long, 240 against 125 us per cloud.  Two kernels it stays.)
   const int pinned = (c->grid_pinned && record_epochs) ? 1 : 0;
   // few enough threads that the scan moves through the cloud front to back (a growth step is found within the first
   // trip or two: the points come in random order), enough to keep the HBM pipes full on the one scan that reads everything
