@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
                                                   uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                   uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
                                                   const int32_t* __restrict__ nvals, const uint32_t* __restrict__ redo, unsigned int* __restrict__ n_redo,
-                                                  uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
+                                                  uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off, unsigned int* __restrict__ n_redo_out) {
   // adj_off != null: the packed lattice offset (dx+16) | (dy+16) << 5 | (dz+16) << 10 of every stored entry goes to a row of
   // its own (the local cut reads it instead of gathering the neighbours' records for their lattice coordinates); a row that
   // is not in band gets 0xffff in its first slot: its order comes from a sort that does not carry the offsets
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
   __syncthreads();
   if (cnt > CAP) {  // dense volumetric neighbourhood: the pass with the full-size list takes this row
-    if (lane == 0 && redo_out) redo_out[atomicAdd(n_redo, 1u)] = (uint32_t)u;
+    if (lane == 0 && redo_out) redo_out[atomicAdd(n_redo_out, 1u)] = (uint32_t)u;   // (its own counter: a middle pass reads one list and fills the next)
     return;
   }
   if (__ballot(!in_band) == 0ull) {
@@ -173,9 +173,10 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
 // for occupied cells only.  Candidates arrive brick by brick, so the survivors are put in order of integer offset length
 // with a counting sort (histogram in LDS); inside a length group the final slot is found as above.  Rows that do not fit,
 // or whose float distances leave the band of their integer lengths, go to the redo list of the general kernel.
-#define ADJM_BRICKS 128
-#define ADJM_TRIPS 5   // candidates per lane kept in registers (CAPC = 64 * ADJM_TRIPS)
-template <int CAP, int NB>
+// (round 4: balls up to 12 voxels -- 7 x 7 x 7 bricks, six per lane -- take this path too: config 2's ball of ten voxels went through
+// the general kernel's 2048-slot pass, which tests all 4189 offsets of the ball where a planar neighbourhood occupies 305.)
+// ADJM_TRIPS candidates per lane are kept in registers (CAPC = 64 * ADJM_TRIPS)
+template <int CAP, int NB, int ADJM_TRIPS>
 __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids, int64_t U,
                                                         const Brick* __restrict__ bricks, uint32_t hbits, const uint64_t* __restrict__ masks,
                                                         int R, float res_f, float min_x, float min_y, float min_z, float r2,
@@ -184,10 +185,11 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
                                                         const int32_t* __restrict__ nvals, unsigned int* __restrict__ n_redo,
                                                         uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
   constexpr int NB3 = NB * NB * NB, Bh = NB / 2, CAPC = 64 * ADJM_TRIPS;
-  static_assert(NB3 <= ADJM_BRICKS, "two bricks per lane");
+  constexpr int BTRIPS = (NB3 + 63) / 64, ADJM_BRICKS = 64 * BTRIPS;   // bricks per lane, table size
+  static_assert(NB3 <= 512, "brick slot: nine bits of a candidate");
   __shared__ uint64_t s_occ[ADJM_BRICKS];
   __shared__ uint32_t s_first[ADJM_BRICKS];
-  __shared__ uint16_t s_cand[CAPC];     // used << 13 | brick slot << 6 | bit
+  __shared__ uint16_t s_cand[CAPC];     // used << 15 | brick slot << 6 | bit
   __shared__ uint64_t lst[CAP];
   __shared__ uint8_t gl[CAP];
   __shared__ uint16_t loff[CAP];   // packed lattice offset of every survivor (see k_adjacency)
@@ -208,10 +210,12 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   for (int k = lane; k < 128; k += 64) s_hist[k] = 0;
   const int px = (int)(kx & 3u), py = (int)(ky & 3u), pz = (int)(kz & 3u);
   const uint64_t* mrow = masks + (size_t)((pz * 4 + py) * 4 + px) * (size_t)NB3;
-  // ---- one brick per lane (two trips: NB3 <= 128): the whole 32-byte table entry comes in one round trip ----
-  uint64_t cand[2] = {0ull, 0ull}, cusd[2] = {0ull, 0ull};
+  // ---- one brick per lane and trip: the whole 32-byte table entry comes in one round trip ----
+  uint64_t cand[BTRIPS], cusd[BTRIPS];
 #pragma unroll
-  for (int trip = 0; trip < 2; ++trip) {
+  for (int trip = 0; trip < BTRIPS; ++trip) { cand[trip] = 0ull; cusd[trip] = 0ull; }
+#pragma unroll
+  for (int trip = 0; trip < BTRIPS; ++trip) {
     const int sidx = trip * 64 + lane;
     uint64_t occ = 0ull;
     uint32_t first = 0u;
@@ -239,7 +243,9 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
     }
   }
   // ---- expand the set bits of all lanes into one candidate list ----
-  const int mine = __popcll(cand[0]) + __popcll(cand[1]);
+  int mine = 0;
+#pragma unroll
+  for (int trip = 0; trip < BTRIPS; ++trip) mine += __popcll(cand[trip]);
   int incl = mine;
   for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
   const int ntot = __shfl(incl, 63, 64);
@@ -248,13 +254,13 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   {
     int pos = incl - mine;
 #pragma unroll
-    for (int trip = 0; trip < 2; ++trip) {
+    for (int trip = 0; trip < BTRIPS; ++trip) {
       uint64_t mm = cand[trip];
       const int sidx = trip * 64 + lane;
       while (mm) {
         const int bit = __ffsll((long long)mm) - 1;
         mm &= mm - 1ull;
-        s_cand[pos++] = (uint16_t)(((int)((cusd[trip] >> bit) & 1ull) << 13) | (sidx << 6) | bit);
+        s_cand[pos++] = (uint16_t)(((int)((cusd[trip] >> bit) & 1ull) << 15) | (sidx << 6) | bit);
       }
     }
   }
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
       bool keep = false, is_used = false;
       if (q < ntot) {
         const int cb = s_cand[q];
-        const int sidx = (cb >> 6) & 127, bit = cb & 63;
-        is_used = (cb >> 13) != 0;
+        const int sidx = (cb >> 6) & 511, bit = cb & 63;
+        is_used = (cb >> 15) != 0;
         const int bi = sidx % NB - Bh, bj = (sidx / NB) % NB - Bh, bk = sidx / (NB * NB) - Bh;
         // bit = z0 y0 x0 z1 y1 x1 (brick_local)
         const int lx = ((bit >> 2) & 1) | (((bit >> 5) & 1) << 1), ly = ((bit >> 1) & 1) | (((bit >> 4) & 1) << 1), lz = (bit & 1) | (((bit >> 3) & 1) << 1);
@@ -401,7 +407,7 @@ static vgs_status build_hash_and_offsets(vgs_ctx* c, float* r2_out) {
     }
     const int Bh = (Rm + 3) / 4, NB = 2 * Bh + 1, NB3 = NB * NB * NB;
     c->adj_mask_nb = 0;
-    if (NB == 3 || NB == 5) {
+    if (NB == 3 || NB == 5 || NB == 7) {
       std::vector<uint64_t> masks((size_t)64 * NB3, 0ull);
       for (int p = 0; p < 64; ++p) {
         const int px = p & 3, py = (p >> 2) & 3, pz = p >> 4;
@@ -476,7 +482,7 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
 #define LAUNCH_ADJ(CAPV, FULLV, GRID, REDO, NREDO, REDO_OUT)                                                                 \
   hipLaunchKernelGGL((k_adjacency<CAPV, FULLV>), dim3(GRID), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,            \
                      (const Brick*)c->hkey.p, c->hbits, c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, \
-                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT, off)
+                     c->adj_stride, out_key, out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, REDO, NREDO, REDO_OUT, off, NREDO)
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
   if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !c->K.no_adjmasks) {
     // hot path: candidates from the brick occupancy masks; rows it cannot take go through the general kernel
@@ -484,13 +490,32 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
     VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
 #define LAUNCH_ADJM(NBV)                                                                                                          \
-    hipLaunchKernelGGL((k_adjacency_masks<240, NBV>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,  \
+    hipLaunchKernelGGL((k_adjacency_masks<240, NBV, 5>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,  \
                        (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
                        out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p, off)
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
 #undef LAUNCH_ADJM
     // rows it passed on (more candidates than its list): the general kernel, a fixed grid striding over the device-side list
     LAUNCH_ADJ(1024, false, (unsigned int)(U < 2048 ? U : 2048), c->work_ids.p, d_nredo, nullptr);
+  } else if (c->n_off <= 8192 && !full && c->adj_mask_nb == 7 && gt && !c->K.no_adjmasks) {
+    // balls of up to 12 voxels (config 2: ten): candidates from the occupancy masks of 7 x 7 x 7 bricks -- a planar neighbourhood
+    // occupies 305 of the 4189 ball cells; rows with more than 512 candidates or survivors go down the general kernel's two passes
+    VGS_HIP_TRY(c, c->work_ids.ensure(2 * (size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
+    unsigned int* d_n1 = (unsigned int*)(c->counters.p + 40);
+    unsigned int* d_n2 = (unsigned int*)(c->counters.p + 41);
+    VGS_HIP_TRY(c, hipMemsetAsync(d_n1, 0, 16, c->stream));
+    uint32_t* list1 = c->work_ids.p;
+    uint32_t* list2 = c->work_ids.p + U;
+    hipLaunchKernelGGL((k_adjacency_masks<512, 7, 8>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,
+                       (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,
+                       out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_n1, list1, off);
+    const unsigned int g2 = (unsigned int)(U < 4096 ? U : 4096);   // the grids stride over the device-side lists
+    hipLaunchKernelGGL((k_adjacency<2048, false>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U, (const Brick*)c->hkey.p, c->hbits,
+                       c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride, out_key, out_cnt, out_nall, gt,
+                       c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, list1, d_n1, list2, off, d_n2);
+    hipLaunchKernelGGL((k_adjacency<8192, false>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U, (const Brick*)c->hkey.p, c->hbits,
+                       c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride, out_key, out_cnt, out_nall, gt,
+                       c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, list2, d_n2, (uint32_t*)nullptr, off, d_n2);
   } else if (c->n_off <= 1024) {
     if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);
   } else if (c->n_off <= 8192) {

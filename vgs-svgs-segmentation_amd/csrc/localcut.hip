@@ -543,12 +543,12 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
 // ones the lazy schedule works on for long or gives up on, so they form class A1, the part of the bulk launch that is
 // dealt out first.  (Any voxel may go to any class: the split only schedules.)
 // One global atomic per class and 1024 voxels (same-address atomics serialise).
-#define LC_NCLASS 5   // A, B, C, D, A1
+#define LC_NCLASS 6   // A, B, C, D, A1, C0 (the part of class C up to max_c0 neighbours: a smaller LDS footprint, one more workgroup per CU)
 __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
                                                    int max_a, int max_b, int max_c, const uint32_t* __restrict__ used_ids,
                                                    const uint8_t* __restrict__ nl_cnt, const uint32_t* __restrict__ nl_tot, int a1_max, uint32_t* __restrict__ ids_a,
                                                    uint32_t* __restrict__ ids_b, uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d,
-                                                   uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc) {
+                                                   uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc, int max_c0, uint32_t* __restrict__ ids_c0) {
   __shared__ unsigned int s_cnt[16][LC_NCLASS];   // per wavefront and class: count, then base
   __shared__ unsigned int s_base[LC_NCLASS];
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
   int cls = -1;
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
-    cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3));
+    cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 5 : (m <= max_c ? 2 : 3)));
     if (cls == 0 && nl_cnt && nl_cnt[used_ids[u]] != NL_NONE && (int)nl_tot[used_ids[u]] <= a1_max) cls = 4;   // a voxel without a list stays in A
   }
   unsigned long long mk[LC_NCLASS];
@@ -572,27 +572,27 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
     s_base[k] = tot ? atomicAdd(&n_abc[k], tot) : 0u;
   }
   __syncthreads();
-  uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1};
+  uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1, ids_c0};
   for (int k = 0; k < LC_NCLASS; ++k)
     if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }
 
 // Class sizes alone (A and A1 together): what the host needs to size the launches does not depend on the near-pair lists, so it is
 // counted BEFORE they are built and fetched while they are (vgs_stage_localcut).
-__global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restrict__ adj_cnt, int64_t U, int max_a, int max_b, int max_c,
-                                                        unsigned int* __restrict__ n_cls /* 4 */) {
-  __shared__ unsigned int s_cnt[4];
-  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+__global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restrict__ adj_cnt, int64_t U, int max_a, int max_b, int max_c, int max_c0,
+                                                        unsigned int* __restrict__ n_cls /* 5: A + A1, B, C, D, C0 */) {
+  __shared__ unsigned int s_cnt[5];
+  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cls = -1;
-  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c ? 2 : 3)); }
-  for (int k = 0; k < 4; ++k) {
+  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); }
+  for (int k = 0; k < 5; ++k) {
     const unsigned long long mk = __ballot(cls == k);
     if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_cnt[k], (unsigned int)__popcll(mk));
   }
   __syncthreads();
-  if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // Smallest squared distance (to the bisection's resolution) whose weight bound is at or below a singleton's threshold:
@@ -690,7 +690,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure((8 + LW_HO_BINS) * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure((9 + LW_HO_BINS) * (size_t)U + 16));
   VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
   VGS_HIP_TRY(c, c->counters.ensure(64));
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
@@ -701,6 +701,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   uint32_t* ids_f = c->work_ids.p + 8 * U;    // handed over by the A/B wave kernels (m <= WAVE_B): LW_HO_BINS lists of U slots, by neighbourhood size
   uint32_t* ids_g = c->work_ids.p + 5 * U;    // handed over by the C wave kernel
   uint32_t* ids_a1 = c->work_ids.p + 6 * U;   // class A voxels with a short near-pair list of their own: they run first
+  uint32_t* ids_c0 = c->work_ids.p + (8 + LW_HO_BINS) * U;   // class C0: WAVE_B < m <= WAVE_C0
   uint32_t* ids_f2 = c->work_ids.p + 7 * U;   // sent on by the dense hand-over kernel (a list overflowed)
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 5 class counters (words 8-10)
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);        // lengths of the LW_HO_BINS lists (words 14-15)
@@ -717,6 +718,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   constexpr int LCAP_A = 448, LCAP_B = 312, LCAP_C = LW_LCAP_C;
   constexpr unsigned int GRID_F = 16384, GRID_G = 1024;
   constexpr int NW_C = 4;  // wavefronts per voxel in class C (they share 33 KB of LDS)
+  // Class C0 (round 4): the planar neighbourhoods of a ball of ten voxels hold pi * 100 = 314 voxels -- 61 % of config 2's class C are
+  // at most 320 -- and class C is latency bound at the five 31.8 KB workgroups a CU holds.  The same kernel for up to 320 vertices
+  // with a 2032-edge list takes 26.8 KB = 21 LDS granules: SIX per CU.
+  constexpr int WAVE_C0 = 320, LCAP_C0 = 2032;
   constexpr int WAVE_D = 1024, LCAP_D = 4096, NW_D = 8;  // class D: 66 KB of LDS per voxel, two voxels per CU  // fixed grids of the hand-over launches  // A and B: exactly 5 KB of LDS per wavefront (32 wavefronts per CU)
     constexpr int SMALL_M = 128, SMALL_CAP = LC_SMALL_CAP;
   constexpr int LARGE_M = 2048, LARGE_CAP = 8192;
@@ -728,10 +733,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 #else
   const bool early_sizes = vgs_can_split_readback(c);
 #endif
-  unsigned int* d_ncls = (unsigned int*)(c->counters.p + 44);   // words 44-45: A + A1, B, C, D
+  unsigned int* d_ncls = (unsigned int*)(c->counters.p + 44);   // words 44-46: A + A1, B, C, D, C0
+  const int max_c0 = c->K.no_c0 ? WAVE_B : WAVE_C0;   // VGS_NO_C0: class C takes them all
   if (early_sizes) {
-    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, d_ncls);
-    vgs_status sb = vgs_readback_begin(c, d_ncls, 16);
+    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls);
+    vgs_status sb = vgs_readback_begin(c, d_ncls, 20);
     if (sb != VGS_OK) return sb;
   }
   {
@@ -743,14 +749,14 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const int a1_max = c->K.a1_max;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
                      0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, c->nl_tot.p, a1_max, ids_a, ids_b, ids_c,
-                     ids_d, ids_a1, d_nabc);
-  unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0};
+                     ids_d, ids_a1, d_nabc, max_c0, ids_c0);
+  unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0, 0};
   unsigned int n_bulk = 0;   // A + A1
   if (early_sizes) {
-    unsigned int ncls[4] = {0, 0, 0, 0};
-    vgs_status se = vgs_readback_end(c, ncls, 16);
+    unsigned int ncls[5] = {0, 0, 0, 0, 0};
+    vgs_status se = vgs_readback_end(c, ncls, 20);
     if (se != VGS_OK) return se;
-    n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3];
+    n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3]; nabc[5] = ncls[4];
     nabc[0] = n_bulk; nabc[4] = 0;   // (host-side bookkeeping only: the kernel reads the split from d_nabc)
   } else {
     VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
@@ -862,21 +868,27 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   {
     // class D (more than 512 neighbours) on its own stream: eight wavefronts per voxel up to 1024 neighbours; beyond
     // that the kernel hands the voxel over (list g) to the workgroup kernel with its histogram rounds
-    if (nabc[3] > 0) {
+    if (nabc[3] + nabc[5] > 0) {
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev[2], 0));
+      // class C0 shares class D's side stream (D is a handful of voxels): it runs beside class C, its hand-overs join C's list
+      if (nabc[5] > 0)
+        hipLaunchKernelGGL((k_localcut_wave<WAVE_C0, LCAP_C0, NW_C>), dim3(((nabc[5] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream4, (const uint32_t*)nullptr, 0,
+                           ids_c0, (int)nabc[5], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
+                           ids_g, d_ng, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
+      if (nabc[3] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_D, LCAP_D, NW_D>), dim3(((nabc[3] + 7) / 8) * 8), dim3(64 * NW_D), 0, c->stream4, (const uint32_t*)nullptr, 0,
                          ids_d, (int)nabc[3], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt,
                          ids_g, d_ng, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
       VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
-      VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows both C and D
     }
     if (nabc[2] > 0)
       hipLaunchKernelGGL((k_localcut_wave<WAVE_C, LCAP_C, NW_C>), dim3(((nabc[2] + 7) / 8) * 8), dim3(64 * NW_C), 0, c->stream2, (const uint32_t*)nullptr, 0, ids_c, (int)nabc[2], (const unsigned int*)nullptr,
                          c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_g, d_ng, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
     VGS_HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));   // class C done (its hand-overs follow)
+    if (nabc[3] + nabc[5] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));   // the hand-over launch below follows C, C0 and D
     // class C / D hand-overs: fixed grid, length read on the device (no host round trip)
     vgs_status st = VGS_OK;
-    const unsigned int ncd = nabc[2] + nabc[3];
+    const unsigned int ncd = nabc[2] + nabc[3] + nabc[5];
     if (ncd > 0) {
       if (!dense) st = launch_block(c->stream2, ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
       else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
@@ -931,7 +943,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // the main stream goes on once every class has produced its rows or marked them pending
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[5], 0));
-  if (nabc[3] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[12], 0));
+  if (nabc[3] + nabc[5] > 0) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[12], 0));
   if (c->K.no_overlap) {   // diagnostics: the merge stage starts behind the hand-over kernels
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
@@ -942,8 +954,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   }
   c->lc_tail.grid_f = grid_f;
   for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
+  c->lc_tail.nabc[2] += nabc[5];
   VGS_HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));   // end of the stage's main-stream work (vgs_localcut_finish measures the tail behind it)
-  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
+  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2] + nabc[5]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
   c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
   VGS_HIP_TRY(c, hipGetLastError());
   return VGS_OK;

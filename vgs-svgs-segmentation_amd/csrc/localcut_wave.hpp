@@ -143,7 +143,9 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   constexpr bool NEAR = SMALL && NW == 1;
   constexpr int NMAP_DIM = 2 * NL_BALL + 1;
   constexpr int NMAP_BYTES = (NMAP_DIM * NMAP_DIM * NMAP_DIM + 3) / 4 * 4;
-  constexpr int CBUF_BYTES = (NEAR && NMAP_BYTES + 2 * MAXM > 12 * MAXM) ? NMAP_BYTES + 2 * MAXM : 12 * MAXM;
+  constexpr int HCAP_ = (!SMALL || NW > 1) ? (MAXM <= 512 ? 1024 : 2048) : 1;   // (the hash of the multi-wavefront classes, see below)
+  constexpr int CBUF_BYTES = (NEAR && NMAP_BYTES + 2 * MAXM > 12 * MAXM) ? NMAP_BYTES + 2 * MAXM
+                           : (((!SMALL || NW > 1) && HCAP_ * 4 + 2 * MAXM > 12 * MAXM) ? HCAP_ * 4 + 2 * MAXM : 12 * MAXM);
   __shared__ __attribute__((aligned(16))) unsigned char cbuf[CBUF_BYTES];
   float* const cx = (float*)cbuf;
   float* const cy = cx + MAXM;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
   // Both live in the centroids' bytes (as the one-wavefront classes' map does): the general enumeration stages the
   // centroids when it first runs, and the lists are not read after that -- with arrays of its own the class-C workgroup
   // grew from 31.8 to 36.9 KB, four per CU instead of five, and every scene got 18 % slower.
-  constexpr int HCAP = NEARH ? (MAXM <= 512 ? 1024 : 2048) : 1;
+  constexpr int HCAP = NEARH ? HCAP_ : 1;
   static_assert(!NEARH || HCAP * 4 + 2 * MAXM <= CBUF_BYTES, "hash and offsets must fit the centroid buffer");
   uint32_t* const htab = (uint32_t*)cbuf;
   uint16_t* const hlat = (uint16_t*)(cbuf + (size_t)HCAP * 4);

@@ -92,6 +92,7 @@ struct VgsKnobs {
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
+  bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool debug = false;        // VGS_DEBUG
 };
