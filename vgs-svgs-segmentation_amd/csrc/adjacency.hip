@@ -499,14 +499,14 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     LAUNCH_ADJ(1024, false, (unsigned int)(U < 2048 ? U : 2048), c->work_ids.p, d_nredo, nullptr);
   } else if (c->n_off <= 8192 && !full && c->adj_mask_nb == 7 && gt && !c->K.no_adjmasks) {
     // balls of up to 12 voxels (config 2: ten): candidates from the occupancy masks of 7 x 7 x 7 bricks -- a planar neighbourhood
-    // occupies 305 of the 4189 ball cells; rows with more than 512 candidates or survivors go down the general kernel's two passes
+    // occupies 305 of the 4189 ball cells (up to 832 occupied cells are taken as candidates: the unused voxels count too); rows with more candidates, or more than 512 survivors, go down the general kernel's two passes
     VGS_HIP_TRY(c, c->work_ids.ensure(2 * (size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
     unsigned int* d_n1 = (unsigned int*)(c->counters.p + 40);
     unsigned int* d_n2 = (unsigned int*)(c->counters.p + 41);
     VGS_HIP_TRY(c, hipMemsetAsync(d_n1, 0, 16, c->stream));
     uint32_t* list1 = c->work_ids.p;
     uint32_t* list2 = c->work_ids.p + U;
-    hipLaunchKernelGGL((k_adjacency_masks<512, 7, 8>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,
+    hipLaunchKernelGGL((k_adjacency_masks<512, 7, 13>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,
                        (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,
                        out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_n1, list1, off);
     const unsigned int g2 = (unsigned int)(U < 4096 ? U : 4096);   // the grids stride over the device-side lists

@@ -450,13 +450,36 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
           bx[k] = cx[vb[k]]; by[k] = cy[vb[k]]; bz[k] = cz[vb[k]];
           diff[k] = ok[k] && (!merged || seg[va[k]] != seg[vb[k]]);
         }
+        // the trip's candidates are appended together: one LDS counter round trip per trip instead of one per pair of the lane
+        // (multi-wavefront classes; same list order as pair-by-pair appends)
+        bool inr[LW_TRIP];
+        unsigned long long mks[LW_TRIP];
+        int tot = 0;
 #pragma unroll
         for (int k = 0; k < LW_TRIP; ++k) {
           const float dx = ax[k] - bx[k], dy = ay[k] - by[k], dz = az[k] - bz[k];
           float d2 = (dx * dx + dy * dy) + dz * dz;
           d2 = (d2 == d2) ? d2 : 1.0e4f;  // dist_space stays 100 when a centroid has a zero component (VS:1829)
-          const bool inr = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
-          append(inr, ((uint32_t)va[k] << PSH) | (uint32_t)vb[k]);
+          inr[k] = diff[k] && (d2 >= cut_lo) && (final_round || d2 < cut_hi);
+          mks[k] = __ballot(inr[k]);
+          tot += __popcll(mks[k]);
+        }
+        int base_t;
+        if constexpr (NW == 1) {
+          base_t = count;
+          count += tot;
+        } else {
+          int b0 = 0;
+          if (tot != 0 && lane == 0) b0 = atomicAdd(&sh_i[SH_COUNT], tot);
+          base_t = __builtin_amdgcn_readfirstlane(b0);
+        }
+#pragma unroll
+        for (int k = 0; k < LW_TRIP; ++k) {
+          if (inr[k]) {
+            const int pos = n_list + base_t + __popcll(mks[k] & lt_mask);
+            if (pos < LCAP) lk[pos] = (uint64_t)(((uint32_t)va[k] << PSH) | (uint32_t)vb[k]);
+          }
+          base_t += __popcll(mks[k]);
         }
       }
     }
@@ -633,15 +656,23 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       }
     };
     const int j = lane & 15;
-    for (int base = wave * 4; base < m; base += NW * 4) {
+    static_assert(NL_S <= 16, "one trip reads a whole list");
+    // Two dependent global loads per trip (the vertex's voxel id out of the row, then its list) used to be waited for trip by
+    // trip -- 19 trips of ~2100 cycles for 305 vertices.  Now the ids run two trips ahead and the entries one (round 4).
+    constexpr int STEP = NW * 4;
+    const int v0 = wave * 4 + (lane >> 4);
+    const float4 none4 = make_float4(__builtin_huge_valf(), 0.f, 0.f, 0.f);
+    uint32_t id_next = (v0 + STEP < m) ? (uint32_t)row[v0 + STEP] : 0u;                    // ids of trip 1
+    float4 E_next = none4;                                                                 // entries of trip 0
+    if (v0 < m && j < NL_S) E_next = P.near.ent[(size_t)(uint32_t)row[v0] * NL_S + (size_t)j];
+    for (int base = wave * 4; base < m; base += STEP) {
       const int va = base + (lane >> 4);
       const bool act = va < m;
-      for (int c0 = 0; c0 < NL_S; c0 += 16) {   // sixteen entries of four vertices at a time; lists are sorted: stop behind the shell
-        float4 E = make_float4(__builtin_huge_valf(), 0.f, 0.f, 0.f);
-        if (act && c0 + j < NL_S) E = P.near.ent[(size_t)(uint32_t)row[va] * NL_S + (size_t)(c0 + j)];
-        take(va, act, E);
-        if (__ballot(act && j == 15 && E.x < cut_hi) == 0ull) break;
-      }
+      const float4 E = E_next;
+      E_next = none4;
+      if (va + STEP < m && j < NL_S) E_next = P.near.ent[(size_t)id_next * NL_S + (size_t)j];
+      id_next = (va + 2 * STEP < m) ? (uint32_t)row[va + 2 * STEP] : 0u;
+      take(va, act, E);
     }
   };
 
