@@ -141,6 +141,65 @@ __global__ void k_vccs_plant(const unsigned long long* __restrict__ seed_key, in
 // label and only the table goes to memory: one global atomic per (workgroup, supervoxel, component) instead of fourteen
 // per voxel that changes -- the contended 64-bit atomics were half of the stage's time.  Integer sums: any order, same result.
 #define VX_SLOTS 128
+// The best offer among the labels of the 26 neighbours.  A voxel on a border sees two to four other supervoxels, each through
+// several neighbours, and the evaluation of one label is a gather of the supervoxel's state and a wait for it: the DISTINCT labels
+// are enumerated first and the states of the first four requested together.  (Round 4: the rounds turned out to be bound by
+// instruction issue, not by memory -- 26 x (five compares, an if-chain over four registers) of half-rate VALU per voxel.)  The
+// enumeration is arithmetic: key = (label ^ ref) - 1 with ref = the voxel's own label is 0xffffffff for the own label, >= 2^31 for
+// "no neighbour" (-1) and < 2^31 for every other label (labels stay below 2^31 - 2); the smallest key is a minimum over 26 values (v_min3), and the next one
+// is the minimum of key - (previous + 1) in unsigned arithmetic, where everything already taken wraps to the top: one subtraction
+// and a third of a min3 per neighbour and level, all full rate, and a level is only run while some lane of the wavefront still
+// has a label to find.  Minimum by (distance, label): the order of evaluation does not matter.
+__device__ __forceinline__ uint32_t vx_min26(const uint32_t (&k)[26], uint32_t c) {
+  uint32_t m = 0xffffffffu - c;   // the voxel's own key as a 27th value: when every neighbour's label has been taken, the minimum must not wrap round to one of them
+#pragma unroll
+  for (int o = 0; o < 26; o += 2) m = min(m, min(k[o] - c, k[o + 1] - c));
+  return m;
+}
+__device__ __forceinline__ void vccs_best_offer(const int (&nl)[26], int own, const float (&c)[3], const float (&n)[3], const VccsState* __restrict__ st,
+                                                float w_s_over_seed, float w_n, int& best_l, float& best_d) {
+  const uint32_t ref = own >= 0 ? (uint32_t)own : 0x7ffffffeu;   // (an unowned voxel: -1 ^ ref must stay above 2^31 after the decrement)
+  uint32_t key[26];
+#pragma unroll
+  for (int o = 0; o < 26; ++o) key[o] = ((uint32_t)nl[o] ^ ref) - 1u;
+  int sl[4] = {-1, -1, -1, -1};
+  bool more = true;
+  uint32_t off = 0u;
+  bool live[4] = {false, false, false, false};   // (wave-uniform) some lane has a label at this level
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q > 0 && !live[q - 1]) break;
+    const uint32_t kq = vx_min26(key, off) + off;
+    more = more && kq < 0x80000000u;
+    live[q] = __ballot(more) != 0ull;
+    if (!live[q]) break;
+    sl[q] = more ? (int)((kq + 1u) ^ ref) : -1;
+    off = kq + 1u;
+  }
+  VccsState A[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (live[q]) A[q] = st[sl[q] >= 0 ? sl[q] : 0];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!live[q]) continue;
+    const int l = sl[q];
+    const float d = vccs_distance(c, n, A[q].c, A[q].n, w_s_over_seed, w_n);
+    if (l >= 0 && (d < best_d || (d == best_d && l < best_l))) { best_d = d; best_l = l; }
+  }
+  // a fifth label and beyond (corners where many supervoxels meet): one at a time
+  while (live[3] && __ballot(more) != 0ull) {
+    const uint32_t kq = vx_min26(key, off) + off;
+    more = more && kq < 0x80000000u;
+    if (__ballot(more) == 0ull) break;
+    off = kq + 1u;
+    const int l = (int)((kq + 1u) ^ ref);
+    if (more && l >= 0) {
+      const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
+      if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int4* __restrict__ nbr4, const float* __restrict__ cen,
                               const float* __restrict__ nrm, const int32_t* __restrict__ label_in, const float* __restrict__ dist_in,
                               const VccsState* __restrict__ st, float w_s_over_seed, float w_n, int32_t* __restrict__ label_out,
@@ -173,15 +232,7 @@ __global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int4* __re
     }
 #pragma unroll
     for (int o = 0; o < 26; ++o) nl[o] = nl[o] >= 0 ? label_in[nl[o]] : -1;
-    int last = own;
-#pragma unroll
-    for (int o = 0; o < 26; ++o) {
-      const int l = nl[o];
-      if (l < 0 || l == own || l == last) continue;  // the label just tried gives the same distance again
-      last = l;
-      const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
-      if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
-    }
+    vccs_best_offer(nl, own, c, n, st, w_s_over_seed, w_n, best_l, best_d);
     label_out[v] = best_l;
     dist_out[v] = best_d;
     // moving this voxel's contribution from its old owner to the new one gives exactly the sums a full re-accumulation
@@ -218,6 +269,163 @@ __global__ __launch_bounds__(256) void k_vccs_expand(int64_t V, const int4* __re
     for (int a = 0; a < 6; ++a) { const unsigned long long x = s_sum[k][a]; if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], x); }
     const int dc = s_cnt[k];
     if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
+  }
+}
+
+// ---------------------------------------------------------------- expansion over tiles (round 4)
+// The round above is bound by its vector-memory instructions: per voxel seven loads of neighbour ids and 26 divergent gathers of
+// their labels, 216 B through the memory pipeline.  Voxels are sorted by Morton code, so an aligned 8 x 8 x 8 block of lattice
+// cells -- a TILE -- is one contiguous run of the voxel array (about 60 voxels on a scanned surface).  One wavefront takes one tile:
+// it writes the labels of the tile's own voxels (a coalesced load) and of the voxels in the one-cell shell around it (a list built
+// once per run: at most seven tiles see a voxel in their shell) into a 10 x 10 x 10 array in LDS, and every voxel then reads its
+// 26 neighbours from there (the array is first filled with "no voxel": four 16-byte LDS stores per lane).  Per voxel and round
+// that is 4 B of label, 2 B of cell index and about 12 B of shell instead of the 216.  Same synchronous round, same result.
+#define VT_CELLS 1000
+#define VT_SHELL 488
+__device__ __forceinline__ void vt_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+__global__ void k_vccs_tile_heads(const uint64_t* __restrict__ code, int64_t V, uint32_t* __restrict__ head) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  head[v] = (v == 0 || (code[v - 1] >> 9) != (code[v] >> 9)) ? 1u : 0u;
+}
+__global__ void k_vccs_tile_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ scan, int64_t V, uint32_t* __restrict__ tile_start) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  if (head[v]) tile_start[scan[v] - 1u] = (uint32_t)v;
+  if (v == V - 1) tile_start[scan[v]] = (uint32_t)V;
+}
+// per voxel: its cell in the tile's 10^3 array; per tile: the (voxel, cell) list of its shell
+__global__ __launch_bounds__(256) void k_vccs_tile_build(const uint64_t* __restrict__ vox_code, int64_t V, const int32_t* __restrict__ nbr,
+                                                         const uint32_t* __restrict__ tile_start, int T, uint16_t* __restrict__ cell,
+                                                         uint2* __restrict__ halo, unsigned long long pool_cap,
+                                                         unsigned long long* __restrict__ pool_count, uint2* __restrict__ meta) {
+  __shared__ uint32_t s_seen[4][32];
+  __shared__ uint2 s_ent[4][VT_SHELL];
+  __shared__ int s_n[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = (int)blockIdx.x * 4 + w;
+  if (t >= T) return;
+  if (lane < 32) s_seen[w][lane] = 0u;
+  if (lane == 0) s_n[w] = 0;
+  vt_sync();
+  const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+  for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) {
+    const uint32_t lo = (uint32_t)vox_code[v] & 511u;   // z0 y0 x0 z1 y1 x1 z2 y2 x2 from bit 0
+    const int z = (int)((lo & 1u) | ((lo >> 2) & 2u) | ((lo >> 4) & 4u));
+    const int y = (int)(((lo >> 1) & 1u) | ((lo >> 3) & 2u) | ((lo >> 5) & 4u));
+    const int x = (int)(((lo >> 2) & 1u) | ((lo >> 4) & 2u) | ((lo >> 6) & 4u));
+    const int ci = (x + 1) + 10 * (y + 1) + 100 * (z + 1);
+    for (int o = 0; o < 26; ++o) {
+      const int u = nbr[(int64_t)o * V + v];
+      if (u < 0) continue;
+      int dx, dy, dz;
+      vccs_offset(o, &dx, &dy, &dz);
+      if ((unsigned)(x + dx) < 8u && (unsigned)(y + dy) < 8u && (unsigned)(z + dz) < 8u) continue;   // one of the tile's own
+      const int cu = ci + dx + 10 * dy + 100 * dz;
+      const uint32_t bit = 1u << (cu & 31);
+      if (!(atomicOr(&s_seen[w][cu >> 5], bit) & bit)) s_ent[w][atomicAdd(&s_n[w], 1)] = make_uint2((uint32_t)u, (uint32_t)cu);
+    }
+    cell[v] = (uint16_t)ci;
+  }
+  vt_sync();
+  const int n = s_n[w];
+  unsigned long long off = 0ull;
+  if (lane == 0) off = atomicAdd(pool_count, (unsigned long long)n);
+  off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0, 64) << 32) | (unsigned long long)(uint32_t)__shfl((int)off, 0, 64);
+  if (off + (unsigned long long)n > pool_cap) { if (lane == 0) meta[t] = make_uint2(0u, 0xffffffffu); return; }   // cannot happen (<= 7 V entries); checked by the host
+  for (int i = lane; i < n; i += 64) halo[off + (unsigned long long)i] = s_ent[w][i];
+  if (lane == 0) meta[t] = make_uint2((uint32_t)off, (uint32_t)n);
+}
+#define VT_SLOTS 16
+__global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta,
+                              const uint2* __restrict__ halo, const uint16_t* __restrict__ cell,
+                              const float* __restrict__ cen, const float* __restrict__ nrm, const int32_t* __restrict__ label_in,
+                              const float* __restrict__ dist_in, const VccsState* __restrict__ st, float w_s_over_seed, float w_n,
+                              int32_t* __restrict__ label_out, float* __restrict__ dist_out, long long* __restrict__ sums,
+                              unsigned int* __restrict__ count) {
+  // one wavefront = one workgroup = one tile: no workgroup barrier, a tile of 500 voxels holds nobody else up, 5 KB of LDS
+  __shared__ __attribute__((aligned(16))) int L[VT_CELLS];
+  __shared__ int s_key[VT_SLOTS];
+  __shared__ unsigned long long s_sum[VT_SLOTS][6];
+  __shared__ int s_cnt[VT_SLOTS];
+  const int lane = threadIdx.x;
+  const int t = (int)blockIdx.x;
+  if (lane < VT_SLOTS) {
+    s_key[lane] = -1; s_cnt[lane] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0ull;
+  }
+  for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);   // an empty cell reads as "no neighbour"
+  const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+  const uint2 m = meta[t];
+  // what the first 64 voxels need is requested before the shell is staged
+  struct Vox { int ci; float d; float c[3]; float n[3]; };
+  auto load_vox = [&](uint32_t v, Vox& x) {
+    x.ci = (int)cell[v]; x.d = dist_in[v];
+    for (int a = 0; a < 3; ++a) { x.c[a] = cen[3 * (int64_t)v + a]; x.n[a] = nrm[3 * (int64_t)v + a]; }
+  };
+  Vox x0;
+  int lab0 = -1;
+  const uint32_t v0 = ts + (uint32_t)lane;
+  if (v0 < te) { load_vox(v0, x0); lab0 = label_in[v0]; }
+  vt_sync();
+  for (uint32_t i = (uint32_t)lane; i < m.y; i += 64u) { const uint2 e = halo[m.x + i]; L[e.y] = label_in[e.x]; }
+  if (v0 < te) L[x0.ci] = lab0;
+  for (uint32_t v = v0 + 64u; v < te; v += 64u) L[cell[v]] = label_in[v];
+  vt_sync();
+  bool touched = false;
+  for (uint32_t v = v0; v < te; v += 64u) {
+    Vox x;
+    if (v == v0) x = x0; else load_vox(v, x);
+    const int ci = x.ci;
+    const int own = L[ci];
+    int best_l = own;
+    float best_d = x.d;
+    int nl[26];
+#pragma unroll
+    for (int o = 0; o < 26; ++o) {
+      const int k = o < 13 ? o : o + 1;   // vccs_offset(o)
+      nl[o] = L[ci + (k % 3 - 1) + 10 * ((k / 3) % 3 - 1) + 100 * (k / 9 - 1)];
+    }
+    vccs_best_offer(nl, own, x.c, x.n, st, w_s_over_seed, w_n, best_l, best_d);
+    label_out[v] = best_l;
+    dist_out[v] = best_d;
+    if (best_l != own) {
+      touched = true;
+      long long f[6];
+      for (int a = 0; a < 3; ++a) { f[a] = vccs_fix_pos(x.c[a]); f[3 + a] = vccs_fix_nrm(x.n[a]); }
+      for (int side = 0; side < 2; ++side) {
+        const int l = side ? best_l : own;
+        if (l < 0) continue;
+        const long long sgn = side ? 1 : -1;
+        int slot = -1;
+        unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
+        for (int probe = 0; probe < VT_SLOTS; ++probe) {
+          const int prev = atomicCAS(&s_key[h], -1, l);
+          if (prev == -1 || prev == l) { slot = (int)h; break; }
+          h = (h + 1) & (VT_SLOTS - 1);
+        }
+        if (slot >= 0) {
+          for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], (unsigned long long)(sgn * f[a]));
+          atomicAdd(&s_cnt[slot], (int)sgn);
+        } else {
+          for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)(sgn * f[a]));
+          if (side) atomicAdd(&count[l], 1u); else atomicSub(&count[l], 1u);
+        }
+      }
+    }
+  }
+  if (__ballot(touched) == 0ull) return;
+  vt_sync();
+  if (lane < VT_SLOTS) {
+    const int l = s_key[lane];
+    if (l >= 0) {
+      for (int a = 0; a < 6; ++a) { const unsigned long long x = s_sum[lane][a]; if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], x); }
+      const int dc = s_cnt[lane];
+      if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
+    }
   }
 }
 
@@ -681,15 +889,29 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
-  VGS_HIP_TRY(c, c->vc_nbr4.ensure(28 * (size_t)V));
+  if (c->K.no_vccs_tiles) VGS_HIP_TRY(c, c->vc_nbr4.ensure(28 * (size_t)V));
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, nrm.p, (int4*)c->vc_nbr4.p);
+                     c->vc_nbr.p, nrm.p, c->K.no_vccs_tiles ? (int4*)c->vc_nbr4.p : (int4*)nullptr);
   // ---- seeds: one per occupied seed_res cell, snapped to the voxel nearest to the cell centre ----
   const float seed = c->P.seed_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
   VGS_HIP_TRY(c, c->cell_code_a.ensure(V)); VGS_HIP_TRY(c, c->cell_code_b.ensure(V));
   VGS_HIP_TRY(c, c->cell_id_a.ensure(V)); VGS_HIP_TRY(c, c->cell_id_b.ensure(V));
   VGS_HIP_TRY(c, c->head_flag.ensure(V + 1)); VGS_HIP_TRY(c, c->perm_a.ensure(V + 1));
+  // ---- tiles of the expansion rounds (k_vccs_expand_tiles): runs of equal code >> 9, numbered by a scan; their number comes back with
+  // the number of seeds below
+  const bool tiles = !c->K.no_vccs_tiles;
+  uint32_t T32 = 0;
+  if (tiles) {
+    size_t scan_bytes_t = 0;
+    VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+    VGS_HIP_TRY(c, c->sort_tmp.ensure(scan_bytes_t));
+    VGS_HIP_TRY(c, c->vc_tile_start.ensure(V + 1));
+    hipLaunchKernelGGL(k_vccs_tile_heads, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->head_flag.p);
+    VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p);
+    VGS_HIP_TRY(c, hipMemcpyAsync(&T32, c->perm_a.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
+  }
   hipLaunchKernelGGL(k_vccs_cell_codes, dim3(nbV), dim3(TB), 0, c->stream, cen.p, V, mnx, mny, mnz, seed, c->cell_code_a.p, c->cell_id_a.p);
   size_t sort_bytes = 0, scan_bytes = 0;
   VGS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_bytes, c->cell_code_a.p, c->cell_code_b.p, c->cell_id_a.p, c->cell_id_b.p, (size_t)V, 0, 63, c->stream));
@@ -704,6 +926,16 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
   const int K = (int)K32;
   const unsigned nbK = (unsigned)((K + TB - 1) / TB);
+  const int NT = (int)T32;
+  const unsigned nbT = (unsigned)((NT + 3) / 4);   // the builder: four tiles per workgroup
+  if (tiles) {
+    const unsigned long long pool_cap = 7ull * (unsigned long long)V;   // a voxel lies in the shell of at most seven tiles
+    VGS_HIP_TRY(c, c->vc_cell.ensure(V)); VGS_HIP_TRY(c, c->vc_halo.ensure(pool_cap));
+    VGS_HIP_TRY(c, c->vc_tile_meta.ensure(NT)); VGS_HIP_TRY(c, c->vc_pool.ensure(1));
+    VGS_HIP_TRY(c, hipMemsetAsync(c->vc_pool.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_vccs_tile_build, dim3(nbT), dim3(256), 0, c->stream, c->vox_code.p, V, c->vc_nbr.p, c->vc_tile_start.p, NT, c->vc_cell.p,
+                       (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p, (uint2*)c->vc_tile_meta.p);
+  }
   VGS_HIP_TRY(c, c->vc_seedkey.ensure(K)); VGS_HIP_TRY(c, c->vc_sums.ensure(6 * (size_t)K)); VGS_HIP_TRY(c, c->vc_count.ensure(K));
   VGS_HIP_TRY(c, c->vc_state.ensure(6 * (size_t)K));
   VccsState* state = (VccsState*)c->vc_state.p;
@@ -726,8 +958,13 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
     hipLaunchKernelGGL(k_vccs_reset, dim3(nbV), dim3(TB), 0, c->stream, V, lab[cur], dst[cur]);
     hipLaunchKernelGGL(k_vccs_plant, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, cen.p, nrm.p, lab[cur], dst[cur], state, c->vc_sums.p, c->vc_count.p);
     for (int it = 0; it < T; ++it) {
-      hipLaunchKernelGGL(k_vccs_expand, dim3(nbV), dim3(TB), 0, c->stream, V, (const int4*)c->vc_nbr4.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
-                         lab[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
+      if (tiles)
+        hipLaunchKernelGGL(k_vccs_expand_tiles, dim3((unsigned)NT), dim3(64), 0, c->stream, NT, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
+                           (const uint2*)c->vc_halo.p, c->vc_cell.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
+                           lab[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
+      else
+        hipLaunchKernelGGL(k_vccs_expand, dim3(nbV), dim3(TB), 0, c->stream, V, (const int4*)c->vc_nbr4.p, cen.p, nrm.p, lab[cur], dst[cur], state, w_s_over_seed, w_n,
+                           lab[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
       cur ^= 1;
       hipLaunchKernelGGL(k_vccs_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state);
     }

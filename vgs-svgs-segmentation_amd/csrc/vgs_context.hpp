@@ -92,6 +92,7 @@ struct VgsKnobs {
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
+  bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool debug = false;        // VGS_DEBUG
@@ -236,6 +237,9 @@ struct vgs_ctx {
   DevBuf<float> vc_cen, vc_nrm, vc_dist, vc_state;
   DevBuf<int32_t> vc_nbr, vc_label;
   DevBuf<int32_t> vc_nbr4;    // vc_nbr once more as [7][V] int4 (28 entries per voxel, two unused): four neighbours to a load for the expansion rounds
+  DevBuf<uint32_t> vc_tile_start;   // expansion over tiles (vccs.hip): start of every 8^3 tile's run of voxels
+  DevBuf<uint16_t> vc_cell;                    // a voxel's cell in its tile's 10^3 label array
+  DevBuf<uint64_t> vc_halo, vc_tile_meta, vc_pool;   // (voxel, cell) of the voxels in the tiles' shells; (offset, length) per tile; entries handed out
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
   DevBuf<uint32_t> vc_count;
