@@ -297,47 +297,73 @@ __global__ void k_vccs_tile_starts(const uint32_t* __restrict__ head, const uint
   if (head[v]) tile_start[scan[v] - 1u] = (uint32_t)v;
   if (v == V - 1) tile_start[scan[v]] = (uint32_t)V;
 }
-// per voxel: its cell in the tile's 10^3 array; per tile: the (voxel, cell) list of its shell
-__global__ __launch_bounds__(256) void k_vccs_tile_build(const uint64_t* __restrict__ vox_code, int64_t V, const int32_t* __restrict__ nbr,
-                                                         const uint32_t* __restrict__ tile_start, int T, uint16_t* __restrict__ cell,
-                                                         uint2* __restrict__ halo, unsigned long long pool_cap,
-                                                         unsigned long long* __restrict__ pool_count, uint2* __restrict__ meta) {
-  __shared__ uint32_t s_seen[4][32];
-  __shared__ uint2 s_ent[4][VT_SHELL];
-  __shared__ int s_n[4];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int t = (int)blockIdx.x * 4 + w;
-  if (t >= T) return;
-  if (lane < 32) s_seen[w][lane] = 0u;
-  if (lane == 0) s_n[w] = 0;
-  vt_sync();
+// Round 4, second step: the same arrangement BUILDS the tiles.  The wavefront writes the ids of its own voxels into the 10^3 array,
+// looks the 488 cells of the shell up in the brick table (five times fewer probes than 26 per voxel), and the array then answers
+// "who is my neighbour" for the normals: the [26][V] neighbour table of k_vccs_neighbours is neither written nor read.
+__global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restrict__ vox_code, int depth, const Brick* __restrict__ bricks, uint32_t hbits,
+                                                        const float* __restrict__ cen, const uint32_t* __restrict__ tile_start, uint16_t* __restrict__ cell,
+                                                        float* __restrict__ nrm, uint2* __restrict__ halo, unsigned long long pool_cap,
+                                                        unsigned long long* __restrict__ pool_count, uint2* __restrict__ meta) {
+  __shared__ __attribute__((aligned(16))) int I[VT_CELLS];
+  __shared__ uint2 s_ent[VT_SHELL];
+  __shared__ int s_n;
+  const int lane = threadIdx.x;
+  const int t = (int)blockIdx.x;
+  for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)I)[i] = make_int4(-1, -1, -1, -1);
+  if (lane == 0) s_n = 0;
   const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+  const uint64_t code0 = vox_code[ts];
+  const uint32_t ox = vm_compact21(code0 >> 2) & ~7u, oy = vm_compact21(code0 >> 1) & ~7u, oz = vm_compact21(code0) & ~7u;
+  const uint32_t lim = 1u << depth;
+  vt_sync();
   for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) {
     const uint32_t lo = (uint32_t)vox_code[v] & 511u;   // z0 y0 x0 z1 y1 x1 z2 y2 x2 from bit 0
     const int z = (int)((lo & 1u) | ((lo >> 2) & 2u) | ((lo >> 4) & 4u));
     const int y = (int)(((lo >> 1) & 1u) | ((lo >> 3) & 2u) | ((lo >> 5) & 4u));
     const int x = (int)(((lo >> 2) & 1u) | ((lo >> 4) & 2u) | ((lo >> 6) & 4u));
     const int ci = (x + 1) + 10 * (y + 1) + 100 * (z + 1);
-    for (int o = 0; o < 26; ++o) {
-      const int u = nbr[(int64_t)o * V + v];
-      if (u < 0) continue;
-      int dx, dy, dz;
-      vccs_offset(o, &dx, &dy, &dz);
-      if ((unsigned)(x + dx) < 8u && (unsigned)(y + dy) < 8u && (unsigned)(z + dz) < 8u) continue;   // one of the tile's own
-      const int cu = ci + dx + 10 * dy + 100 * dz;
-      const uint32_t bit = 1u << (cu & 31);
-      if (!(atomicOr(&s_seen[w][cu >> 5], bit) & bit)) s_ent[w][atomicAdd(&s_n[w], 1)] = make_uint2((uint32_t)u, (uint32_t)cu);
-    }
+    I[ci] = (int)v;
     cell[v] = (uint16_t)ci;
   }
+  for (int ci = lane; ci < VT_CELLS; ci += 64) {
+    const int cx = ci % 10, cy = (ci / 10) % 10, cz = ci / 100;
+    if ((unsigned)(cx - 1) < 8u && (unsigned)(cy - 1) < 8u && (unsigned)(cz - 1) < 8u) continue;   // one of the tile's own cells
+    const uint32_t gx = ox + (uint32_t)(cx - 1), gy = oy + (uint32_t)(cy - 1), gz = oz + (uint32_t)(cz - 1);   // (below zero wraps above lim)
+    if (!(gx < lim && gy < lim && gz < lim)) continue;
+    bool unused_flag;
+    const int u = brick_find(bricks, hbits, gx, gy, gz, &unused_flag);
+    if (u < 0) continue;
+    I[ci] = u;
+    s_ent[atomicAdd(&s_n, 1)] = make_uint2((uint32_t)u, (uint32_t)ci);
+  }
   vt_sync();
-  const int n = s_n[w];
+  const int n = s_n;
   unsigned long long off = 0ull;
   if (lane == 0) off = atomicAdd(pool_count, (unsigned long long)n);
   off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0, 64) << 32) | (unsigned long long)(uint32_t)__shfl((int)off, 0, 64);
-  if (off + (unsigned long long)n > pool_cap) { if (lane == 0) meta[t] = make_uint2(0u, 0xffffffffu); return; }   // cannot happen (<= 7 V entries); checked by the host
-  for (int i = lane; i < n; i += 64) halo[off + (unsigned long long)i] = s_ent[w][i];
-  if (lane == 0) meta[t] = make_uint2((uint32_t)off, (uint32_t)n);
+  const bool fits = off + (unsigned long long)n <= pool_cap;   // always (a voxel lies in the shell of at most seven tiles)
+  if (fits) for (int i = lane; i < n; i += 64) halo[off + (unsigned long long)i] = s_ent[i];
+  if (lane == 0) meta[t] = fits ? make_uint2((uint32_t)off, (uint32_t)n) : make_uint2(0u, 0u);
+  // the voxel normals from the neighbourhood's centroids, neighbours in the order of vccs_offset as k_vccs_neighbours takes them
+  for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) {
+    const uint32_t lo = (uint32_t)vox_code[v] & 511u;
+    const int z = (int)((lo & 1u) | ((lo >> 2) & 2u) | ((lo >> 4) & 4u));
+    const int y = (int)(((lo >> 1) & 1u) | ((lo >> 3) & 2u) | ((lo >> 5) & 4u));
+    const int x = (int)(((lo >> 2) & 1u) | ((lo >> 4) & 2u) | ((lo >> 6) & 4u));
+    const int ci = (x + 1) + 10 * (y + 1) + 100 * (z + 1);
+    float pts[27 * 3];
+    pts[0] = cen[3 * (int64_t)v]; pts[1] = cen[3 * (int64_t)v + 1]; pts[2] = cen[3 * (int64_t)v + 2];
+    int np = 1;
+#pragma unroll
+    for (int o = 0; o < 26; ++o) {
+      const int k = o < 13 ? o : o + 1;   // vccs_offset(o)
+      const int u = I[ci + (k % 3 - 1) + 10 * ((k / 3) % 3 - 1) + 100 * (k / 9 - 1)];
+      if (u >= 0) { pts[3 * np] = cen[3 * (int64_t)u]; pts[3 * np + 1] = cen[3 * (int64_t)u + 1]; pts[3 * np + 2] = cen[3 * (int64_t)u + 2]; ++np; }
+    }
+    float nn[3];
+    vccs_normal_from_points(pts, np, nn);
+    nrm[3 * (int64_t)v] = nn[0]; nrm[3 * (int64_t)v + 1] = nn[1]; nrm[3 * (int64_t)v + 2] = nn[2];
+  }
 }
 #define VT_SLOTS 16
 __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta,
@@ -886,12 +912,14 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   static_assert(sizeof(VccsState) == 24, "VccsState");
   DevBuf<float>& cen = c->vc_cen; DevBuf<float>& nrm = c->vc_nrm; DevBuf<float>& dist = c->vc_dist;
   VGS_HIP_TRY(c, cen.ensure(3 * V)); VGS_HIP_TRY(c, nrm.ensure(3 * V)); VGS_HIP_TRY(c, dist.ensure(2 * V));
-  VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
+  VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
-  if (c->K.no_vccs_tiles) VGS_HIP_TRY(c, c->vc_nbr4.ensure(28 * (size_t)V));
-  hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, nrm.p, c->K.no_vccs_tiles ? (int4*)c->vc_nbr4.p : (int4*)nullptr);
+  if (c->K.no_vccs_tiles) {
+    VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_nbr4.ensure(28 * (size_t)V));
+    hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                       c->vc_nbr.p, nrm.p, (int4*)c->vc_nbr4.p);
+  }
   // ---- seeds: one per occupied seed_res cell, snapped to the voxel nearest to the cell centre ----
   const float seed = c->P.seed_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
@@ -927,14 +955,13 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
   const int K = (int)K32;
   const unsigned nbK = (unsigned)((K + TB - 1) / TB);
   const int NT = (int)T32;
-  const unsigned nbT = (unsigned)((NT + 3) / 4);   // the builder: four tiles per workgroup
   if (tiles) {
     const unsigned long long pool_cap = 7ull * (unsigned long long)V;   // a voxel lies in the shell of at most seven tiles
     VGS_HIP_TRY(c, c->vc_cell.ensure(V)); VGS_HIP_TRY(c, c->vc_halo.ensure(pool_cap));
     VGS_HIP_TRY(c, c->vc_tile_meta.ensure(NT)); VGS_HIP_TRY(c, c->vc_pool.ensure(1));
     VGS_HIP_TRY(c, hipMemsetAsync(c->vc_pool.p, 0, 8, c->stream));
-    hipLaunchKernelGGL(k_vccs_tile_build, dim3(nbT), dim3(256), 0, c->stream, c->vox_code.p, V, c->vc_nbr.p, c->vc_tile_start.p, NT, c->vc_cell.p,
-                       (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p, (uint2*)c->vc_tile_meta.p);
+    hipLaunchKernelGGL(k_vccs_tile_setup, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                       c->vc_tile_start.p, c->vc_cell.p, nrm.p, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p, (uint2*)c->vc_tile_meta.p);
   }
   VGS_HIP_TRY(c, c->vc_seedkey.ensure(K)); VGS_HIP_TRY(c, c->vc_sums.ensure(6 * (size_t)K)); VGS_HIP_TRY(c, c->vc_count.ensure(K));
   VGS_HIP_TRY(c, c->vc_state.ensure(6 * (size_t)K));
