@@ -375,29 +375,41 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
   // one wavefront = one workgroup = one tile: no workgroup barrier, a tile of 500 voxels holds nobody else up, 5 KB of LDS
   __shared__ __attribute__((aligned(16))) int L[VT_CELLS];
   __shared__ int s_key[VT_SLOTS];
-  __shared__ unsigned long long s_sum[VT_SLOTS][6];
+  __shared__ int s_sum[VT_SLOTS][6];
   __shared__ int s_cnt[VT_SLOTS];
   const int lane = threadIdx.x;
   const int t = (int)blockIdx.x;
   if (lane < VT_SLOTS) {
     s_key[lane] = -1; s_cnt[lane] = 0;
-    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0ull;
+    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0;
   }
   for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);   // an empty cell reads as "no neighbour"
   const uint32_t ts = tile_start[t], te = tile_start[t + 1];
   const uint2 m = meta[t];
+  long long base[3];
+  for (int a = 0; a < 3; ++a) base[a] = vccs_fix_pos(cen[3 * (int64_t)ts + a]);   // (wave-uniform)
   // what the first 64 voxels need is requested before the shell is staged
   struct Vox { int ci; float d; float c[3]; float n[3]; };
   auto load_vox = [&](uint32_t v, Vox& x) {
     x.ci = (int)cell[v]; x.d = dist_in[v];
     for (int a = 0; a < 3; ++a) { x.c[a] = cen[3 * (int64_t)v + a]; x.n[a] = nrm[3 * (int64_t)v + a]; }
   };
+  // (requesting the second 64 voxels' inputs up front as well costs 18 registers -- four instead of five wavefronts per SIMD -- and
+  // was measured slower: 12.14 against 11.98 ms for config 4)
   Vox x0;
   int lab0 = -1;
   const uint32_t v0 = ts + (uint32_t)lane;
   if (v0 < te) { load_vox(v0, x0); lab0 = label_in[v0]; }
+  uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);
+  if ((uint32_t)lane < m.y) e0 = halo[m.x + (uint32_t)lane];
+  if ((uint32_t)lane + 64u < m.y) e1 = halo[m.x + (uint32_t)lane + 64u];
+  int h0 = -1, h1 = -1;
+  if ((uint32_t)lane < m.y) h0 = label_in[e0.x];
+  if ((uint32_t)lane + 64u < m.y) h1 = label_in[e1.x];
   vt_sync();
-  for (uint32_t i = (uint32_t)lane; i < m.y; i += 64u) { const uint2 e = halo[m.x + i]; L[e.y] = label_in[e.x]; }
+  if ((uint32_t)lane < m.y) L[e0.y] = h0;
+  if ((uint32_t)lane + 64u < m.y) L[e1.y] = h1;
+  for (uint32_t i = (uint32_t)lane + 128u; i < m.y; i += 64u) { const uint2 e = halo[m.x + i]; L[e.y] = label_in[e.x]; }
   if (v0 < te) L[x0.ci] = lab0;
   for (uint32_t v = v0 + 64u; v < te; v += 64u) L[cell[v]] = label_in[v];
   vt_sync();
@@ -421,23 +433,36 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
     if (best_l != own) {
       touched = true;
       long long f[6];
-      for (int a = 0; a < 3; ++a) { f[a] = vccs_fix_pos(x.c[a]); f[3 + a] = vccs_fix_nrm(x.n[a]); }
+      // (vccs_fix_pos / vccs_fix_nrm in single precision: the scaling by a power of two is exact in either format, so the rounding
+      // to an integer sees the same real number and the results are equal; the double-precision forms cost eight f64 operations each)
+      for (int a = 0; a < 3; ++a) { f[a] = (long long)__builtin_rintf(x.c[a] * 65536.0f); f[3 + a] = (long long)__builtin_rintf(x.n[a] * 1048576.0f); }
+      // inside a tile the fixed-point positions differ by a few voxels: 32-bit sums relative to the tile's first voxel (a position
+      // farther than 2^21 units away -- voxels of several metres -- goes straight to memory); normals are below 2^20 as they are
+      int r[6];
+      bool small = true;
+      for (int a = 0; a < 3; ++a) {
+        const long long d = f[a] - base[a];
+        small = small && d > -(1ll << 21) && d < (1ll << 21);
+        r[a] = (int)d; r[3 + a] = (int)f[3 + a];
+      }
       for (int side = 0; side < 2; ++side) {
         const int l = side ? best_l : own;
         if (l < 0) continue;
-        const long long sgn = side ? 1 : -1;
+        const int sgn = side ? 1 : -1;
         int slot = -1;
-        unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
-        for (int probe = 0; probe < VT_SLOTS; ++probe) {
-          const int prev = atomicCAS(&s_key[h], -1, l);
-          if (prev == -1 || prev == l) { slot = (int)h; break; }
-          h = (h + 1) & (VT_SLOTS - 1);
+        if (small) {
+          unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
+          for (int probe = 0; probe < VT_SLOTS; ++probe) {
+            const int prev = atomicCAS(&s_key[h], -1, l);
+            if (prev == -1 || prev == l) { slot = (int)h; break; }
+            h = (h + 1) & (VT_SLOTS - 1);
+          }
         }
         if (slot >= 0) {
-          for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], (unsigned long long)(sgn * f[a]));
-          atomicAdd(&s_cnt[slot], (int)sgn);
+          for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], sgn * r[a]);
+          atomicAdd(&s_cnt[slot], sgn);
         } else {
-          for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)(sgn * f[a]));
+          for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)((long long)sgn * f[a]));
           if (side) atomicAdd(&count[l], 1u); else atomicSub(&count[l], 1u);
         }
       }
@@ -448,8 +473,11 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
   if (lane < VT_SLOTS) {
     const int l = s_key[lane];
     if (l >= 0) {
-      for (int a = 0; a < 6; ++a) { const unsigned long long x = s_sum[lane][a]; if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], x); }
       const int dc = s_cnt[lane];
+      for (int a = 0; a < 6; ++a) {
+        const long long x = (long long)s_sum[lane][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
+        if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)x);
+      }
       if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
     }
   }
