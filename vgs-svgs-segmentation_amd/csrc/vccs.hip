@@ -345,6 +345,8 @@ __global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restri
   if (fits) for (int i = lane; i < n; i += 64) halo[off + (unsigned long long)i] = s_ent[i];
   if (lane == 0) meta[t] = fits ? make_uint2((uint32_t)off, (uint32_t)n) : make_uint2(0u, 0u);
   // the voxel normals from the neighbourhood's centroids, neighbours in the order of vccs_offset as k_vccs_neighbours takes them
+  // (vccs_mode 1 has its own two-ring normals: nrm is null)
+  if (nrm == nullptr) return;
   for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) {
     const uint32_t lo = (uint32_t)vox_code[v] & 511u;
     const int z = (int)((lo & 1u) | ((lo >> 2) & 2u) | ((lo >> 4) & 4u));
@@ -801,6 +803,97 @@ __global__ void k_pcl_max_label(int K, const uint8_t* __restrict__ alive, unsign
   if (k < K && alive[k]) atomicMax(out, (unsigned int)(k + 1));
 }
 
+// ---- vccs_mode 1 over tiles (round 4).  The live sweeps and the final claim read, for each of a voxel's 27 cells, the owner and the
+// live flag: both travel in one word, P = owner << 1 | live (-1: no owner), staged per tile in the 10^3 LDS array of
+// k_vccs_expand_tiles.  The fold -- distinct owners below the limit that reach the voxel through a live leaf, in ascending label
+// order, an offer strictly below the recorded distance taking the voxel -- enumerates them as successive minima (vx_min27: the
+// keys ARE the labels, so the order is the sequential one) instead of an insertion sort over 27 gathered values.
+__device__ __forceinline__ uint32_t vx_min27(const uint32_t (&k)[27], uint32_t c) {
+  uint32_t m = 0xffffffffu - c;
+#pragma unroll
+  for (int o = 0; o < 27; o += 3) m = min(m, min(min(k[o] - c, k[o + 1] - c), k[o + 2] - c));
+  return m;
+}
+__global__ void k_pclt_init(int64_t V, const int32_t* __restrict__ owner, int32_t* __restrict__ P) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) { const int s = owner[v]; P[v] = s < 0 ? -1 : ((s << 1) | 1); }
+}
+template <bool CLAIM>
+__global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta, const uint2* __restrict__ halo,
+                                                   const uint16_t* __restrict__ cell, const int32_t* __restrict__ P_in, const float* __restrict__ dist0,
+                                                   const float* __restrict__ cen, const float* __restrict__ nrm, const VccsState* __restrict__ st,
+                                                   float w_s_over_seed, float w_n, int32_t* __restrict__ P_out, unsigned int* __restrict__ changed,
+                                                   int32_t* __restrict__ owner1, float* __restrict__ dist1) {
+  __shared__ __attribute__((aligned(16))) int L[VT_CELLS];
+  const int lane = threadIdx.x;
+  const int t = (int)blockIdx.x;
+  for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);
+  const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+  const uint2 m = meta[t];
+  const uint32_t v0 = ts + (uint32_t)lane;
+  int ci0 = 0, p0 = -1;
+  if (v0 < te) { ci0 = (int)cell[v0]; p0 = P_in[v0]; }
+  uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);
+  if ((uint32_t)lane < m.y) e0 = halo[m.x + (uint32_t)lane];
+  if ((uint32_t)lane + 64u < m.y) e1 = halo[m.x + (uint32_t)lane + 64u];
+  int h0 = -1, h1 = -1;
+  if ((uint32_t)lane < m.y) h0 = P_in[e0.x];
+  if ((uint32_t)lane + 64u < m.y) h1 = P_in[e1.x];
+  vt_sync();
+  if ((uint32_t)lane < m.y) L[e0.y] = h0;
+  if ((uint32_t)lane + 64u < m.y) L[e1.y] = h1;
+  for (uint32_t i = (uint32_t)lane + 128u; i < m.y; i += 64u) { const uint2 e = halo[m.x + i]; L[e.y] = P_in[e.x]; }
+  if (v0 < te) L[ci0] = p0;
+  for (uint32_t v = v0 + 64u; v < te; v += 64u) L[cell[v]] = P_in[v];
+  vt_sync();
+  bool any_change = false;
+  for (uint32_t v = v0; v < te; v += 64u) {
+    const int ci = v == v0 ? ci0 : (int)cell[v];
+    const int p = L[ci];
+    const int own = p < 0 ? -1 : (p >> 1);
+    if (!CLAIM && own < 0) { P_out[v] = -1; continue; }   // no leaf, no live flag
+    const uint32_t limit = CLAIM ? 0x7fffffffu : (uint32_t)own;
+    uint32_t key[27];
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+      const int q = L[ci + (o % 3 - 1) + 10 * ((o / 3) % 3 - 1) + 100 * (o / 9 - 1)];
+      const uint32_t s = (uint32_t)(q >> 1);
+      key[o] = (q >= 0 && (q & 1) && s < limit) ? s : 0xffffffffu;
+    }
+    int cur = own;
+    float cd = 0.f;
+    bool have = false;
+    float c[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f};
+    uint32_t off = 0u;
+    bool more = true;
+    while (true) {
+      const uint32_t kq = vx_min27(key, off) + off;
+      more = more && kq < 0x80000000u;
+      if (__ballot(more) == 0ull) break;
+      off = kq + 1u;
+      if (more && (int)kq != cur) {
+        if (!have) {
+          have = true;
+          cd = dist0[v];
+          for (int a = 0; a < 3; ++a) { c[a] = cen[3 * (int64_t)v + a]; n[a] = nrm[3 * (int64_t)v + a]; }
+        }
+        const int s = (int)kq;
+        const float d = vccs_distance(c, n, st[s].c, st[s].n, w_s_over_seed, w_n);
+        if (d < cd) { cd = d; cur = s; }
+      }
+    }
+    if (CLAIM) {
+      owner1[v] = cur;
+      dist1[v] = have ? cd : dist0[v];
+    } else {
+      const int pn = (own << 1) | (cur == own ? 1 : 0);
+      P_out[v] = pn;
+      any_change = any_change || pn != p;
+    }
+  }
+  if (!CLAIM && __ballot(any_change) != 0ull && lane == 0) atomicOr(changed, 1u);
+}
+
 static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   const int64_t V = c->V, N = c->N;
   const int TB = 256;
@@ -816,6 +909,29 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   // the 26-neighbour table (its 1-ring normals are overwritten by the 2-ring ones)
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
                      c->vc_nbr.p, nrm.p, (int4*)nullptr);
+  // tiles for the live sweeps and the claim (k_pclt_sweep)
+  const bool tiles = !c->K.no_vccs_tiles;
+  int NT = 0;
+  if (tiles) {
+    VGS_HIP_TRY(c, c->head_flag.ensure(V + 1)); VGS_HIP_TRY(c, c->perm_a.ensure(V + 1));
+    size_t scan_bytes_t = 0;
+    VGS_HIP_TRY(c, rocprim::inclusive_scan(nullptr, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+    VGS_HIP_TRY(c, c->sort_tmp.ensure(scan_bytes_t));
+    VGS_HIP_TRY(c, c->vc_tile_start.ensure(V + 1));
+    hipLaunchKernelGGL(k_vccs_tile_heads, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->head_flag.p);
+    VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p);
+    uint32_t T32 = 0;
+    VGS_READBACK(c, &T32, c->perm_a.p + (V - 1), 4);
+    NT = (int)T32;
+    const unsigned long long pool_cap = 7ull * (unsigned long long)V;
+    VGS_HIP_TRY(c, c->vc_cell.ensure(V)); VGS_HIP_TRY(c, c->vc_halo.ensure(pool_cap));
+    VGS_HIP_TRY(c, c->vc_tile_meta.ensure(NT)); VGS_HIP_TRY(c, c->vc_pool.ensure(1)); VGS_HIP_TRY(c, c->vc_plive.ensure(2 * (size_t)V));
+    VGS_HIP_TRY(c, hipMemsetAsync(c->vc_pool.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_vccs_tile_setup, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                       c->vc_tile_start.p, c->vc_cell.p, (float*)nullptr, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p,
+                       (uint2*)c->vc_tile_meta.p);
+  }
   hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p);
   hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p);
   // ---- seeds ----
@@ -874,6 +990,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   int32_t* own[2] = {c->vc_label.p, c->vc_label.p + V};
   float* dst[2] = {dist.p, dist.p + V};
   uint8_t* live[2] = {c->vc_live.p, c->vc_live.p + V};
+  int32_t* plive[2] = {tiles ? c->vc_plive.p : nullptr, tiles ? c->vc_plive.p + V : nullptr};
   unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);
   int cur = 0;
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
@@ -887,7 +1004,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
     }
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
-      hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
+      if (tiles) hipLaunchKernelGGL(k_pclt_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], plive[lc]);
+      else hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
       // fixed point of the live flags: the recursion is on smaller labels, so it ends -- a sweep that changes nothing is the proof.
       // Sweeps go out in pairs with one read-back per pair (a sweep at the fixed point changes nothing, so a spare one is harmless):
       // half the host round trips.  Leaving the loop without that proof would give labels that differ from the sequential
@@ -897,16 +1015,26 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
         unsigned int ch[2] = {1u, 1u};
         for (int k = 0; k < 2; ++k) {
           VGS_HIP_TRY(c, hipMemsetAsync(d_changed + k, 0, 4, c->stream));
-          hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
-                             live[lc ^ 1], d_changed + k);
+          if (tiles)
+            hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
+                               (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
+                               d_changed + k, (int32_t*)nullptr, (float*)nullptr);
+          else
+            hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
+                               live[lc ^ 1], d_changed + k);
           lc ^= 1;
         }
         VGS_READBACK(c, ch, d_changed, 8);
         settled = !ch[0] || !ch[1];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
       }
       if (!settled) { c->err = "svgs_supervoxels (vccs_mode 1): the live flags did not reach their fixed point in 4096 sweeps"; return VGS_E_STATE; }
-      hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
-                         own[cur ^ 1], dst[cur ^ 1]);
+      if (tiles)
+        hipLaunchKernelGGL(k_pclt_sweep<true>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
+                           (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
+                           (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1]);
+      else
+        hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
+                           own[cur ^ 1], dst[cur ^ 1]);
       cur ^= 1;
       VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * sizeof(long long), c->stream));
       VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
