@@ -150,18 +150,12 @@ __global__ void k_vccs_plant(const unsigned long long* __restrict__ seed_key, in
 // is the minimum of key - (previous + 1) in unsigned arithmetic, where everything already taken wraps to the top: one subtraction
 // and a third of a min3 per neighbour and level, all full rate, and a level is only run while some lane of the wavefront still
 // has a label to find.  Minimum by (distance, label): the order of evaluation does not matter.
-__device__ __forceinline__ uint32_t vx_min26(const uint32_t (&k)[26], uint32_t c) {
-  uint32_t m = 0xffffffffu - c;   // the voxel's own key as a 27th value: when every neighbour's label has been taken, the minimum must not wrap round to one of them
-#pragma unroll
-  for (int o = 0; o < 26; o += 2) m = min(m, min(k[o] - c, k[o + 1] - c));
-  return m;
-}
 __device__ __forceinline__ void vccs_best_offer(const int (&nl)[26], int own, const float (&c)[3], const float (&n)[3], const VccsState* __restrict__ st,
                                                 float w_s_over_seed, float w_n, int& best_l, float& best_d) {
-  const uint32_t ref = own >= 0 ? (uint32_t)own : 0x7ffffffeu;   // (an unowned voxel: -1 ^ ref must stay above 2^31 after the decrement)
+  const uint32_t ref = vccs_enum_ref(own);
   uint32_t key[26];
 #pragma unroll
-  for (int o = 0; o < 26; ++o) key[o] = ((uint32_t)nl[o] ^ ref) - 1u;
+  for (int o = 0; o < 26; ++o) key[o] = vccs_enum_key(nl[o], ref);
   int sl[4] = {-1, -1, -1, -1};
   bool more = true;
   uint32_t off = 0u;
@@ -169,11 +163,11 @@ __device__ __forceinline__ void vccs_best_offer(const int (&nl)[26], int own, co
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (q > 0 && !live[q - 1]) break;
-    const uint32_t kq = vx_min26(key, off) + off;
-    more = more && kq < 0x80000000u;
+    const uint32_t kq = vccs_enum_next(key, 26, off);
+    more = more && vccs_enum_valid(kq);
     live[q] = __ballot(more) != 0ull;
     if (!live[q]) break;
-    sl[q] = more ? (int)((kq + 1u) ^ ref) : -1;
+    sl[q] = more ? vccs_enum_label(kq, ref) : -1;
     off = kq + 1u;
   }
   VccsState A[4];
@@ -189,11 +183,11 @@ __device__ __forceinline__ void vccs_best_offer(const int (&nl)[26], int own, co
   }
   // a fifth label and beyond (corners where many supervoxels meet): one at a time
   while (live[3] && __ballot(more) != 0ull) {
-    const uint32_t kq = vx_min26(key, off) + off;
-    more = more && kq < 0x80000000u;
+    const uint32_t kq = vccs_enum_next(key, 26, off);
+    more = more && vccs_enum_valid(kq);
     if (__ballot(more) == 0ull) break;
     off = kq + 1u;
-    const int l = (int)((kq + 1u) ^ ref);
+    const int l = vccs_enum_label(kq, ref);
     if (more && l >= 0) {
       const float d = vccs_distance(c, n, st[l].c, st[l].n, w_s_over_seed, w_n);
       if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
@@ -806,14 +800,8 @@ __global__ void k_pcl_max_label(int K, const uint8_t* __restrict__ alive, unsign
 // ---- vccs_mode 1 over tiles (round 4).  The live sweeps and the final claim read, for each of a voxel's 27 cells, the owner and the
 // live flag: both travel in one word, P = owner << 1 | live (-1: no owner), staged per tile in the 10^3 LDS array of
 // k_vccs_expand_tiles.  The fold -- distinct owners below the limit that reach the voxel through a live leaf, in ascending label
-// order, an offer strictly below the recorded distance taking the voxel -- enumerates them as successive minima (vx_min27: the
+// order, an offer strictly below the recorded distance taking the voxel -- enumerates them as successive minima (vccs_enum_next: the
 // keys ARE the labels, so the order is the sequential one) instead of an insertion sort over 27 gathered values.
-__device__ __forceinline__ uint32_t vx_min27(const uint32_t (&k)[27], uint32_t c) {
-  uint32_t m = 0xffffffffu - c;
-#pragma unroll
-  for (int o = 0; o < 27; o += 3) m = min(m, min(min(k[o] - c, k[o + 1] - c), k[o + 2] - c));
-  return m;
-}
 __global__ void k_pclt_init(int64_t V, const int32_t* __restrict__ owner, int32_t* __restrict__ P) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v < V) { const int s = owner[v]; P[v] = s < 0 ? -1 : ((s << 1) | 1); }
@@ -867,8 +855,8 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
     uint32_t off = 0u;
     bool more = true;
     while (true) {
-      const uint32_t kq = vx_min27(key, off) + off;
-      more = more && kq < 0x80000000u;
+      const uint32_t kq = vccs_enum_next(key, 27, off);
+      more = more && vccs_enum_valid(kq);
       if (__ballot(more) == 0ull) break;
       off = kq + 1u;
       if (more && (int)kq != cur) {

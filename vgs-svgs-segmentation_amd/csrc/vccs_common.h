@@ -63,6 +63,27 @@ VGS_HD float vccs_distance(const float* c, const float* n, const float* sc, cons
   return ds * w_s_over_seed + w_n * dn;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Distinct labels of a neighbourhood as successive minima (vccs.hip: vccs_best_offer, k_pclt_sweep; checked on the host by
+// tests/test_enum_arith.py).  key = (label ^ ref) - 1 with ref = the voxel's own label (an unowned voxel: 2^31 - 2) is
+// 0xffffffff for the own label, >= 2^31 for "no neighbour" (-1) and < 2^31 for every other label (labels stay below 2^31 - 2).
+// The next key above the ones already taken is  off + min over the keys of (key - off)  in unsigned arithmetic with
+// off = previous + 1: a key already taken wraps to the top, and the voxel's own key is always part of the minimum, so that a
+// neighbourhood whose labels have all been taken ends at 0xffffffff instead of wrapping round to one of them.
+VGS_HD uint32_t vccs_enum_ref(int own) { return own >= 0 ? (uint32_t)own : 0x7ffffffeu; }
+VGS_HD uint32_t vccs_enum_key(int label, uint32_t ref) { return ((uint32_t)label ^ ref) - 1u; }
+VGS_HD int vccs_enum_label(uint32_t key, uint32_t ref) { return (int)((key + 1u) ^ ref); }
+VGS_HD bool vccs_enum_valid(uint32_t key) { return key < 0x80000000u; }
+// smallest key >= off (returned as a key, not as a difference); keys: n values
+VGS_HD uint32_t vccs_enum_next(const uint32_t* keys, int n, uint32_t off) {
+  uint32_t m = 0xffffffffu - off;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int o = 0; o < n; ++o) { const uint32_t d = keys[o] - off; m = d < m ? d : m; }
+  return m + off;
+}
+
 // fixed point so that the per-supervoxel sums do not depend on the order of the atomic adds
 VGS_HD long long vccs_fix_pos(float x) { return (long long)__builtin_rint((double)x * 65536.0); }
 VGS_HD long long vccs_fix_nrm(float x) { return (long long)__builtin_rint((double)x * 1048576.0); }
