@@ -1140,20 +1140,11 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2))
       wave_sync();
       for (int k = lane; k < P.cb_words; k += 64) cb[k] = 0u;
       wave_sync();
-      bool from_lds = false;
-      if constexpr (NEAR) from_lds = !cen_ready;   // the lattice offsets of the vertices are still in LDS (the near-pair lists served every shell: 91 % of the bulk)
-      if (from_lds) {
-        const int D = 2 * P.cb_R + 1, sh = P.cb_R - NL_BALL;
-        for (int c = lane; c < m; c += 64)
-          if ((int)seg[c] == s0) {
-            const uint32_t q = nlat[c];   // (dx + NL_BALL) | (dy + NL_BALL) << 4 | (dz + NL_BALL) << 8
-            const uint32_t idx = (uint32_t)((((int)((q >> 8) & 15u) + sh) * D + ((int)((q >> 4) & 15u) + sh)) * D + ((int)(q & 15u) + sh));
-            atomicOr(&cb[idx >> 5], 1u << (idx & 31u));
-          }
-      } else if (orow != nullptr && orow[0] != 0xffffu) {
+      // (Building the row from the LDS copy of the lattice offsets where the near-pair lists served every shell -- no second read of
+      // the row's offsets -- was measured in round 4: it costs the bulk kernel four spilled registers, 2.67 -> 2.70 ms.)
+      if (orow != nullptr && orow[0] != 0xffffu)
         for (int c = lane; c < m; c += 64)
           if ((int)seg[c] == s0) { const uint32_t idx = vgs_cb_index(orow[c], P.cb_R); atomicOr(&cb[idx >> 5], 1u << (idx & 31u)); }
-      }
       wave_sync();
       uint32_t* const out = P.cbits + (size_t)u * (size_t)P.cb_words;
       for (int k = lane; k < P.cb_words; k += 64) out[k] = cb[k];
