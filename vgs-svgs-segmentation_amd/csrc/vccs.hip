@@ -91,11 +91,25 @@ __global__ void k_vccs_pick_seeds(const uint64_t* __restrict__ code, const uint3
                                   int64_t V, const float* __restrict__ cen, float min_x, float min_y, float min_z, float seed,
                                   unsigned long long* __restrict__ seed_key) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= V) return;
-  const uint32_t v = sorted_id[j];
-  const uint32_t cell = scan[j] - 1u;
-  const float d2 = vccs_cell_center_d2(code[j], cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], min_x, min_y, min_z, seed);
-  atomicMin(&seed_key[cell], ((unsigned long long)vm_bits(d2) << 32) | (unsigned long long)v);
+  const int lane = threadIdx.x & 63;
+  // the voxels of a cell are neighbours in the sorted order: the minimum is taken over each run of equal cells among the lanes first
+  // (segmented scan, six shuffle steps) and only the last lane of a run goes to memory -- a cell holds some thirty voxels
+  uint32_t cell = 0xffffffffu;
+  unsigned long long key = ~0ull;
+  if (j < V) {
+    const uint32_t v = sorted_id[j];
+    cell = scan[j] - 1u;
+    const float d2 = vccs_cell_center_d2(code[j], cen[3 * v], cen[3 * v + 1], cen[3 * v + 2], min_x, min_y, min_z, seed);
+    key = ((unsigned long long)vm_bits(d2) << 32) | (unsigned long long)v;
+  }
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t co = (uint32_t)__shfl_up((int)cell, o, 64);
+    const unsigned long long ko = ((unsigned long long)(uint32_t)__shfl_up((int)(key >> 32), o, 64) << 32) | (unsigned long long)(uint32_t)__shfl_up((int)key, o, 64);
+    if (lane >= o && co == cell && ko < key) key = ko;   // runs are contiguous: equal cells o lanes apart span one run
+  }
+  const uint32_t cnext = (uint32_t)__shfl_down((int)cell, 1, 64);
+  if (cell == 0xffffffffu || (lane < 63 && cnext == cell)) return;   // not the last lane of its run
+  atomicMin(&seed_key[cell], key);
 }
 
 __global__ void k_vccs_fill_u64(unsigned long long* p, int64_t n, unsigned long long v) {
@@ -811,13 +825,25 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
                                                    const uint16_t* __restrict__ cell, const int32_t* __restrict__ P_in, const float* __restrict__ dist0,
                                                    const float* __restrict__ cen, const float* __restrict__ nrm, const VccsState* __restrict__ st,
                                                    float w_s_over_seed, float w_n, int32_t* __restrict__ P_out, unsigned int* __restrict__ changed,
-                                                   int32_t* __restrict__ owner1, float* __restrict__ dist1) {
+                                                   int32_t* __restrict__ owner1, float* __restrict__ dist1, long long* __restrict__ sums,
+                                                   unsigned int* __restrict__ count) {
   __shared__ __attribute__((aligned(16))) int L[VT_CELLS];
+  // CLAIM: the per-supervoxel sums move with the voxels that change owner, per tile in an LDS table keyed by label (k_vccs_expand_tiles)
+  __shared__ int s_key[CLAIM ? VT_SLOTS : 1];
+  __shared__ int s_sum[CLAIM ? VT_SLOTS : 1][6];
+  __shared__ int s_cnt[CLAIM ? VT_SLOTS : 1];
   const int lane = threadIdx.x;
   const int t = (int)blockIdx.x;
   for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);
+  if (CLAIM && lane < VT_SLOTS) {
+    s_key[lane] = -1; s_cnt[lane] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0;
+  }
   const uint32_t ts = tile_start[t], te = tile_start[t + 1];
   const uint2 m = meta[t];
+  long long base[3] = {0, 0, 0};
+  if (CLAIM) for (int a = 0; a < 3; ++a) base[a] = vccs_fix_pos(cen[3 * (int64_t)ts + a]);   // (wave-uniform)
+  bool touched = false;
   const uint32_t v0 = ts + (uint32_t)lane;
   int ci0 = 0, p0 = -1;
   if (v0 < te) { ci0 = (int)cell[v0]; p0 = P_in[v0]; }
@@ -873,6 +899,39 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
     if (CLAIM) {
       owner1[v] = cur;
       dist1[v] = have ? cd : dist0[v];
+      if (cur != own) {   // (an offer was evaluated: c and n are loaded)
+        touched = true;
+        long long f[6];
+        for (int a = 0; a < 3; ++a) { f[a] = vccs_fix_pos(c[a]); f[3 + a] = vccs_fix_nrm(n[a]); }
+        int r[6];
+        bool small = true;
+        for (int a = 0; a < 3; ++a) {
+          const long long d = f[a] - base[a];
+          small = small && d > -(1ll << 21) && d < (1ll << 21);
+          r[a] = (int)d; r[3 + a] = (int)f[3 + a];
+        }
+        for (int side = 0; side < 2; ++side) {
+          const int l = side ? cur : own;
+          if (l < 0) continue;
+          const int sgn = side ? 1 : -1;
+          int slot = -1;
+          if (small) {
+            unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
+            for (int probe = 0; probe < VT_SLOTS; ++probe) {
+              const int prev = atomicCAS(&s_key[h], -1, l);
+              if (prev == -1 || prev == l) { slot = (int)h; break; }
+              h = (h + 1) & (VT_SLOTS - 1);
+            }
+          }
+          if (slot >= 0) {
+            for (int a = 0; a < 6; ++a) atomicAdd(&s_sum[slot][a], sgn * r[a]);
+            atomicAdd(&s_cnt[slot], sgn);
+          } else {
+            for (int a = 0; a < 6; ++a) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)((long long)sgn * f[a]));
+            if (side) atomicAdd(&count[l], 1u); else atomicSub(&count[l], 1u);
+          }
+        }
+      }
     } else {
       const int pn = (own << 1) | (cur == own ? 1 : 0);
       P_out[v] = pn;
@@ -880,6 +939,34 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
     }
   }
   if (!CLAIM && __ballot(any_change) != 0ull && lane == 0) atomicOr(changed, 1u);
+  if (CLAIM && __ballot(touched) != 0ull) {
+    vt_sync();
+    if (lane < VT_SLOTS) {
+      const int l = s_key[lane];
+      if (l >= 0) {
+        const int dc = s_cnt[lane];
+        for (int a = 0; a < 6; ++a) {
+          const long long x = (long long)s_sum[lane][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
+          if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)x);
+        }
+        if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
+      }
+    }
+  }
+}
+// the sums at the start of a pass: every living supervoxel owns exactly its seed voxel
+__global__ void k_pclt_seed_sums(int K, const int32_t* __restrict__ seed_of, const unsigned long long* __restrict__ seed_key, const uint8_t* __restrict__ alive,
+                                 const float* __restrict__ cen, const float* __restrict__ nrm, long long* __restrict__ sums, unsigned int* __restrict__ count) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  for (int a = 0; a < 6; ++a) sums[6 * k + a] = 0;
+  count[k] = 0;
+  int64_t v = -1;
+  if (seed_of) v = (int64_t)seed_of[k];                                                     // the first pass: the seeds themselves
+  else if (alive[k] && seed_key[k] != ~0ull) v = (int64_t)(uint32_t)seed_key[k];            // re-seeding (k_pcl_plant_again)
+  if (v < 0) return;
+  for (int a = 0; a < 3; ++a) { sums[6 * k + a] = vccs_fix_pos(cen[3 * v + a]); sums[6 * k + 3 + a] = vccs_fix_nrm(nrm[3 * v + a]); }
+  count[k] = 1;
 }
 
 static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
@@ -983,12 +1070,16 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   int cur = 0;
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
   hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
+  if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)seeds, (const unsigned long long*)nullptr, (const uint8_t*)nullptr,
+                                cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
   for (int pass = 0; pass < 6; ++pass) {
     if (pass > 0) {
       hipLaunchKernelGGL(k_vccs_fill_u64, dim3(nbK), dim3(TB), 0, c->stream, seed_key, (int64_t)K, ~0ull);
       hipLaunchKernelGGL(k_vccs_reseed, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, state, seed_key);
       hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
       hipLaunchKernelGGL(k_pcl_plant_again, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, c->vc_alive.p, own[cur]);
+      if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)nullptr, (const unsigned long long*)seed_key,
+                                    (const uint8_t*)c->vc_alive.p, cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
     }
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
@@ -1006,7 +1097,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
           if (tiles)
             hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                                (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
-                               d_changed + k, (int32_t*)nullptr, (float*)nullptr);
+                               d_changed + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr);
           else
             hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                                live[lc ^ 1], d_changed + k);
@@ -1019,14 +1110,16 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       if (tiles)
         hipLaunchKernelGGL(k_pclt_sweep<true>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                            (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
-                           (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1]);
+                           (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
       else
         hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                            own[cur ^ 1], dst[cur ^ 1]);
       cur ^= 1;
-      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * sizeof(long long), c->stream));
-      VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
-      hipLaunchKernelGGL(k_pcl_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+      if (!tiles) {   // (over tiles the claim moved the sums with the voxels that changed owner: integers, the same totals)
+        VGS_HIP_TRY(c, hipMemsetAsync(c->vc_sums.p, 0, 6 * (size_t)K * sizeof(long long), c->stream));
+        VGS_HIP_TRY(c, hipMemsetAsync(c->vc_count.p, 0, (size_t)K * 4, c->stream));
+        hipLaunchKernelGGL(k_pcl_accumulate, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+      }
       hipLaunchKernelGGL(k_pcl_update, dim3(nbK), dim3(TB), 0, c->stream, K, c->vc_sums.p, c->vc_count.p, state, c->vc_alive.p);
     }
   }
