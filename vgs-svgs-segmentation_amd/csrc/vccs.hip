@@ -299,9 +299,11 @@ __global__ void k_vccs_tile_heads(const uint64_t* __restrict__ code, int64_t V, 
   if (v >= V) return;
   head[v] = (v == 0 || (code[v - 1] >> 9) != (code[v] >> 9)) ? 1u : 0u;
 }
-__global__ void k_vccs_tile_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ scan, int64_t V, uint32_t* __restrict__ tile_start) {
+__global__ void k_vccs_tile_starts(const uint32_t* __restrict__ head, const uint32_t* __restrict__ scan, int64_t V, uint32_t* __restrict__ tile_start,
+                                   uint32_t* __restrict__ tile_of) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
+  if (tile_of) tile_of[v] = scan[v] - 1u;
   if (head[v]) tile_start[scan[v] - 1u] = (uint32_t)v;
   if (v == V - 1) tile_start[scan[v]] = (uint32_t)V;
 }
@@ -311,10 +313,13 @@ __global__ void k_vccs_tile_starts(const uint32_t* __restrict__ head, const uint
 __global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restrict__ vox_code, int depth, const Brick* __restrict__ bricks, uint32_t hbits,
                                                         const float* __restrict__ cen, const uint32_t* __restrict__ tile_start, uint16_t* __restrict__ cell,
                                                         float* __restrict__ nrm, uint2* __restrict__ halo, unsigned long long pool_cap,
-                                                        unsigned long long* __restrict__ pool_count, uint2* __restrict__ meta) {
+                                                        unsigned long long* __restrict__ pool_count, uint2* __restrict__ meta,
+                                                        const uint32_t* __restrict__ tile_of, int32_t* __restrict__ nbr_tiles) {
   __shared__ __attribute__((aligned(16))) int I[VT_CELLS];
   __shared__ uint2 s_ent[VT_SHELL];
   __shared__ int s_n;
+  __shared__ int s_nt[27];   // (vccs_mode 1) the tile on each of the 26 sides that holds a voxel of the shell, -1: none
+  if (threadIdx.x < 27) s_nt[threadIdx.x] = -1;
   const int lane = threadIdx.x;
   const int t = (int)blockIdx.x;
   for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)I)[i] = make_int4(-1, -1, -1, -1);
@@ -343,8 +348,10 @@ __global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restri
     if (u < 0) continue;
     I[ci] = u;
     s_ent[atomicAdd(&s_n, 1)] = make_uint2((uint32_t)u, (uint32_t)ci);
+    if (nbr_tiles) s_nt[(cx == 0 ? 0 : (cx == 9 ? 2 : 1)) + 3 * (cy == 0 ? 0 : (cy == 9 ? 2 : 1)) + 9 * (cz == 0 ? 0 : (cz == 9 ? 2 : 1))] = (int)tile_of[u];   // (every voxel on that side says the same)
   }
   vt_sync();
+  if (nbr_tiles && lane < 27) nbr_tiles[(int64_t)t * 27 + lane] = s_nt[lane];
   const int n = s_n;
   unsigned long long off = 0ull;
   if (lane == 0) off = atomicAdd(pool_count, (unsigned long long)n);
@@ -826,7 +833,22 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
                                                    const float* __restrict__ cen, const float* __restrict__ nrm, const VccsState* __restrict__ st,
                                                    float w_s_over_seed, float w_n, int32_t* __restrict__ P_out, unsigned int* __restrict__ changed,
                                                    int32_t* __restrict__ owner1, float* __restrict__ dist1, long long* __restrict__ sums,
-                                                   unsigned int* __restrict__ count) {
+                                                   unsigned int* __restrict__ count, const int32_t* __restrict__ nbr_tiles,
+                                                   const uint32_t* __restrict__ tchg_in, uint32_t* __restrict__ tchg_out) {
+  // A sweep's output for a tile is a function of the flags in its window -- its own voxels and the shell, which lie in the tile and in
+  // the tiles on its 26 sides.  If none of these changed a flag in the previous sweep, the window is what it was then and so is the
+  // output: the tile copies its flags and is done.  From the second sweep of a round on most tiles are that quiet.
+  if (!CLAIM && tchg_in) {
+    const int t = (int)blockIdx.x, lane = threadIdx.x;
+    uint32_t f = 0u;
+    if (lane < 27) { const int nt = lane == 13 ? t : nbr_tiles[(int64_t)t * 27 + lane]; if (nt >= 0) f = tchg_in[nt]; }
+    if (__ballot(f != 0u) == 0ull) {
+      const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+      for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) P_out[v] = P_in[v];
+      if (lane == 0) tchg_out[t] = 0u;
+      return;
+    }
+  }
   __shared__ __attribute__((aligned(16))) int L[VT_CELLS];
   // CLAIM: the per-supervoxel sums move with the voxels that change owner, per tile in an LDS table keyed by label (k_vccs_expand_tiles)
   __shared__ int s_key[CLAIM ? VT_SLOTS : 1];
@@ -938,7 +960,10 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
       any_change = any_change || pn != p;
     }
   }
-  if (!CLAIM && __ballot(any_change) != 0ull && lane == 0) atomicOr(changed, 1u);
+  if (!CLAIM) {
+    const bool chg = __ballot(any_change) != 0ull;
+    if (lane == 0) { if (chg) atomicOr(changed, 1u); if (tchg_out) tchg_out[t] = chg ? 1u : 0u; }
+  }
   if (CLAIM && __ballot(touched) != 0ull) {
     vt_sync();
     if (lane < VT_SLOTS) {
@@ -995,17 +1020,19 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->vc_tile_start.ensure(V + 1));
     hipLaunchKernelGGL(k_vccs_tile_heads, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->head_flag.p);
     VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p);
+    VGS_HIP_TRY(c, c->vc_tile_of.ensure(V));
+    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p, c->vc_tile_of.p);
     uint32_t T32 = 0;
     VGS_READBACK(c, &T32, c->perm_a.p + (V - 1), 4);
     NT = (int)T32;
     const unsigned long long pool_cap = 7ull * (unsigned long long)V;
     VGS_HIP_TRY(c, c->vc_cell.ensure(V)); VGS_HIP_TRY(c, c->vc_halo.ensure(pool_cap));
     VGS_HIP_TRY(c, c->vc_tile_meta.ensure(NT)); VGS_HIP_TRY(c, c->vc_pool.ensure(1)); VGS_HIP_TRY(c, c->vc_plive.ensure(2 * (size_t)V));
+    VGS_HIP_TRY(c, c->vc_nbr_tiles.ensure(27 * (size_t)NT)); VGS_HIP_TRY(c, c->vc_tchg.ensure(2 * (size_t)NT));
     VGS_HIP_TRY(c, hipMemsetAsync(c->vc_pool.p, 0, 8, c->stream));
     hipLaunchKernelGGL(k_vccs_tile_setup, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
                        c->vc_tile_start.p, c->vc_cell.p, (float*)nullptr, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p,
-                       (uint2*)c->vc_tile_meta.p);
+                       (uint2*)c->vc_tile_meta.p, (const uint32_t*)c->vc_tile_of.p, c->vc_nbr_tiles.p);
   }
   hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p);
   hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p);
@@ -1066,6 +1093,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   float* dst[2] = {dist.p, dist.p + V};
   uint8_t* live[2] = {c->vc_live.p, c->vc_live.p + V};
   int32_t* plive[2] = {tiles ? c->vc_plive.p : nullptr, tiles ? c->vc_plive.p + V : nullptr};
+  uint32_t* tchg[2] = {tiles ? c->vc_tchg.p : nullptr, tiles ? c->vc_tchg.p + NT : nullptr};   // per tile: a flag changed in that sweep
   unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);
   int cur = 0;
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
@@ -1083,7 +1111,10 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
     }
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
-      if (tiles) hipLaunchKernelGGL(k_pclt_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], plive[lc]);
+      if (tiles) {
+        hipLaunchKernelGGL(k_pclt_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], plive[lc]);
+        VGS_HIP_TRY(c, hipMemsetAsync(tchg[lc], 0x01, (size_t)NT * 4, c->stream));   // the first sweep of a round works every tile
+      }
       else hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
       // fixed point of the live flags: the recursion is on smaller labels, so it ends -- a sweep that changes nothing is the proof.
       // Sweeps go out in pairs with one read-back per pair (a sweep at the fixed point changes nothing, so a spare one is harmless):
@@ -1097,7 +1128,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
           if (tiles)
             hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                                (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
-                               d_changed + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr);
+                               d_changed + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr,
+                               (const int32_t*)c->vc_nbr_tiles.p, (const uint32_t*)tchg[lc], tchg[lc ^ 1]);
           else
             hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                                live[lc ^ 1], d_changed + k);
@@ -1110,7 +1142,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       if (tiles)
         hipLaunchKernelGGL(k_pclt_sweep<true>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                            (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
-                           (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p);
+                           (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p, (const int32_t*)nullptr,
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr);
       else
         hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                            own[cur ^ 1], dst[cur ^ 1]);
@@ -1174,7 +1207,7 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->vc_tile_start.ensure(V + 1));
     hipLaunchKernelGGL(k_vccs_tile_heads, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->head_flag.p);
     VGS_HIP_TRY(c, rocprim::inclusive_scan(c->sort_tmp.p, scan_bytes_t, c->head_flag.p, c->perm_a.p, (size_t)V, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p);
+    hipLaunchKernelGGL(k_vccs_tile_starts, dim3(nbV), dim3(TB), 0, c->stream, c->head_flag.p, c->perm_a.p, V, c->vc_tile_start.p, (uint32_t*)nullptr);
     VGS_HIP_TRY(c, hipMemcpyAsync(&T32, c->perm_a.p + (V - 1), 4, hipMemcpyDeviceToHost, c->stream));
   }
   hipLaunchKernelGGL(k_vccs_cell_codes, dim3(nbV), dim3(TB), 0, c->stream, cen.p, V, mnx, mny, mnz, seed, c->cell_code_a.p, c->cell_id_a.p);
@@ -1198,7 +1231,8 @@ vgs_status vgs_stage_vccs(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->vc_tile_meta.ensure(NT)); VGS_HIP_TRY(c, c->vc_pool.ensure(1));
     VGS_HIP_TRY(c, hipMemsetAsync(c->vc_pool.p, 0, 8, c->stream));
     hipLaunchKernelGGL(k_vccs_tile_setup, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                       c->vc_tile_start.p, c->vc_cell.p, nrm.p, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p, (uint2*)c->vc_tile_meta.p);
+                       c->vc_tile_start.p, c->vc_cell.p, nrm.p, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p, (uint2*)c->vc_tile_meta.p,
+                       (const uint32_t*)nullptr, (int32_t*)nullptr);
   }
   VGS_HIP_TRY(c, c->vc_seedkey.ensure(K)); VGS_HIP_TRY(c, c->vc_sums.ensure(6 * (size_t)K)); VGS_HIP_TRY(c, c->vc_count.ensure(K));
   VGS_HIP_TRY(c, c->vc_state.ensure(6 * (size_t)K));

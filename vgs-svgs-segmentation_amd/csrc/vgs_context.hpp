@@ -238,6 +238,8 @@ struct vgs_ctx {
   DevBuf<int32_t> vc_nbr, vc_label;
   DevBuf<int32_t> vc_nbr4;    // vc_nbr once more as [7][V] int4 (28 entries per voxel, two unused): four neighbours to a load for the expansion rounds
   DevBuf<uint32_t> vc_tile_start;   // expansion over tiles (vccs.hip): start of every 8^3 tile's run of voxels
+  DevBuf<uint32_t> vc_tile_of, vc_tchg;        // vccs_mode 1: tile of every voxel; per tile "a live flag changed in that sweep" (two sweeps' worth)
+  DevBuf<int32_t> vc_nbr_tiles;                // vccs_mode 1: the tiles on the 26 sides of a tile ([NT][27], -1: none)
   DevBuf<int32_t> vc_plive;                    // vccs_mode 1 over tiles: owner << 1 | live, two sweeps' worth
   DevBuf<uint16_t> vc_cell;                    // a voxel's cell in its tile's 10^3 label array
   DevBuf<uint64_t> vc_halo, vc_tile_meta, vc_pool;   // (voxel, cell) of the voxels in the tiles' shells; (offset, length) per tile; entries handed out
