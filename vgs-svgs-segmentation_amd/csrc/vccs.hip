@@ -1120,11 +1120,13 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       // Sweeps go out in pairs with one read-back per pair (a sweep at the fixed point changes nothing, so a spare one is harmless):
       // half the host round trips.  Leaving the loop without that proof would give labels that differ from the sequential
       // order silently: it is an error.
+      // Over tiles a sweep at the fixed point costs a few microseconds (every tile is quiet), a host round trip costs thirty: the first
+      // batch of a round is four sweeps (a round needs four or five; six were measured slower than pairs), later ones are pairs.
       bool settled = false;
-      for (int sweep = 0; sweep < 4096 && !settled; sweep += 2) {
-        unsigned int ch[2] = {1u, 1u};
-        for (int k = 0; k < 2; ++k) {
-          VGS_HIP_TRY(c, hipMemsetAsync(d_changed + k, 0, 4, c->stream));
+      for (int sweep = 0, nb = tiles ? 4 : 2; sweep < 4096 && !settled; sweep += nb, nb = 2) {
+        unsigned int ch[6] = {1u, 1u, 1u, 1u, 1u, 1u};
+        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4 * (size_t)nb, c->stream));
+        for (int k = 0; k < nb; ++k) {
           if (tiles)
             hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                                (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
@@ -1135,8 +1137,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
                                live[lc ^ 1], d_changed + k);
           lc ^= 1;
         }
-        VGS_READBACK(c, ch, d_changed, 8);
-        settled = !ch[0] || !ch[1];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
+        VGS_READBACK(c, ch, d_changed, 4 * (size_t)nb);
+        for (int k = 0; k < nb; ++k) settled = settled || !ch[k];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
       }
       if (!settled) { c->err = "svgs_supervoxels (vccs_mode 1): the live flags did not reach their fixed point in 4096 sweeps"; return VGS_E_STATE; }
       if (tiles)
