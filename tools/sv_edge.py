@@ -17,11 +17,15 @@ cases = [
     ("pc", 120_000, dict(voxel_size=0.02, seed_size=0.06, graph_size=0.2)),
     ("town", 200_000, dict(voxel_size=0.1, seed_size=0.1, graph_size=0.5)),
     ("urban", 200_000, dict(voxel_size=0.05, seed_size=1.0, graph_size=0.5)),
+    ("urban*40", 200_000, dict(voxel_size=4.0, seed_size=12.0, graph_size=20.0)),     # a scene of kilometres: tile-relative positions above 2^21 units
+    ("urban*100", 200_000, dict(voxel_size=10.0, seed_size=40.0, graph_size=50.0)),
 ]
 bad = 0
 for mode in (0, 1):
     for kind, n, kw in cases:
-        xyz = {"urban": v.scenes.urban_scene, "town": v.scenes.town_scene, "pc": v.scenes.pc_scene}[kind](n, seed=11)
+        base, _, scale = kind.partition("*")
+        xyz = {"urban": v.scenes.urban_scene, "town": v.scenes.town_scene, "pc": v.scenes.pc_scene}[base](n, seed=11)
+        if scale: xyz = (xyz * np.float32(float(scale))).astype(np.float32)
         p = v.default_params(3, vccs_mode=mode, **kw)
         try:
             e = v.Engine(p); e.set_points(xyz); e.supervoxels()
