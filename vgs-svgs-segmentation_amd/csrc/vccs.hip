@@ -382,7 +382,12 @@ __global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restri
     nrm[3 * (int64_t)v] = nn[0]; nrm[3 * (int64_t)v + 1] = nn[1]; nrm[3 * (int64_t)v + 2] = nn[2];
   }
 }
-#define VT_SLOTS 16
+// slots of a tile's table of per-supervoxel sums: a tile's window meets up to two dozen supervoxels at seed = 5 voxels; a contribution
+// that finds the table full goes to memory with seven 64-bit atomics (all of them that way: the stage takes twice as long).  Config 4
+// with 16 / 32 / 64 / 128 slots: 11.30 / 10.92 / 11.05 / 11.2 ms (64 slots cost the fifth LDS granule)
+#ifndef VT_SLOTS
+#define VT_SLOTS 32
+#endif
 __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta,
                               const uint2* __restrict__ halo, const uint16_t* __restrict__ cell,
                               const float* __restrict__ cen, const float* __restrict__ nrm, const int32_t* __restrict__ label_in,
@@ -396,9 +401,9 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
   __shared__ int s_cnt[VT_SLOTS];
   const int lane = threadIdx.x;
   const int t = (int)blockIdx.x;
-  if (lane < VT_SLOTS) {
-    s_key[lane] = -1; s_cnt[lane] = 0;
-    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0;
+  for (int k = lane; k < VT_SLOTS; k += 64) {
+    s_key[k] = -1; s_cnt[k] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[k][a] = 0;
   }
   for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);   // an empty cell reads as "no neighbour"
   const uint32_t ts = tile_start[t], te = tile_start[t + 1];
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
         const int sgn = side ? 1 : -1;
         int slot = -1;
         if (small) {
-          unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
+          unsigned int h = ((unsigned int)l * 2654435761u) >> (VT_SLOTS == 128 ? 25 : (VT_SLOTS == 64 ? 26 : (VT_SLOTS == 32 ? 27 : 28)));
           for (int probe = 0; probe < VT_SLOTS; ++probe) {
             const int prev = atomicCAS(&s_key[h], -1, l);
             if (prev == -1 || prev == l) { slot = (int)h; break; }
@@ -487,12 +492,12 @@ __global__ __launch_bounds__(64) void k_vccs_expand_tiles(int T, const uint32_t*
   }
   if (__ballot(touched) == 0ull) return;
   vt_sync();
-  if (lane < VT_SLOTS) {
-    const int l = s_key[lane];
+  for (int k = lane; k < VT_SLOTS; k += 64) {
+    const int l = s_key[k];
     if (l >= 0) {
-      const int dc = s_cnt[lane];
+      const int dc = s_cnt[k];
       for (int a = 0; a < 6; ++a) {
-        const long long x = (long long)s_sum[lane][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
+        const long long x = (long long)s_sum[k][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
         if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)x);
       }
       if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
@@ -857,9 +862,9 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
   const int lane = threadIdx.x;
   const int t = (int)blockIdx.x;
   for (int i = lane; i < VT_CELLS / 4; i += 64) ((int4*)L)[i] = make_int4(-1, -1, -1, -1);
-  if (CLAIM && lane < VT_SLOTS) {
-    s_key[lane] = -1; s_cnt[lane] = 0;
-    for (int a = 0; a < 6; ++a) s_sum[lane][a] = 0;
+  if (CLAIM) for (int k = lane; k < VT_SLOTS; k += 64) {
+    s_key[k] = -1; s_cnt[k] = 0;
+    for (int a = 0; a < 6; ++a) s_sum[k][a] = 0;
   }
   const uint32_t ts = tile_start[t], te = tile_start[t + 1];
   const uint2 m = meta[t];
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
           const int sgn = side ? 1 : -1;
           int slot = -1;
           if (small) {
-            unsigned int h = ((unsigned int)l * 2654435761u) >> 28;   // 4 bits
+            unsigned int h = ((unsigned int)l * 2654435761u) >> (VT_SLOTS == 128 ? 25 : (VT_SLOTS == 64 ? 26 : (VT_SLOTS == 32 ? 27 : 28)));
             for (int probe = 0; probe < VT_SLOTS; ++probe) {
               const int prev = atomicCAS(&s_key[h], -1, l);
               if (prev == -1 || prev == l) { slot = (int)h; break; }
@@ -966,12 +971,12 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
   }
   if (CLAIM && __ballot(touched) != 0ull) {
     vt_sync();
-    if (lane < VT_SLOTS) {
-      const int l = s_key[lane];
+    for (int k = lane; k < VT_SLOTS; k += 64) {
+      const int l = s_key[k];
       if (l >= 0) {
-        const int dc = s_cnt[lane];
+        const int dc = s_cnt[k];
         for (int a = 0; a < 6; ++a) {
-          const long long x = (long long)s_sum[lane][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
+          const long long x = (long long)s_sum[k][a] + (a < 3 ? (long long)dc * base[a] : 0ll);
           if (x) atomicAdd((unsigned long long*)&sums[6 * l + a], (unsigned long long)x);
         }
         if (dc > 0) atomicAdd(&count[l], (unsigned int)dc); else if (dc < 0) atomicSub(&count[l], (unsigned int)(-dc));
