@@ -368,17 +368,39 @@ __global__ __launch_bounds__(64) void k_vccs_tile_setup(const uint64_t* __restri
     const int y = (int)(((lo >> 1) & 1u) | ((lo >> 3) & 2u) | ((lo >> 5) & 4u));
     const int x = (int)(((lo >> 2) & 1u) | ((lo >> 4) & 2u) | ((lo >> 6) & 4u));
     const int ci = (x + 1) + 10 * (y + 1) + 100 * (z + 1);
-    float pts[27 * 3];
-    pts[0] = cen[3 * (int64_t)v]; pts[1] = cen[3 * (int64_t)v + 1]; pts[2] = cen[3 * (int64_t)v + 2];
+    // (vccs_normal_from_points without its array of 27 centroids -- 324 bytes of scratch per lane, 3 GB of scratch traffic per run:
+    // the centroids are gathered twice in the same order, the second time out of the cache; same operations in the same order)
+    const float p0[3] = {cen[3 * (int64_t)v], cen[3 * (int64_t)v + 1], cen[3 * (int64_t)v + 2]};
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    sx = sx + p0[0]; sy = sy + p0[1]; sz = sz + p0[2];
     int np = 1;
 #pragma unroll
     for (int o = 0; o < 26; ++o) {
       const int k = o < 13 ? o : o + 1;   // vccs_offset(o)
       const int u = I[ci + (k % 3 - 1) + 10 * ((k / 3) % 3 - 1) + 100 * (k / 9 - 1)];
-      if (u >= 0) { pts[3 * np] = cen[3 * (int64_t)u]; pts[3 * np + 1] = cen[3 * (int64_t)u + 1]; pts[3 * np + 2] = cen[3 * (int64_t)u + 2]; ++np; }
+      if (u >= 0) { sx = sx + cen[3 * (int64_t)u]; sy = sy + cen[3 * (int64_t)u + 1]; sz = sz + cen[3 * (int64_t)u + 2]; ++np; }
     }
-    float nn[3];
-    vccs_normal_from_points(pts, np, nn);
+    float nn[3] = {0.f, 0.f, 0.f};
+    if (np >= 3) {
+      const float mx = sx / np, my = sy / np, mz = sz / np;
+      float C[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      {
+        const float d0 = p0[0] - mx, d1 = p0[1] - my, d2 = p0[2] - mz;
+        C[0] = C[0] + d0 * d0; C[1] = C[1] + d0 * d1; C[2] = C[2] + d0 * d2;
+        C[4] = C[4] + d1 * d1; C[5] = C[5] + d1 * d2; C[8] = C[8] + d2 * d2;
+      }
+#pragma unroll
+      for (int o = 0; o < 26; ++o) {
+        const int k = o < 13 ? o : o + 1;
+        const int u = I[ci + (k % 3 - 1) + 10 * ((k / 3) % 3 - 1) + 100 * (k / 9 - 1)];
+        if (u >= 0) {
+          const float d0 = cen[3 * (int64_t)u] - mx, d1 = cen[3 * (int64_t)u + 1] - my, d2 = cen[3 * (int64_t)u + 2] - mz;
+          C[0] = C[0] + d0 * d0; C[1] = C[1] + d0 * d1; C[2] = C[2] + d0 * d2;
+          C[4] = C[4] + d1 * d1; C[5] = C[5] + d1 * d2; C[8] = C[8] + d2 * d2;
+        }
+      }
+      vccs_normal_finish(C, p0, nn);
+    }
     nrm[3 * (int64_t)v] = nn[0]; nrm[3 * (int64_t)v + 1] = nn[1]; nrm[3 * (int64_t)v + 2] = nn[2];
   }
 }

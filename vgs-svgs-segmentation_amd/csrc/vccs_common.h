@@ -15,6 +15,16 @@ VGS_HD void vccs_offset(int o, int* dx, int* dy, int* dz) {
 
 // normal of a voxel: smallest-eigenvalue direction of the covariance of the centroids of the voxel (pts[0..2]) and
 // its occupied neighbours, flipped towards the viewpoint (0,0,0); zero when fewer than 3 centroids are available
+// (the tail of vccs_normal_from_points: C holds the six upper sums, p0 is the voxel's own centroid; vccs.hip's tile kernel gathers the
+// centroids twice in the same order instead of keeping them in an array of 81 floats, which lives in scratch memory on the GPU)
+VGS_HD void vccs_normal_finish(float* C, const float* p0, float* n) {
+  C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+  float evecs[9], evals[3];
+  vm_eigen33(C, evecs, evals);
+  float nx = evecs[0], ny = evecs[3], nz = evecs[6];
+  if ((nx * (0.f - p0[0]) + ny * (0.f - p0[1]) + nz * (0.f - p0[2])) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+  n[0] = nx; n[1] = ny; n[2] = nz;
+}
 VGS_HD void vccs_normal_from_points(const float* pts, int np, float* n) {
   n[0] = 0.f; n[1] = 0.f; n[2] = 0.f;
   if (np < 3) return;
@@ -27,12 +37,7 @@ VGS_HD void vccs_normal_from_points(const float* pts, int np, float* n) {
     C[0] = C[0] + d0 * d0; C[1] = C[1] + d0 * d1; C[2] = C[2] + d0 * d2;
     C[4] = C[4] + d1 * d1; C[5] = C[5] + d1 * d2; C[8] = C[8] + d2 * d2;
   }
-  C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-  float evecs[9], evals[3];
-  vm_eigen33(C, evecs, evals);
-  float nx = evecs[0], ny = evecs[3], nz = evecs[6];
-  if ((nx * (0.f - pts[0]) + ny * (0.f - pts[1]) + nz * (0.f - pts[2])) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
-  n[0] = nx; n[1] = ny; n[2] = nz;
+  vccs_normal_finish(C, pts, n);
 }
 
 VGS_HD uint64_t vccs_seed_cell(float cx, float cy, float cz, float min_x, float min_y, float min_z, float seed) {
