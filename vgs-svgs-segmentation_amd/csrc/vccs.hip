@@ -60,11 +60,13 @@ __global__ void k_vccs_neighbours(const uint64_t* __restrict__ vox_code, int64_t
     if (nx < lim && ny < lim && nz < lim) { bool unused_flag; t = brick_find(bricks, hbits, nx, ny, nz, &unused_flag); }
     nbr[(int64_t)o * V + v] = t;   // [26][V]: a wavefront reads one offset of 64 consecutive voxels
     quad[o] = t;
-    if (t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
+    if (nrm && t >= 0) { pts[3 * np] = cen[3 * t]; pts[3 * np + 1] = cen[3 * t + 1]; pts[3 * np + 2] = cen[3 * t + 2]; ++np; }
   }
-  float n[3];
-  vccs_normal_from_points(pts, np, n);
-  nrm[3 * v] = n[0]; nrm[3 * v + 1] = n[1]; nrm[3 * v + 2] = n[2];
+  if (nrm) {   // (vccs_mode 1 has its own two-ring normals and passes null)
+    float n[3];
+    vccs_normal_from_points(pts, np, n);
+    nrm[3 * v] = n[0]; nrm[3 * v + 1] = n[1]; nrm[3 * v + 2] = n[2];
+  }
   // the same table four entries to a load ([7][V] of int4: the expansion rounds read it 54 times and are bound by their number of
   // vector-memory instructions, not by bytes)
   if (nbr4)
@@ -1033,9 +1035,9 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   VGS_HIP_TRY(c, c->counters.ensure(64));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
-  // the 26-neighbour table (its 1-ring normals are overwritten by the 2-ring ones)
+  // the 26-neighbour table (no 1-ring normals: the 2-ring ones follow)
   hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, nrm.p, (int4*)nullptr);
+                     c->vc_nbr.p, (float*)nullptr, (int4*)nullptr);
   // tiles for the live sweeps and the claim (k_pclt_sweep)
   const bool tiles = !c->K.no_vccs_tiles;
   int NT = 0;
