@@ -40,6 +40,9 @@ def test_one_wavefront_local_cut_keeps_its_registers_without_scratch(tmp_path):
         assert u["VGPRs Spill"] == 0, (name, u)
         assert u["VGPRs"] <= 80, (name, u)
         assert u["Occupancy"] >= 6, (name, u)
+    # class C0: six workgroups of 26 KB per CU need six wavefronts per SIMD as well
+    c0 = [v for n, v in k.items() if "k_localcut_waveILi320ELi2032ELi4E" in n]
+    assert len(c0) == 1 and c0[0]["VGPRs"] <= 80 and c0[0]["VGPRs Spill"] == 0 and c0[0]["Occupancy"] >= 6, c0
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -72,6 +72,11 @@
 #ifndef LW_NEAR_GROUPS
 #define LW_NEAR_GROUPS 2
 #endif
+// class C0 (MAXM 320, 26 KB of LDS): six workgroups fit a CU only if its wavefronts keep to the 80 registers of six per SIMD (at four per
+// SIMD the compiler takes 91 and the CU holds five workgroups, as for class C): config 2 10.5 -> 10.1 ms, no spilled vector register
+#ifndef LW_WAVES_C0
+#define LW_WAVES_C0 6
+#endif
 #ifndef LW_MASTER_ROT
 #define LW_MASTER_ROT 0
 #endif
@@ -119,7 +124,7 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
 // the bookkeeping between shells stay on wavefront 0.  Candidates are then appended through an LDS counter, so their
 // order in the list depends on timing; the sort that follows removes that (keys are unique).
 template <int MAXM, int LCAP, int NW = 1>
-__global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? 4 : 2)) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
+__global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM == 320 ? LW_WAVES_C0 : 4) : 2)) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
                                                       const uint32_t* __restrict__ work, int n_work,
                                                       const unsigned int* __restrict__ n_work_dev,
                                                       const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt,
