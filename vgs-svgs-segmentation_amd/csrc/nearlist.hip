@@ -15,7 +15,10 @@
 #ifndef NLB_QCAP
 #define NLB_QCAP 128
 #endif
-__global__ __launch_bounds__(64) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
+#ifndef NL_WAVES
+#define NL_WAVES 8   // 64 registers, no spill: the 32 wavefronts per CU the 2.4 KB queue allows (at the default budget the compiler took 69: 28)
+#endif
+__global__ __launch_bounds__(64, NL_WAVES) void k_near_lists(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                    const uint32_t* __restrict__ adj_cnt, int adj_stride, const NodeRec* __restrict__ node,
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
                                                    float lat_d2_lim, float d2max, const uint64_t* __restrict__ vox_code,
