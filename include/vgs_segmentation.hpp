@@ -115,7 +115,6 @@ class VoxelBasedSegmentation {
     if (!cloud_) throw std::runtime_error("addPointsFromInputCloud before setInputCloud");
     chk(vgs_set_points(ctx(), &cloud_->points[0].x, (int64_t)cloud_->points.size(), (int32_t)sizeof(PointT)), "vgs_set_points");
     chk(vgs_voxelize(ctx()), "vgs_voxelize");
-    voxelized_res_ = p_.voxel_size;
     adj_off_.clear(); adj_idx_.clear();
   }
   void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {
@@ -142,15 +141,19 @@ class VoxelBasedSegmentation {
     return out;
   }
 
+  // VS:124-131 only STORES its arguments: the octree keeps binning with the constructor's resolution (VS:84), and so does the
+  // engine -- voxel_size is not forwarded.  The stored value is what the reference's debug meshes draw their boxes with
+  // (VS:561-582) and what getVoxelCenterFromOctreeKey scales the keys by (VS:2106-2108); with a value other than the
+  // constructor's the reference's centres no longer lie in their voxels, which the engine does not reproduce: its centres
+  // are the octree's own ("setVoxelSize").
   void setVoxelSize(double input_resolution, int points_num_min, int voxels_num_min, int voxels_adj_min) {  // VS:124
-    p_.voxel_size = (float)input_resolution; p_.points_min = points_num_min; p_.voxels_min = voxels_num_min;
+    voxel_resolution_ = (float)input_resolution; p_.points_min = points_num_min; p_.voxels_min = voxels_num_min;
     p_.adjacency_min = voxels_adj_min;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
   }
+  float getVoxelResolution() const { return voxel_resolution_ > 0.0f ? voxel_resolution_ : p_.voxel_size; }   // (debug meshes)
   void setBoundingBox(double, double, double, double, double, double) {}                 // VS:133 (the engine keeps the octree's box)
-  // VS:146.  The voxel table is built by addPointsFromInputCloud; a setVoxelSize() with another resolution in between (the reference
-  // only stores the value, VS:124-131, and would go on with an octree of the old size) rolls the context back to its points, so the
-  // table is rebuilt here at the new size -- as the Python mirror does (api.py) -- instead of failing later with VGS_E_STATE.
+  // VS:146.  The voxel table is built by addPointsFromInputCloud with the constructor's resolution and stays as it is.
   void setVoxelCenters() { ensure_voxels(); }
   std::vector<PointXYZ> getVoxelCenters() {                                              // VS:191
     ensure_voxels();
@@ -216,14 +219,8 @@ class VoxelBasedSegmentation {
   std::unique_ptr<vgs_ctx, vgs_detail::CtxDeleter> ctx_;
   PCXYZPtr cloud_;
   bool drawn_ = false;
-  float voxelized_res_ = -1.0f;    // resolution the voxel table was built with (addPointsFromInputCloud / ensure_voxels)
-  void ensure_voxels() {
-    if (voxelized_res_ >= 0.0f && voxelized_res_ != p_.voxel_size) {   // setVoxelSize changed the resolution: the context is back at its points
-      chk(vgs_voxelize(ctx()), "vgs_voxelize");
-      voxelized_res_ = p_.voxel_size;
-      adj_off_.clear(); adj_idx_.clear();
-    }
-  }
+  float voxel_resolution_ = 0.0f;  // setVoxelSize's value (VS:127): stored, never binned with
+  void ensure_voxels() {}          // (the table is built by addPointsFromInputCloud; kept as the one place a lazy rebuild would go)
   std::vector<int64_t> adj_off_;   // getOneVoxelAdjacency's copy of the lists
   std::vector<int32_t> adj_idx_;
 };

@@ -34,15 +34,20 @@ def test_cpp_driver_matches_python_engine(gpu, tmp_path):
 
 @pytest.mark.gpu
 def test_set_voxel_size_after_the_octree_was_built(gpu, tmp_path):
-    """setVoxelSize() with a resolution other than the constructor's (the reference only stores it, voxel_segmentation.h:124-131):
-    the mirror rebuilds the voxel table at the new size in setVoxelCenters() -- round 3 threw VGS_E_STATE in the next call."""
+    """setVoxelSize() with a resolution other than the constructor's only STORES it (voxel_segmentation.h:124-131): the octree
+    keeps the constructor's resolution (VS:84), so the segmentation is the one of the constructor's voxel size."""
     subprocess.check_call(["make", "-C", CSRC, "-s", "example"])
     xyz = gpu.scenes.town_scene(40_000)
     f = tmp_path / "pts.f32"
     xyz.tofile(f)
-    want = subprocess.check_output([EXE, str(f)], text=True).split()
-    got = subprocess.check_output([EXE, str(f), "--ctor-res", "0.4"], text=True).split()
-    assert got == want
+    got = [int(x) for x in subprocess.check_output([EXE, str(f), "--ctor-res", "0.4"], text=True).split()]
+    eng = gpu.Engine(gpu.default_params(2, voxel_size=0.4))
+    eng.set_points(xyz)
+    eng.run()
+    c = eng.counts()
+    assert got == [c["points"], c["voxels"], c["clusters"], c["kept"], int((eng.point_labels() >= 0).sum())]
+    plain = [int(x) for x in subprocess.check_output([EXE, str(f)], text=True).split()]
+    assert plain[1] != got[1]   # (the task file's 0.15 m gives another voxel table)
 
 
 RUN = os.path.join(ROOT, "examples", "vgs_run")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one BASELINE.json configuration on the GPU and print ONE bench-style JSON line (counts, ms per step, stage times).
-usage: tools/run_config.py c1|c2|c3|c4 [points] [steps]      (not the bench contract: bench.py times configs[2])"""
+usage: tools/run_config.py c1|c2|c3|c3n|c4|c4p|xl [points] [steps]      (not the bench contract: bench.py times configs[2])"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vgs_svgs_segmentation_amd as v
@@ -16,6 +16,10 @@ elif cfg == "c4":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3), "URB10M: urban scene, SVGS (Task_File_SVGS.txt: voxel 0.05 m, seed 0.25 m, graph 0.5 m)"
 elif cfg == "c4p":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3, vccs_mode=1), "URB10M: urban scene, SVGS, supervoxels in PCL's own order (vccs_mode 1)"
+elif cfg == "c3n":
+    xyz, p, name = v.scenes.noisy_surface_scene(n or 5_000_000), v.default_params(2, voxel_size=0.1), "C3N: undulating surface, 3 cm range noise, VGS, voxel 0.1 m, graph 0.5 m"
+elif cfg == "xl":
+    xyz, p, name = v.scenes.solid_block_scene(n or 500_000), v.default_params(2, voxel_size=0.05, graph_size=0.5), "BLOCK: solid cube, VGS, voxel 0.05 m, graph 0.5 m (neighbourhoods up to 4159 voxels)"
 elif cfg == "c1":
     xyz, p, name = v.scenes.town_scene(n or 500_000), v.default_params(2), "TOWN stand-in: VGS, Task_File_VGS.txt defaults"
 else:

@@ -304,7 +304,8 @@ class VoxelBasedSegmentation:
         self._eng.voxelize()
 
     def setVoxelSize(self, input_resolution, points_num_min, voxels_num_min, voxels_adj_min):  # VS:124
-        self._p.voxel_size = float(input_resolution)
+        # stored only (VS:127): the octree keeps binning with the constructor's resolution (VS:84)
+        self.voxel_resolution_ = float(input_resolution)
         self._p.points_min = int(points_num_min)
         self._p.voxels_min = int(voxels_num_min)
         self._p.adjacency_min = int(voxels_adj_min)

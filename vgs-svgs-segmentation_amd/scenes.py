@@ -187,6 +187,25 @@ def tiled_urban_scene(n_total=80_000_000, tiles=(4, 2), seed0=SEEDS["URB80M"], t
     return out[0] if tile_index is not None else np.concatenate(out, axis=0)
 
 
+def noisy_surface_scene(n=5_000_000, seed=1, sigma=0.03):
+    """"c3n": an undulating surface under centimetres of range noise (6000 points per m^2, sigma = 3 cm by default) -- the
+    regime real terrestrial scans live in and the synthetic BASELINE scenes (sigma = 3 mm) do not reach: no segment of a
+    neighbourhood forms early and freezes, so almost every voxel needs all of its heavy pairs.  (numpy's default PCG64
+    stream: the scene DESIGN.md quoted since round 2, tools/fuzzy_bench.py.)"""
+    rng = np.random.default_rng(seed)
+    side = np.sqrt(n / 6000.0)
+    x, y = rng.random(n) * side, rng.random(n) * side
+    z = 0.3 * np.sin(2.0 * x) * np.cos(1.5 * y) + rng.normal(0, sigma, n) + 2.0
+    return np.stack([x + 0.011, y + 0.017, z], axis=1).astype(np.float32)
+
+
+def solid_block_scene(n=500_000, side=1.30, seed=12):
+    """Points uniform in a solid cube (tools/xl_time.py): at voxel 0.05 m / graph 0.5 m its neighbourhoods are whole search
+    balls of up to 4159 used voxels -- the regime above every one-wavefront and dense class of the local cut."""
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(0, 1, (n, 3)) * side + np.array([1.0, -2.0, 0.2])).astype(np.float32)
+
+
 def make_scene(name, n=None):
     name = name.upper()
     if name == "PC1M":
@@ -197,4 +216,8 @@ def make_scene(name, n=None):
         return town_scene(n or 500_000)
     if name == "URB80M":
         return tiled_urban_scene(n or 80_000_000)
+    if name == "C3N":
+        return noisy_surface_scene(n or 5_000_000)
+    if name == "BLOCK":
+        return solid_block_scene(n or 500_000)
     raise ValueError(f"unknown scene {name}")
