@@ -143,6 +143,9 @@ vgs_status vgs_get_stage_times(vgs_ctx* ctx, double* ms /* VGS_T_COUNT */);
 vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
 /* The same with room to grow (n <= 16): 8 neighbourhoods above 2048 used voxels, cut by the extra-large instantiation of the general
  * kernel (the reference sizes its matrix to any n, VS:1815-1818; round 4 -- such a voxel used to end the run with VGS_E_UNSUPPORTED) */
+/* round 5: 9 voxels cut by the pair-list kernel (csrc/localcut_pg.hpp), 10 entries of the pair lists built for them (csrc/pairlist.hpp),
+ * 11 one-wavefront voxels handed over without a try on the strength of the scene's samples (LwParams::vote), 12 rows that found the
+ * pair lists' pool exhausted */
 vgs_status vgs_get_schedule_counters_ex(vgs_ctx* ctx, int64_t* out, int32_t n);
 /* Screening table of the dense hand-over kernels for a parameter set (host arithmetic, no context, no GPU; for tests): a
  * pair of valid positions and normals whose squared centroid distance d2 is >= *d2_stop, or whose dot(n1, n2) lies in

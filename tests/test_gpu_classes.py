@@ -89,8 +89,9 @@ def test_case_reaches_the_class(run):
     assert sc["outside_limits"] == 0
     if run["name"] in ("plane_r10", "slab_r10"):
         # smooth surfaces seen through a ball of ten voxels: more heavy edges than the dense kernels' lists hold, taken in
-        # bands of descending weight (localcut_dense.hpp); the slab's neighbourhoods above 512 go on to the general kernel
-        assert sc["banded"] > 0, sc
+        # bands of descending weight (localcut_dense.hpp) -- or, round 5, read from the pair lists in bands of descending weight by
+        # construction (localcut_pg.hpp); the slab's neighbourhoods above 512 go on to the general kernel
+        assert sc["banded"] > 0 or sc["pair_list_cut"] > 0, sc
     if run["name"] == "slab_r10":
         assert sc["dense_sent_on"] > 0 and sc["handed_over_large"] > 0, sc
 

@@ -87,7 +87,10 @@ def test_case_reaches_its_path(case):
     sc = case["eng"].schedule_counters()
     assert sc["outside_limits"] == 0
     for key in REACHES.get(case["name"], ()):
-        assert sc[key] > 0, f"{case['name']} was built to reach {key}: {sc}"
+        # (round 5: where hand-overs are many they are cut from the pair lists -- bands of descending weight by construction -- instead
+        # of the dense kernel's banded phases)
+        got = sc[key] + (sc["pair_list_cut"] if key == "banded" else 0)
+        assert got > 0, f"{case['name']} was built to reach {key}: {sc}"
 
 
 def test_adjacency_exact_order(case):

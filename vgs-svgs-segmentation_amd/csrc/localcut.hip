@@ -503,11 +503,13 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 
 #include "localcut_wave.hpp"
 #include "localcut_dense.hpp"
+#include "localcut_pg.hpp"
 #ifndef LD_SMALL_LCAP
 #define LD_SMALL_LCAP 2048
 #endif
 #define DN_SMALL 128, LD_SMALL_LCAP, 2048, 256   // hand-overs of the one-wavefront classes
 #define DN_LARGE 512, 4096, 2048, 512   // hand-overs of classes C and D up to 512 neighbours
+#define PG_SMALL 128, 2048, 4, 5, true   // the pair-list kernel for the hand-overs of the one-wavefront classes
 
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
@@ -538,17 +540,55 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
   for (int k = lane; k < cb_words; k += 64) cbits[(size_t)u * (size_t)cb_words + k] = cb[k];
 }
 
+// The hand-over lists of the one-wavefront classes, built from the marks their kernels left (pending[u] = 1 + list + LW_HO_BINS * why,
+// localcut_wave.hpp): voxel order, one atomic per list and 1024 voxels; the reasons are counted into the schedule counters on the way.
+// The marks become plain "pending" flags for the merge stage.
+__global__ __launch_bounds__(1024) void k_ho_lists(uint8_t* __restrict__ pending, int64_t U, uint32_t* __restrict__ ids, int64_t stride,
+                                                   unsigned int* __restrict__ n_lists, unsigned long long* __restrict__ counters) {
+  __shared__ unsigned int s_cnt[16][LW_HO_BINS];
+  __shared__ unsigned int s_base[LW_HO_BINS];
+  __shared__ unsigned int s_why[LW_N_WHY];
+  if (threadIdx.x < LW_N_WHY) s_why[threadIdx.x] = 0u;
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bin = -1, why = -1;
+  if (u < U) { const int p = (int)pending[u]; if (p != 0 && p != LW_PENDING_LISTED) { bin = (p - 1) % LW_HO_BINS; why = (p - 1) / LW_HO_BINS; pending[u] = LW_PENDING_LISTED; } }
+  unsigned long long mk[LW_HO_BINS];
+  for (int k = 0; k < LW_HO_BINS; ++k) {
+    mk[k] = __ballot(bin == k);
+    if (lane == 0) s_cnt[wave][k] = (unsigned int)__popcll(mk[k]);
+  }
+  __syncthreads();
+  for (int k = 0; k < LW_N_WHY; ++k) {
+    const unsigned long long wk = __ballot(why == k);
+    if (lane == 0 && wk != 0ull) atomicAdd(&s_why[k], (unsigned int)__popcll(wk));
+  }
+  if (threadIdx.x < LW_HO_BINS) {
+    const int k = threadIdx.x;
+    unsigned int tot = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
+    s_base[k] = tot ? atomicAdd(&n_lists[k], tot) : 0u;
+  }
+  __syncthreads();
+  if (bin >= 0) ids[(int64_t)bin * stride + s_base[bin] + s_cnt[wave][bin] + __popcll(mk[bin] & ((1ull << lane) - 1ull))] = (uint32_t)u;
+  if (threadIdx.x < LW_N_WHY && s_why[threadIdx.x] != 0u) {
+    const int word[LW_N_WHY] = {3, 62, -1};   // the lazy schedule gave the voxel up (whatever the reason), voted over, (size: not counted)
+    if (word[threadIdx.x] >= 0) atomicAdd(&counters[word[threadIdx.x]], (unsigned long long)s_why[threadIdx.x]);
+  }
+}
+
 // split the used voxels into classes by the number of neighbours; order inside a class follows the voxel order.
 // Class A (the bulk) is split once more: voxels with few heavy near pairs of their own (short near-pair list) are the
 // ones the lazy schedule works on for long or gives up on, so they form class A1, the part of the bulk launch that is
 // dealt out first.  (Any voxel may go to any class: the split only schedules.)
 // One global atomic per class and 1024 voxels (same-address atomics serialise).
-#define LC_NCLASS 6   // A, B, C, D, A1, C0 (the part of class C up to max_c0 neighbours: a smaller LDS footprint, one more workgroup per CU)
+#define LC_NCLASS 7   // A, B, C, D, A1, C0 (the part of class C up to max_c0 neighbours: a smaller LDS footprint, one more workgroup per CU), S (samples of A, A1, B: LwParams::ho_bins)
 __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ adj_mused, const uint32_t* __restrict__ adj_cnt, int64_t U, int prune,
                                                    int max_a, int max_b, int max_c, const uint32_t* __restrict__ used_ids,
                                                    const uint8_t* __restrict__ nl_cnt, const uint32_t* __restrict__ nl_tot, int a1_max, uint32_t* __restrict__ ids_a,
                                                    uint32_t* __restrict__ ids_b, uint32_t* __restrict__ ids_c, uint32_t* __restrict__ ids_d,
-                                                   uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc, int max_c0, uint32_t* __restrict__ ids_c0) {
+                                                   uint32_t* __restrict__ ids_a1, unsigned int* __restrict__ n_abc, int max_c0, uint32_t* __restrict__ ids_c0,
+                                                   int sample, uint32_t* __restrict__ ids_s) {
   __shared__ unsigned int s_cnt[16][LC_NCLASS];   // per wavefront and class: count, then base
   __shared__ unsigned int s_base[LC_NCLASS];
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -557,7 +597,8 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
     cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 5 : (m <= max_c ? 2 : 3)));
-    if (cls == 0 && nl_cnt && nl_cnt[used_ids[u]] != NL_NONE && (int)nl_tot[used_ids[u]] <= a1_max) cls = 4;   // a voxel without a list stays in A
+    if (sample && cls <= 1 && (u & 15) == 0) cls = 6;   // every sixteenth voxel of the one-wavefront classes (k_count_classes counts alike)
+    if (cls == 0 && nl_cnt && nl_cnt[used_ids[u]] != NL_NONE && (int)nl_tot[used_ids[u]] <= a1_max) cls = 4;   // a voxel without a list stays in A   // every sixteenth voxel of the one-wavefront classes (before the A1 split: k_count_classes counts alike)
   }
   unsigned long long mk[LC_NCLASS];
   for (int k = 0; k < LC_NCLASS; ++k) {
@@ -572,7 +613,7 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
     s_base[k] = tot ? atomicAdd(&n_abc[k], tot) : 0u;
   }
   __syncthreads();
-  uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1, ids_c0};
+  uint32_t* const outs[LC_NCLASS] = {ids_a, ids_b, ids_c, ids_d, ids_a1, ids_c0, ids_s};
   for (int k = 0; k < LC_NCLASS; ++k)
     if (cls == k) outs[k][s_base[k] + s_cnt[wave][k] + __popcll(mk[k] & ((1ull << lane) - 1ull))] = (uint32_t)u;
 }
@@ -580,19 +621,19 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
 // Class sizes alone (A and A1 together): what the host needs to size the launches does not depend on the near-pair lists, so it is
 // counted BEFORE they are built and fetched while they are (vgs_stage_localcut).
 __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restrict__ adj_cnt, int64_t U, int max_a, int max_b, int max_c, int max_c0,
-                                                        unsigned int* __restrict__ n_cls /* 5: A + A1, B, C, D, C0 */) {
-  __shared__ unsigned int s_cnt[5];
-  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0u;
+                                                        unsigned int* __restrict__ n_cls /* 6: A + A1, B, C, D, C0, S */, int sample) {
+  __shared__ unsigned int s_cnt[6];
+  if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cls = -1;
-  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); }
-  for (int k = 0; k < 5; ++k) {
+  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); if (sample && cls <= 1 && (u & 15) == 0) cls = 5; }
+  for (int k = 0; k < 6; ++k) {
     const unsigned long long mk = __ballot(cls == k);
     if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_cnt[k], (unsigned int)__popcll(mk));
   }
   __syncthreads();
-  if (threadIdx.x < 5 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 6 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // Smallest squared distance (to the bisection's resolution) whose weight bound is at or below a singleton's threshold:
@@ -690,10 +731,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure((9 + LW_HO_BINS) * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure((10 + LW_HO_BINS) * (size_t)U + 16));
   VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
-  VGS_HIP_TRY(c, c->counters.ensure(64));
-  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 64 * sizeof(uint64_t), c->stream));
+  VGS_HIP_TRY(c, c->counters.ensure(128));   // words 64-127: the one-wavefront classes' samples (LwParams::vote)
+  VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 128 * sizeof(uint64_t), c->stream));
+  {
+    // pair lists (pairlist.hpp): state reset here, rows built when a class asks for them
+    vgs_status sp = vgs_pairlists_begin(c, c->stream);
+    if (sp != VGS_OK) return sp;
+  }
   uint32_t* ids_a = c->work_ids.p;            // m <= WAVE_A: one wavefront per voxel, records in LDS, small footprint
   uint32_t* ids_b = c->work_ids.p + U;        // m <= WAVE_B: one wavefront per voxel, records in LDS
   uint32_t* ids_c = c->work_ids.p + 2 * U;    // m <= WAVE_C: one wavefront per voxel, centroids in LDS, records through L2
@@ -703,6 +749,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   uint32_t* ids_a1 = c->work_ids.p + 6 * U;   // class A voxels with a short near-pair list of their own: they run first
   uint32_t* ids_c0 = c->work_ids.p + (8 + LW_HO_BINS) * U;   // class C0: WAVE_B < m <= WAVE_C0
   uint32_t* ids_f2 = c->work_ids.p + 7 * U;   // sent on by the dense hand-over kernel (a list overflowed)
+  uint32_t* ids_s = c->work_ids.p + (9 + LW_HO_BINS) * U;   // samples of the one-wavefront classes (LwParams::ho_bins)
   unsigned int* d_nabc = (unsigned int*)(c->counters.p + 8);   // 5 class counters (words 8-10)
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);        // lengths of the LW_HO_BINS lists (words 14-15)
   unsigned int* d_ng = (unsigned int*)(c->counters.p + 11) + 1;    // word 11, upper half
@@ -735,9 +782,11 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 #endif
   unsigned int* d_ncls = (unsigned int*)(c->counters.p + 44);   // words 44-46: A + A1, B, C, D, C0
   const int max_c0 = c->K.no_c0 ? WAVE_B : WAVE_C0;   // VGS_NO_C0: class C takes them all
+  const bool dense_ = !c->K.no_dense;
+  const int sample = (c->pl_enabled && dense_ && !c->K.no_vote) ? 1 : 0;
   if (early_sizes) {
-    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls);
-    vgs_status sb = vgs_readback_begin(c, d_ncls, 20);
+    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls, sample);
+    vgs_status sb = vgs_readback_begin(c, d_ncls, 24);
     if (sb != VGS_OK) return sb;
   }
   {
@@ -749,14 +798,14 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const int a1_max = c->K.a1_max;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, c->adj_cnt.p, U,
                      0, WAVE_A, WAVE_B, WAVE_C, c->used_ids.p, c->nl_enabled ? c->nl_cnt.p : (const uint8_t*)nullptr, c->nl_tot.p, a1_max, ids_a, ids_b, ids_c,
-                     ids_d, ids_a1, d_nabc, max_c0, ids_c0);
-  unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0, 0};
+                     ids_d, ids_a1, d_nabc, max_c0, ids_c0, sample, ids_s);
+  unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
   unsigned int n_bulk = 0;   // A + A1
   if (early_sizes) {
-    unsigned int ncls[5] = {0, 0, 0, 0, 0};
-    vgs_status se = vgs_readback_end(c, ncls, 20);
+    unsigned int ncls[6] = {0, 0, 0, 0, 0, 0};
+    vgs_status se = vgs_readback_end(c, ncls, 24);
     if (se != VGS_OK) return se;
-    n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3]; nabc[5] = ncls[4];
+    n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3]; nabc[5] = ncls[4]; nabc[6] = ncls[5];
     nabc[0] = n_bulk; nabc[4] = 0;   // (host-side bookkeeping only: the kernel reads the split from d_nabc)
   } else {
     VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
@@ -810,7 +859,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->conn_bits.ensure((size_t)U * (size_t)c->cb_words));
     WP.cbits = c->conn_bits.p; WP.cb_R = c->cb_R; WP.cb_words = c->cb_words;
   }
-  WP.ho_bins = dense ? LW_HO_BINS : 1;
+  WP.ho_bins = (dense ? LW_HO_BINS : 1) | (sample ? LW_HO_VOTE : 0);
   WP.ho_stride = (int)U;
   {
     // Shells up to (NL_REACH voxels)^2 are complete in the near-pair lists; the margin covers centroids that float
@@ -858,6 +907,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // launched BEFORE the bulk class: once the bulk class has filled every CU's LDS with its small workgroups a 35 KB
   // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).
   // from here on the side streams carry work of this run: a failure below must make the next run wait for them
+  c->pl_enabled_at_launch = false;
   c->lc_tail.open = true; c->lc_tail.dense = dense; c->lc_tail.grid_f = 0; c->lc_tail.grid_g = GRID_G; c->lc_tail.tail_ms = 0.f;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
@@ -893,11 +943,15 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       if (!dense) st = launch_block(c->stream2, ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
       else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
         hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(ncd < 4 * GRID_G ? ncd : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
-                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p);
+                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0, 0u, 0});
     }
     if (st != VGS_OK) return st;
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[3], c->stream2));
+  // the samples of the one-wavefront classes (LwParams::ho_bins) first: the others read what they found
+  if (nabc[6] > 0)
+    hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B, 1, true>), dim3(vgs_xcd_grid(nabc[6])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
+                       ids_s, (int)nabc[6], (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, WP, c->conn.p, cnt, ids_f, d_nf, c->evals.p, dbg_buf, c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
   // classes A and B have the same LDS footprint, so their workgroups interleave freely; B (heavier) goes first
   if (nabc[1] > 0)
     hipLaunchKernelGGL((k_localcut_wave<WAVE_B, LCAP_B>), dim3(vgs_xcd_grid(nabc[1])), dim3(64), 0, c->stream3, (const uint32_t*)nullptr, 0,
@@ -925,19 +979,53 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // touch no handed-over voxel meanwhile (its small workgroups leave the LDS to the 34 KB workgroups of this kernel).
   // (A second pass through the wave kernel with a 1024-edge list and 16 rounds was measured: it costs as much as the
   // workgroup kernel and still hands half of them over.)
-  const unsigned int nab = nabc[0] + nabc[1] + nabc[4];
+  const unsigned int nab = nabc[0] + nabc[1] + nabc[4] + nabc[6];
   // about 1.4 % of the A/B voxels are handed over on the urban scenes; idle workgroups of this kernel are not free
   const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
   {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
+    if (dense && nab > 0)
+      hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt);
     vgs_status st = VGS_OK;
     if (!dense) {
       st = launch_block(c->stream3, ids_f, grid_f, true, d_nf, 0);
+    } else if (grid_f > 0 && c->pl_enabled) {
+      c->pl_enabled_at_launch = true;
+      // Hand-overs of the one-wavefront classes, two ways, decided ON THE DEVICE by how many there are (the launches are queued before
+      // anybody knows: LcGate).  Few (a smooth scene's clutter: 1 % of the voxels): the dense kernel evaluates their pairs itself --
+      // building the pair lists of every row their neighbourhoods touch would evaluate more pairs than that.  Many (range noise, vegetation:
+      // every neighbourhood wants all of its heavy pairs): the rows are built, every heavy pair ONCE instead of once per neighbourhood,
+      // and one workgroup per voxel reads them in bands of descending weight (localcut_pg.hpp).  What either cannot take goes on to the
+      // general kernel through the same list.
+      const unsigned int many = c->K.pg_min_frac > 0 ? (unsigned int)(U / c->K.pg_min_frac) : 0xffffffffu;
+      const LcGate g_few = {d_nf, LW_HO_BINS, many, 0}, g_many = {d_nf, LW_HO_BINS, many, 1};
+      hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few);
+      // (the pair-list chain on a stream of its own: when it is not wanted its four empty launches end beside the dense kernel, not behind it)
+      VGS_HIP_TRY(c, hipEventRecord(c->ev_ho, c->stream3));   // the lists are built
+      VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho, 0));
+      const uint32_t* ids4[LW_HO_BINS]; const unsigned int* nd4[LW_HO_BINS];
+      for (int k = 0; k < LW_HO_BINS; ++k) { ids4[k] = ids_f + (size_t)k * U; nd4[k] = d_nf + k; }
+      st = vgs_pairlists_build(c, c->stream4, ids4, nd4, nullptr, LW_HO_BINS, false, LP.ctab, LP.ctab_scale, LP.d2_stop, 1, g_many, false);
+      if (st == VGS_OK && c->pl_enabled) {
+        const PairLists PLs = {(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring};
+        const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
+        hipLaunchKernelGGL((k_localcut_pg<PG_SMALL>), dim3(grid_f), dim3(256), 0, c->stream4, ids_f, (int)U, LW_HO_BINS, d_nf, 0u, 0, c->adj_key.p, c->adj_cnt.p,
+                           c->adj_stride, c->adj_off.p, c->node.p, LP, PLs, G, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, (uint8_t*)nullptr,
+                           (uint32_t*)nullptr, 0, 0, g_many);
+      } else if (st == VGS_OK) {   // (the pool did not fit: the dense kernel takes them all)
+        hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream4, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
+                           c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_many);
+      }
     } else if (grid_f > 0) {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p);
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, LcGate{nullptr, 0, 0u, 0});
     }
     if (st != VGS_OK) return st;
+    if (grid_f > 0 && dense && c->pl_enabled_at_launch) {   // stream3 ends when both chains have
+      VGS_HIP_TRY(c, hipEventRecord(c->ev_ho2, c->stream4));
+      VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_ho2, 0));
+    }
     VGS_HIP_TRY(c, hipEventRecord(c->ev[4], c->stream3));
   }
   // the main stream goes on once every class has produced its rows or marked them pending
@@ -956,7 +1044,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
   c->lc_tail.nabc[2] += nabc[5];
   VGS_HIP_TRY(c, hipEventRecord(c->ev[13], c->stream));   // end of the stage's main-stream work (vgs_localcut_finish measures the tail behind it)
-  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2] + nabc[5]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
+  c->counts[13] = nabc[0] + nabc[4]; c->counts[14] = nabc[1] + nabc[2] + nabc[5] + nabc[6]; c->counts[15] = nabc[3];  // bulk launch (A1 + A), the other wave classes, class D
   c->counts[VGS_N_PAIRS] = -1;  // per-voxel counts stay in c->evals; vgs_get_counts sums them when asked
   VGS_HIP_TRY(c, hipGetLastError());
   return VGS_OK;
@@ -1013,8 +1101,10 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[3], 0));
   VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
   // one read-back: the kernels' flags (words 0-7), the lengths of the hand-over lists (word 11), the rows put off (word 13)
-  unsigned long long hc[16] = {0};
+  unsigned long long hc[64] = {0};   // (words 58-63: the pair lists' pool and the pair-list kernel's counts)
   VGS_READBACK(c, hc, cnt, sizeof(hc));
+  const unsigned long long lc_why[4] = {hc[3], hc[4], hc[5], hc[6]};   // (the first words of hc are read again behind the kernels launched below)
+  c->lc_diag[9] = (int64_t)hc[63]; c->lc_diag[10] = (int64_t)(hc[58] & 0xffffffffull); c->lc_diag[11] = (int64_t)hc[62]; c->lc_diag[12] = (int64_t)hc[60];
   const unsigned long long* h = hc;
   // hand-overs of the one-wavefront classes (all size lists together), of classes C/D
   const unsigned int nfg[2] = {(unsigned int)((hc[14] & 0xffffffffull) + (hc[14] >> 32) + (hc[15] & 0xffffffffull) + (hc[15] >> 32)),
@@ -1074,7 +1164,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     VGS_HIP_TRY(c, hipGetLastError());
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->lc_diag[0] = (int64_t)h[3]; c->lc_diag[1] = (int64_t)(h[4] + h[5] + h[6]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
+  c->lc_diag[0] = (int64_t)lc_why[0]; c->lc_diag[1] = (int64_t)(lc_why[1] + lc_why[2] + lc_why[3]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
   c->lc_diag[4] = (int64_t)nfg[1]; c->lc_diag[5] = (int64_t)h[1]; c->lc_diag[6] = (int64_t)(hc[13] & 0xffffffffull); c->lc_diag[7] = (int64_t)h[0];
   VGS_HIP_TRY(c, hipGetLastError());
   float kms = 0.f;
@@ -1112,7 +1202,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
       fprintf(stderr, "\n");
     }
   }
-  if (c->K.debug) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], h[3], h[4], h[5], h[6]);
+  if (c->K.debug) fprintf(stderr, "[vgs] localcut classes a=%lld b=%lld c=%lld fallback=%lld bail(shrink)=%llu bail(full)=%llu bail(collapse)=%llu bail(phaseB)=%llu\n", (long long)c->counts[13], (long long)c->counts[14], (long long)c->counts[15], (long long)c->counts[12], lc_why[0], lc_why[1], lc_why[2], lc_why[3]);
 #ifdef VGS_PROF
   {
     unsigned long long lp[2][16];
@@ -1132,6 +1222,14 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     for (int j = 0; j < 16; ++j) if (dn[j][0]) fprintf(stderr, " %s=%.4g", dn[j], j == 8 ? (double)(dp[j] & 0xffffffffull) : (double)dp[j]);
     fprintf(stderr, "\n");
     VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_dn_prof), z, sizeof(dp)));
+    unsigned long long pg[24];
+    VGS_HIP_TRY(c, hipMemcpyFromSymbol(pg, HIP_SYMBOL(g_pg_prof), sizeof(pg)));
+    const char* pn[24] = {"stage", "read", "sort", "merge", "carry", "ring", "phaseB", "result", "", "", "sum_edges", "ring_edges", "bands", "nB", "voxels", "", "", "", "", "", "", "", "", ""};
+    fprintf(stderr, "[vgs-prof] k_localcut_pg:");
+    for (int j = 0; j < 24; ++j) if (pn[j][0]) fprintf(stderr, " %s=%.4g", pn[j], (double)pg[j]);
+    fprintf(stderr, "\n");
+    unsigned long long z24[24] = {0};
+    VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_pg_prof), z24, sizeof(pg)));
   }
   {
     std::vector<uint32_t> dbg(4 * (size_t)U);

@@ -17,6 +17,8 @@
 #ifndef LOCALCUT_DENSE_HPP_
 #define LOCALCUT_DENSE_HPP_
 
+#include "pairlist.hpp"   // LcGate
+
 // Two instantiations: <128, 2048, 2048, 256> for the one-wavefront classes (30 KB of LDS, five voxels per CU) and
 // <512, 4096, 2048, 512> for the hand-overs of the classes above (78 KB, two per CU).  MAXM neighbours at most; LCAP edges
 // heavier than the singleton threshold a neighbourhood may hold (phase B: pairs at or below it); QCAP pairs per block of
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
                                                           int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                           uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                           uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
-                                                          uint32_t* __restrict__ evals_out) {
+                                                          uint32_t* __restrict__ evals_out, LcGate gate) {
+  if (!lc_gate_open(gate)) return;
   constexpr bool SMALL = MAXM <= 255;   // vertex indices and segment sizes fit a byte, pair ids 16 bits
   typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;
   typedef typename std::conditional<SMALL, uint16_t, uint32_t>::type q_t;

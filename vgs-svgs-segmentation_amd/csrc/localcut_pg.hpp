@@ -1,0 +1,610 @@
+// localcut_pg.hpp -- the local graph cut from the PAIR LISTS (pairlist.hpp): one workgroup per voxel, edges taken in exact bands
+// of descending weight, no weight evaluated inside the ball.  Included by localcut.hip behind localcut_dense.hpp.
+//
+// Reference semantics (voxel_segmentation.h:1913-2029) kept exactly, as in the other classes: edges in descending
+// (weight, then ascending pair) order, an edge merges two segments iff w > max(seg_int - cut / size), the result is the segment of
+// vertex 0.  What this class changes once more is where the edges come from.  The one-wavefront classes walk shells of increasing
+// centroid DISTANCE and need a bound between distance and weight (fact U of localcut_wave.hpp) to know how far down the scan may
+// go; the dense hand-over class evaluates every pair of the neighbourhood.  Here every vertex a of the neighbourhood brings the
+// list of its heavy pairs sorted by WEIGHT, so "all edges heavier than L" is a prefix of every list:
+//
+//   band:  every still-active vertex offers its next q entries; L = the heaviest entry NOT offered (>= the floor, see below);
+//          the offered entries heavier than L whose partner is a vertex of this neighbourhood (hash: lattice offset -> vertex),
+//          active and in another segment, are this band's edges -- complete: every unread entry weighs <= L;
+//          sort (regsort.hpp), merge down to L with the claim scheme of localcut_wave.hpp, freeze (fact F), next band.
+//
+// The scan ends as soon as the voxel's own segment is frozen (thr >= L), one segment is left, or the lists are exhausted.
+// Floors: the lists hold the pairs inside each other's ball only (pairlist.hpp); pairs of the neighbourhood outside it weigh at
+// most w_ring, so bands stay above w_ring until the "ring" pairs have been evaluated -- once, by this kernel, among the vertices
+// still active then -- and joined the carried edges; after that the floor is 1 - cut (fact S), below which phase B finishes on
+// direct evaluations as in localcut_dense.hpp.
+// A neighbourhood this kernel cannot take (a vertex without a list, more vertices than MAXM, a list that overflows even at one
+// entry per vertex) goes to `fallback`: the classes of round 4 are still behind it.
+#ifndef LOCALCUT_PG_HPP_
+#define LOCALCUT_PG_HPP_
+
+#include "pairlist.hpp"
+
+struct PgGeom {   // what the in-ball test of the ring stage needs: the voxel lattice as adjacency.hip sees it
+  const uint64_t* vox_code;
+  float res_f, min_x, min_y, min_z;
+  float r2;       // float(graph_size^2): the FLANN predicate's right-hand side
+};
+
+#ifdef VGS_PROF
+__device__ unsigned long long g_pg_prof[24];
+#define PGP_T0() long long _pt0 = clock64()
+#define PGP_ACC(slot) do { long long _pt1 = clock64(); if (tid == 0) atomicAdd(&g_pg_prof[slot], (unsigned long long)(_pt1 - _pt0)); _pt0 = _pt1; } while (0)
+#define PGP_CNT(slot, v) do { if (tid == 0) atomicAdd(&g_pg_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define PGP_T0() do {} while (0)
+#define PGP_ACC(slot) do {} while (0)
+#define PGP_CNT(slot, v) do {} while (0)
+#endif
+
+// MAXM vertices, LCAP edges in flight (<= 512 * NW: the sort's block size), NW wavefronts, OCC workgroups per CU the registers allow;
+// RING_LDS: centroids and normals of the vertices staged in LDS for the ring stage (not for the extra-large instantiation)
+template <int MAXM, int LCAP, int NW, int OCC, bool RING_LDS>
+__global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __restrict__ work, int work_stride, int n_lists,
+                                                             const unsigned int* __restrict__ n_work_dev, unsigned int n_work_host, int xcd_order,
+                                                             const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt, int adj_stride,
+                                                             const uint16_t* __restrict__ adj_off, const NodeRec* __restrict__ node, LcParams P,
+                                                             PairLists PL, PgGeom G, uint8_t* __restrict__ conn,
+                                                             unsigned long long* __restrict__ counters, uint32_t* __restrict__ fallback,
+                                                             unsigned int* __restrict__ n_fallback, uint32_t* __restrict__ evals_out,
+                                                             uint8_t* __restrict__ pending_mark, uint32_t* __restrict__ cbits, int cb_R, int cb_words, LcGate gate) {
+  constexpr int TB = 64 * NW;
+  constexpr int PSH = 16;
+  constexpr uint32_t PMASK = 0xffffu, PCOMP = 0xffffffffu;
+  constexpr int HCAP = MAXM <= 128 ? 256 : (MAXM <= 512 ? 1024 : (MAXM <= 1024 ? 2048 : (MAXM <= 4096 ? 8192 : 16384)));
+  static_assert(HCAP >= 2 * MAXM || MAXM > 4096, "hash load <= 1/2");
+  static_assert(LCAP <= 512 * NW, "one block of 512 keys per wavefront (regsort.hpp)");
+  __shared__ uint64_t lk[LCAP];               // weight bits << 32 | ~pair id
+  __shared__ uint32_t htab[HCAP];             // (packed offset + 1) << 16 | vertex, 0 = empty
+  __shared__ uint32_t lpos[MAXM], lend[MAXM]; // the unread part of every vertex's pair list (pool indices)
+  __shared__ float thr[MAXM];
+  __shared__ uint32_t claim[MAXM];
+  __shared__ uint16_t hlat[MAXM], lcons[MAXM], seg[MAXM], rep[MAXM], ssz[MAXM], alist[MAXM];
+  __shared__ float rc[RING_LDS ? 7 : 1][RING_LDS ? MAXM : 1];   // cx, cy, cz, nx, ny, nz, flags of every vertex (ring stage)
+  __shared__ float ctab3[3][32];              // voxel centres along each axis, offsets -16 .. 15 from the voxel (adjacency.hip's table)
+  __shared__ int s_i[8];
+  __shared__ unsigned int s_L;
+  enum { S_CNT = 0, S_NACT, S_BAD, S_POS, S_MERGES, S_NQ, S_FLAG };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!lc_gate_open(gate)) return;
+  const VgsWeightParams& W = P.W;
+  const float cut = P.cut;
+  const float thr0 = vm_cut_threshold(1.0f, cut, 1);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  unsigned int n_cut = 0;   // voxels this workgroup cut (counters[63], one atomic per workgroup)
+
+  auto h_slot = [&](uint32_t key15) -> uint32_t { return (key15 * 2654435761u) >> 12; };
+  auto h_find = [&](uint32_t key15) -> int {
+    uint32_t h = h_slot(key15);
+    while (true) {
+      const uint32_t e = htab[h & (HCAP - 1)];
+      if (e == 0u) return -1;
+      if ((e >> 16) == key15 + 1u) return (int)(e & 0xffffu);
+      ++h;
+    }
+  };
+
+  auto process = [&](const uint32_t u) {
+    const int m = __builtin_amdgcn_readfirstlane((int)adj_cnt[u]);
+    const uint64_t* row = adj_key + (int64_t)u * adj_stride;
+    const uint16_t* orow = adj_off + (int64_t)u * adj_stride;
+    uint8_t* crow = conn + (int64_t)u * adj_stride;
+    PGP_T0();
+    auto R = [&](int v) -> const NodeRec& { return node[(uint32_t)row[v]]; };
+    auto hand_on = [&]() {   // all threads; the row is written by whoever takes the voxel from the fallback list
+      if (tid == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; atomicAdd(&counters[7], 1ull); if (pending_mark) pending_mark[u] = 0xff; }
+    };
+    if (m > MAXM || orow[0] == 0xffffu) { hand_on(); return; }
+    static_assert(sizeof(uint64_t) * LCAP >= 4 * 1024, "the bit row (<= 31^3 offsets) fits the edge list");
+    // ---- the neighbourhood: lists, offsets, hash, segment state ----
+    for (int k = tid; k < HCAP; k += TB) htab[k] = 0u;
+    if (tid == 0) { s_i[S_BAD] = 0; s_i[S_MERGES] = 0; }
+    __syncthreads();
+    {
+      bool bad = false;
+      for (int c = tid; c < m; c += TB) {
+        const uint32_t t = (uint32_t)row[c];
+        const uint2 ix = PL.idx[t];
+        bad = bad || ix.y >= PL_UNUSABLE;
+        lpos[c] = ix.x; lend[c] = ix.x + (ix.y >= PL_UNUSABLE ? 0u : ix.y);
+        const uint32_t key15 = orow[c];
+        hlat[c] = (uint16_t)key15;
+        uint32_t h = h_slot(key15);
+        while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
+        seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu;
+        if constexpr (RING_LDS) {
+          const NodeRec& rcd = node[t];
+          rc[0][c] = rcd.c[0]; rc[1][c] = rcd.c[1]; rc[2][c] = rcd.c[2]; rc[3][c] = rcd.n[0]; rc[4][c] = rcd.n[1]; rc[5][c] = rcd.n[2];
+          rc[6][c] = __uint_as_float(rcd.flags);
+        }
+      }
+      if (bad) s_i[S_BAD] = 1;
+    }
+    if (tid < 96) {
+      const uint64_t code = G.vox_code[(uint32_t)row[0]];   // the voxel itself is the first entry of its row
+      const int a = tid >> 5, k = tid & 31;
+      const uint32_t key = vm_compact21(code >> (2 - a)) + (uint32_t)(k - 16);
+      ctab3[a][k] = vm_voxel_center(key, G.res_f, a == 0 ? G.min_x : (a == 1 ? G.min_y : G.min_z));
+    }
+    __syncthreads();
+    if (s_i[S_BAD]) { hand_on(); return; }
+    unsigned int my_pairs = 0;
+    bool done = m < 2 || PL.any[(uint32_t)row[0]] != 1;   // no heavy pair holds the voxel: it stays alone (uniform)
+    bool handed = false;
+    PGP_ACC(0);
+
+    // Merge of lk[0, cnt) (sorted) down to (not including) weights <= level, on wavefront 0: the claim scheme of localcut_wave.hpp
+    // with the chain walk of localcut_dense.hpp (sizes and thresholds travel with the walk).  Leaves the position of the first
+    // unprocessed edge in s_i[S_POS], the merges so far in s_i[S_MERGES], seg[] flattened.  Ends with a workgroup barrier.
+    auto merge_list = [&](int cnt, float level) {
+      if (wave == 0) {
+        int merges = s_i[S_MERGES];
+        int pos = 0;
+        bool reached = false;
+        while (pos < cnt && !reached) {
+          const int e = pos + lane;
+          float w = 0.f;
+          int sa = 0, sb = 0;
+          bool alive = false;
+          if (e < cnt) {
+            const uint64_t key = lk[e];
+            w = vm_from_bits((uint32_t)(key >> 32));
+            alive = w > level;
+            const uint32_t pid = PCOMP - (uint32_t)key;
+            sa = seg[pid >> PSH];
+            sb = seg[pid & PMASK];
+          }
+          const int nproc = __popcll(__ballot(alive));   // sorted: the processable edges are a prefix of the step
+          while (true) {
+            float ta = 0.f, tb = 0.f;
+            int nsz = 1;
+            if (alive) {
+              int r = rep[sa], rb = rep[sb], za = (int)ssz[sa], zb = (int)ssz[sb];
+              ta = thr[sa]; tb = thr[sb];
+              while (r != sa || rb != sb) { sa = r; sb = rb; r = rep[sa]; rb = rep[sb]; za = (int)ssz[sa]; zb = (int)ssz[sb]; ta = thr[sa]; tb = thr[sb]; }
+              nsz = za + zb;
+              alive = sa != sb;
+            }
+            if (__ballot(alive) == 0ull) break;
+            if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
+            wave_sync();
+            bool decided = false;
+            if (alive) {
+              const uint32_t ca = claim[sa], cb = claim[sb];   // both loads before either compare
+              decided = (ca == (uint32_t)lane) & (cb == (uint32_t)lane);
+            }
+            wave_sync();
+            if (alive) { claim[sa] = 0xffffffffu; claim[sb] = 0xffffffffu; }
+            const bool pass = decided && (w > ta) && (w > tb);
+            if (pass) {
+              const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
+              const int gone = sa ^ sb ^ keep;
+              rep[gone] = (uint16_t)keep;
+              thr[keep] = vm_cut_threshold(w, cut, nsz);   // seg_int = w (VS:1988)
+              ssz[keep] = (uint16_t)nsz;
+              ssz[gone] = 0;
+            }
+            merges += __popcll(__ballot(pass));
+            alive = alive && !decided;
+            wave_sync();
+          }
+          if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
+          if (merges >= m - 1) break;
+          if (!reached && pos < cnt) {
+            // every edge from here on weighs at most wn: the voxel's own segment frozen above that ends the scan (fact F)
+            const float wn = vm_from_bits((uint32_t)(lk[pos] >> 32));
+            int s0 = 0, r;
+            while ((r = rep[s0]) != s0) s0 = r;
+            if (!(thr[s0] < wn)) { pos = cnt; break; }   // (what is left of the list is dead for the voxel: nothing to carry)
+          }
+        }
+        for (int c = lane; c < m; c += 64) {
+          int s = seg[c];
+          while (rep[s] != s) s = rep[s];
+          seg[c] = (uint16_t)s;
+        }
+        if (lane == 0) { s_i[S_POS] = pos; s_i[S_MERGES] = merges; }
+      }
+      __syncthreads();
+    };
+    auto sort_list = [&](int cnt) __attribute__((always_inline)) {
+      regsort::sort_desc_block<NW>(lk, cnt, wave, lane, [&]() { __syncthreads(); });
+    };
+    // pair p of the row-major triangle over nv vertices (a < b), decoded from the end (localcut_wave.hpp: enum_section)
+    auto decode = [&](uint32_t p, int nv, uint32_t Pn, int& a, int& b) {
+      const uint32_t qq = Pn - 1u - p;
+      uint32_t r = (uint32_t)((__builtin_amdgcn_sqrtf((float)(8u * qq + 1u)) - 1.0f) * 0.5f);
+      r += (((r + 1u) * (r + 2u)) >> 1) <= qq ? 1u : 0u;
+      r -= ((r * (r + 1u)) >> 1) > qq ? 1u : 0u;
+      a = nv - 2 - (int)r;
+      b = nv - 1 - (int)(qq - ((r * (r + 1u)) >> 1));
+    };
+
+    bool phase_a_complete = false;
+    if (!done) {
+      const float floor_ring = PL.w_ring > thr0 ? PL.w_ring : thr0;
+      bool ring_done = !(PL.w_ring > thr0);   // ring pairs that cannot be heavy are no edges of phase A
+      float lev = __builtin_huge_valf();      // every edge heavier than this has been processed
+      int n_carry = 0;
+      int bands = 0;
+      int min_lq = 0;
+      while (true) {
+        ++bands;
+        // ---- the vertices that still have unread entries and can still merge (fact F) ----
+        if (tid == 0) { s_i[S_NACT] = 0; }
+        __syncthreads();
+        for (int base = 0; base < m; base += TB) {
+          const int v = base + tid;
+          bool act = false;
+          if (v < m) act = lpos[v] < lend[v] && thr[seg[v]] < lev;
+          const unsigned long long mk = __ballot(act);
+          int b = 0;
+          if (mk != 0ull && lane == 0) b = atomicAdd(&s_i[S_NACT], __popcll(mk));
+          b = __builtin_amdgcn_readfirstlane(b);
+          if (act) alist[b + __popcll(mk & lt_mask)] = (uint16_t)v;
+        }
+        __syncthreads();
+        const int n_act = s_i[S_NACT];
+        const float floor = ring_done ? thr0 : floor_ring;
+        int free_slots = LCAP - n_carry;
+        int lq = 5;   // log2 of the entries a vertex offers per band
+        while (lq > 1 && (n_act << lq) > free_slots) --lq;
+        if (lq < min_lq) lq = min_lq;   // (a band that consumed nothing: equal keys filled the offer -- the next offer is wider)
+        float L = floor;
+        int cnt = n_carry;
+        while (true) {   // (repeated with a smaller offer when the band overflows the list)
+          const int q = 1 << lq;
+          if (tid == 0) { s_L = vm_bits(floor); s_i[S_CNT] = 0; }
+          __syncthreads();
+          // -- 1. L: the heaviest entry behind the offers --
+          {
+            uint32_t best = 0u;
+            for (int it = tid; it < n_act; it += TB) {
+              const int v = alist[it];
+              const uint32_t g = lpos[v] + (uint32_t)q;
+              if (g < lend[v]) { const float4 E = PL.ent[g]; const float k = E.x > E.y ? E.x : E.y; const uint32_t kb = vm_bits(k); best = kb > best ? kb : best; }
+            }
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)best, o, 64); best = x > best ? x : best; }
+            if (lane == 0 && best != 0u) atomicMax(&s_L, best);
+          }
+          __syncthreads();
+          L = vm_from_bits(s_L);
+          // -- 2. the offered entries heavier than L --
+          const int items = n_act << lq;
+          for (int base = 0; base < items; base += TB) {
+            const int item = base + tid;
+            bool take = false, inr = false;
+            int v = 0;
+            uint32_t pid = 0;
+            float w = 0.0f;
+            if (item < items) {
+              v = alist[item >> lq];
+              const uint32_t g = lpos[v] + (uint32_t)(item & (q - 1));
+              if (g < lend[v]) {
+                const float4 E = PL.ent[g];
+                take = (E.x > E.y ? E.x : E.y) > L;
+                if (take) {
+                  const uint32_t la = hlat[v], of = __float_as_uint(E.z);
+                  const int bx = (int)(la & 31u) + (int)(of & 31u) - 16, by = (int)((la >> 5) & 31u) + (int)((of >> 5) & 31u) - 16,
+                            bz = (int)((la >> 10) & 31u) + (int)((of >> 10) & 31u) - 16;
+                  if ((unsigned)bx < 32u && (unsigned)by < 32u && (unsigned)bz < 32u) {
+                    const int vb = h_find((uint32_t)bx | ((uint32_t)by << 5) | ((uint32_t)bz << 10));
+                    if (vb >= 0) {
+                      w = v < vb ? E.x : E.y;   // the row's order decides which end is the weight's first argument
+                      const int sa = seg[v], sb = seg[vb];
+                      const float t1 = thr[sa], t2 = thr[sb];
+                      // fact S: an edge at or below thr0 belongs to phase B; fact F: both ends must still be able to merge
+                      inr = (w > thr0) & (sa != sb) & (t1 < lev) & (t2 < lev);
+                      const int lo = v < vb ? v : vb, hi = v ^ vb ^ lo;
+                      pid = ((uint32_t)lo << PSH) | (uint32_t)hi;
+                    }
+                  }
+                }
+              }
+            }
+            // an entry is consumed when it is heavier than L: a prefix of the vertex's offer (the offers of one vertex sit in one wavefront)
+            const unsigned long long tk = __ballot(take);
+            if (item < items && (item & (q - 1)) == 0) lcons[v] = (uint16_t)__popcll(tk & (((q == 64 ? 0ull : (1ull << q)) - 1ull) << (lane & 63)));
+            const unsigned long long mk = __ballot(inr);
+            int b = 0;
+            if (mk != 0ull && lane == 0) b = atomicAdd(&s_i[S_CNT], __popcll(mk));
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (inr) { const int at = n_carry + b + __popcll(mk & lt_mask); if (at < LCAP) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid); }
+          }
+          __syncthreads();
+          cnt = n_carry + s_i[S_CNT];
+          if (cnt <= LCAP) break;
+          if (lq == 0 || lq <= min_lq) { handed = true; break; }   // more edges than the list holds at one entry per vertex
+          --lq;
+          __syncthreads();
+        }
+        if (handed) break;
+        {
+          bool any_c = false;
+          for (int it = tid; it < n_act; it += TB) { const int v = alist[it]; const uint32_t cn = (uint32_t)lcons[v]; lpos[v] += cn; any_c = any_c || cn != 0u; }
+          if (tid == 0) s_i[S_FLAG] = 0;
+          __syncthreads();
+          if (any_c) s_i[S_FLAG] = 1;
+          __syncthreads();
+          if (s_i[S_FLAG] == 0 && L > floor && n_act > 0) {   // uniform: nothing consumed although entries are left
+            min_lq = lq + 1;
+            if (min_lq > 6) { handed = true; break; }   // more than 64 equal keys in one list: degenerate ties
+          } else {
+            min_lq = 0;
+          }
+        }
+        PGP_ACC(1);
+        PGP_CNT(10, cnt);
+        // -- 3. sort, merge down to L --
+        if (cnt > 0) {
+          sort_list(cnt);
+          PGP_ACC(2);
+          merge_list(cnt, L);
+          PGP_ACC(3);
+        } else {
+          if (tid == 0) s_i[S_POS] = 0;
+          __syncthreads();
+        }
+        const int pos = s_i[S_POS];
+        lev = L;
+        {
+          const int s0 = seg[0];
+          if (s_i[S_MERGES] >= m - 1 || !(thr[s0] < L)) break;   // one segment left, or the voxel's own segment is frozen (fact F)
+        }
+        // -- 4. carry: the edges at or below L (one orientation of a pair above the band, the other inside) and ring edges --
+        {
+          // in place and ascending: a write never passes the read position; one wavefront (the tail is a handful of edges)
+          if (wave == 0) {
+            int kept = 0;
+            for (int base = pos; base < cnt; base += 64) {
+              const int e = base + lane;
+              bool keep_e = false;
+              uint64_t kk = 0;
+              if (e < cnt) {
+                kk = lk[e];
+                const uint32_t pid = PCOMP - (uint32_t)kk;
+                const int sa = seg[pid >> PSH], sb = seg[pid & PMASK];
+                const float t1 = thr[sa], t2 = thr[sb];
+                keep_e = (sa != sb) & (t1 < L) & (t2 < L);
+              }
+              const unsigned long long mk = __ballot(keep_e);
+              wave_sync();
+              if (keep_e) lk[kept + __popcll(mk & lt_mask)] = kk;
+              kept += __popcll(mk);
+              wave_sync();
+            }
+            if (lane == 0) s_i[S_POS] = kept;
+          }
+          __syncthreads();
+          n_carry = s_i[S_POS];
+        }
+        PGP_ACC(4);
+        if (L > floor) continue;
+        if (ring_done) { phase_a_complete = true; break; }   // every list is read to its end (all keys are above thr0)
+        // ---- the ring stage: pairs of still-active vertices that are not in each other's ball, evaluated here, once ----
+        ring_done = true;
+        {
+          if (tid == 0) { s_i[S_NACT] = 0; s_i[S_NQ] = 0; s_i[S_CNT] = 0; }
+          __syncthreads();
+          for (int base = 0; base < m; base += TB) {
+            const int v = base + tid;
+            const bool act = v < m && thr[seg[v]] < lev;
+            const unsigned long long mk = __ballot(act);
+            int b = 0;
+            if (mk != 0ull && lane == 0) b = atomicAdd(&s_i[S_NACT], __popcll(mk));
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (act) alist[b + __popcll(mk & lt_mask)] = (uint16_t)v;
+          }
+          __syncthreads();
+          const int na = s_i[S_NACT];
+          const uint32_t Pn = (uint32_t)(na * (na - 1) / 2);
+          // the queue of screened pairs sits in the upper half of the edge list; edges grow behind the carried ones in the lower half
+          uint32_t* const queue = (uint32_t*)(lk + LCAP / 2);
+          constexpr int QCAP = LCAP;   // 32-bit slots
+          bool over = n_carry > LCAP / 4;
+          for (uint32_t base = 0; base < Pn && !over; base += QCAP) {
+            for (uint32_t p = base + (uint32_t)tid; p < base + QCAP; p += TB) {   // same trip count for every thread
+              bool keep = false;
+              int a = 0, b = 0;
+              if (p < Pn) {
+                int ia, ib;
+                decode(p, na, Pn, ia, ib);
+                const int xa = alist[ia], xb = alist[ib];
+                a = xa < xb ? xa : xb; b = xa ^ xb ^ a;
+                if (seg[a] != seg[b]) {
+                  const uint32_t la = hlat[a], lb = hlat[b];
+                  const float tx = ctab3[0][la & 31u] - ctab3[0][lb & 31u], ty = ctab3[1][(la >> 5) & 31u] - ctab3[1][(lb >> 5) & 31u],
+                              tz = ctab3[2][(la >> 10) & 31u] - ctab3[2][(lb >> 10) & 31u];
+                  const float d2c = (tx * tx + ty * ty) + tz * tz;
+                  if (!(d2c < G.r2)) {   // not in each other's row (adjacency.hip's predicate): no list holds this pair
+                    ++my_pairs;
+                    NodeRec A, B;
+                    if constexpr (RING_LDS) {
+                      A.c[0] = rc[0][a]; A.c[1] = rc[1][a]; A.c[2] = rc[2][a]; A.n[0] = rc[3][a]; A.n[1] = rc[4][a]; A.n[2] = rc[5][a]; A.flags = __float_as_uint(rc[6][a]);
+                      B.c[0] = rc[0][b]; B.c[1] = rc[1][b]; B.c[2] = rc[2][b]; B.n[0] = rc[3][b]; B.n[1] = rc[4][b]; B.n[2] = rc[5][b]; B.flags = __float_as_uint(rc[6][b]);
+                    } else {
+                      const NodeRec& ra = R(a); const NodeRec& rb = R(b);
+                      A.c[0] = ra.c[0]; A.c[1] = ra.c[1]; A.c[2] = ra.c[2]; A.n[0] = ra.n[0]; A.n[1] = ra.n[1]; A.n[2] = ra.n[2]; A.flags = ra.flags;
+                      B.c[0] = rb.c[0]; B.c[1] = rb.c[1]; B.c[2] = rb.c[2]; B.n[0] = rb.n[0]; B.n[1] = rb.n[1]; B.n[2] = rb.n[2]; B.flags = rb.flags;
+                    }
+                    const float dx = A.c[0] - B.c[0], dy = A.c[1] - B.c[1], dz = A.c[2] - B.c[2];
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const uint32_t both = A.flags & B.flags;
+                    if ((both & VGS_F_POS) != 0u && d2 >= P.d2_stop) {
+                      keep = false;
+                    } else if ((both & (VGS_F_POS | VGS_F_NRM)) == (VGS_F_POS | VGS_F_NRM) && d2 > 0.0f) {
+                      int kb = (int)(d2 * P.ctab_scale);
+                      kb = kb > LC_TBINS - 1 ? LC_TBINS - 1 : kb;
+                      const float dot = vm_dot3(A.n, B.n);
+                      keep = !(dot <= P.ctab[kb] && dot >= -1.0f);
+                    } else {
+                      keep = !(vm_weight_bound_da(A, B, W) <= thr0);
+                    }
+                  }
+                }
+              }
+              const unsigned long long mk = __ballot(keep);
+              if (mk != 0ull) {
+                int qb = 0;
+                if (lane == 0) qb = atomicAdd(&s_i[S_NQ], __popcll(mk));
+                qb = __builtin_amdgcn_readfirstlane(qb);
+                if (keep) { const int at = qb + __popcll(mk & lt_mask); if (at < QCAP) queue[at] = ((uint32_t)a << PSH) | (uint32_t)b; }
+              }
+            }
+            __syncthreads();
+            const int nq = s_i[S_NQ];
+            if (nq > QCAP) { over = true; break; }
+            for (int e = tid; e < nq; e += TB) {
+              const uint32_t pid = queue[e];
+              const float w = vm_pair_weight(R((int)(pid >> PSH)), R((int)(pid & PMASK)), W);
+              if (w > thr0) {
+                const int at = n_carry + atomicAdd(&s_i[S_CNT], 1);
+                if (at < LCAP / 2) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
+              }
+            }
+            __syncthreads();
+            if (tid == 0) s_i[S_NQ] = 0;
+            if (n_carry + s_i[S_CNT] > LCAP / 2) over = true;   // uniform: written before the barrier above
+            __syncthreads();
+          }
+          if (over) { handed = true; break; }
+          n_carry += s_i[S_CNT];
+          PGP_CNT(11, s_i[S_CNT]);
+          __syncthreads();
+        }
+        PGP_ACC(5);
+      }
+      PGP_CNT(12, bands); (void)bands;
+    }
+    if (handed) { hand_on(); return; }
+
+    // =========================== phase B: edges at or below a singleton's threshold ===========================
+    if (phase_a_complete && s_i[S_MERGES] < m - 1) {
+      const int s0 = seg[0];
+      const bool s0_active = (ssz[s0] >= 2) && (thr[s0] < thr0);
+      if (s0_active) {   // uniform
+        if (tid == 0) { s_i[S_CNT] = 0; s_i[S_FLAG] = 0; }
+        if (wave == 0) {
+          // the vertices of the active segments, the voxel's own segment first
+          int n0 = 0;
+          for (int base = 0; base < m; base += 64) {
+            const int v = base + lane;
+            const bool own = v < m && seg[v] == s0;
+            const unsigned long long mk = __ballot(own);
+            if (own) alist[n0 + __popcll(mk & lt_mask)] = (uint16_t)v;
+            n0 += __popcll(mk);
+          }
+          int nb = n0;
+          for (int base = 0; base < m; base += 64) {
+            const int v = base + lane;
+            bool act = false;
+            if (v < m) { const int sv = seg[v]; act = sv != s0 && (ssz[sv] >= 2) && (thr[sv] < thr0); }
+            const unsigned long long mk = __ballot(act);
+            if (act) alist[nb + __popcll(mk & lt_mask)] = (uint16_t)v;
+            nb += __popcll(mk);
+          }
+          if (lane == 0) { s_i[S_NACT] = nb; s_i[S_NQ] = n0; }
+        }
+        __syncthreads();
+        const int nb = s_i[S_NACT], n0 = s_i[S_NQ];
+        {
+          // the voxel's segment changes only through an edge of its own heavier than its threshold (localcut_dense.hpp)
+          const float Lb = thr[s0];
+          const int no = nb - n0;
+          bool hit = false;
+          for (int i2 = tid; i2 < n0 * no; i2 += TB) {
+            const int x = alist[i2 / no], y = alist[n0 + i2 % no];
+            const int a = x < y ? x : y, b = x < y ? y : x;
+            ++my_pairs;
+            if (!(vm_weight_bound_da(R(a), R(b), W) <= Lb)) {
+              const float w = vm_pair_weight(R(a), R(b), W);
+              hit = hit || (w > Lb && w <= thr0);
+            }
+          }
+          if (hit) s_i[S_FLAG] = 2;
+          __syncthreads();
+        }
+        if (s_i[S_FLAG] == 2) {
+          const uint32_t Pb = (uint32_t)(nb * (nb - 1) / 2);
+          for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
+            int ia, ib;
+            decode(p, nb, Pb, ia, ib);
+            const int xa = alist[ia], xb = alist[ib];
+            const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;   // the list is not in vertex order
+            if (seg[a] != seg[b]) {
+              const float w = vm_pair_weight(R(a), R(b), W);
+              ++my_pairs;
+              if (w <= thr0) {   // heavier edges were examined in phase A; NaN compares false
+                const int at = atomicAdd(&s_i[S_CNT], 1);
+                if (at < LCAP) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - (((uint32_t)a << PSH) | (uint32_t)b));
+              }
+            }
+          }
+          __syncthreads();
+          const int nlB = s_i[S_CNT];
+          if (nlB > LCAP) { hand_on(); return; }   // the banded phase B of the dense kernel is behind the fallback list
+          sort_list(nlB);
+          merge_list(nlB, -1.0f);
+          PGP_CNT(13, 1);
+        }
+        PGP_ACC(6);
+      }
+    }
+    // ---- result: the segment of the voxel itself, the whole row (nobody zeroes the table first) ----
+    {
+      const int s0 = seg[0];
+      for (int c = tid; c < m; c += TB) crow[c] = (seg[c] == s0) ? 1 : 0;
+      if (cbits) {
+        // ... and as one bit per ball offset for crossValidation's lattice lookup (localcut_wave.hpp writes the same row): the edge
+        // list's LDS is free now
+        uint32_t* const cb = (uint32_t*)lk;
+        __syncthreads();
+        for (int k = tid; k < cb_words; k += TB) cb[k] = 0u;
+        __syncthreads();
+        for (int c = tid; c < m; c += TB)
+          if (seg[c] == s0) { const uint32_t bi = vgs_cb_index(orow[c], cb_R); atomicOr(&cb[bi >> 5], 1u << (bi & 31u)); }
+        __syncthreads();
+        uint32_t* const outb = cbits + (size_t)u * (size_t)cb_words;
+        for (int k = tid; k < cb_words; k += TB) outb[k] = cb[k];
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
+    if (tid == 0) evals_out[u] = 0;
+    __syncthreads();
+    if (lane == 0 && my_pairs) atomicAdd(&evals_out[u], my_pairs);
+    PGP_CNT(14, 1);
+    PGP_ACC(7);
+  };   // process
+
+  // Either hand-over lists (largest neighbourhoods first, work_stride apart, their lengths on the device: a fixed grid strides over
+  // them) or a class of its own (one list, its length known to the host; workgroup b runs on XCD b % 8 and every XCD takes one
+  // contiguous eighth of the list, so that neighbouring voxels share their L2)
+  const unsigned int xcd_total = (((n_work_host + 7u) >> 3) << 3), per_xcd = (n_work_host + 7u) >> 3;
+  for (unsigned int wi = blockIdx.x;; wi += gridDim.x) {
+    uint32_t u = 0;
+    if (n_work_dev) {
+      unsigned int wpos = wi;
+      int wbin = 0;
+      while (wbin < n_lists && wpos >= n_work_dev[wbin]) { wpos -= n_work_dev[wbin]; ++wbin; }
+      if (wbin == n_lists) break;
+      u = work[(size_t)wbin * work_stride + wpos];
+    } else {
+      if (wi >= xcd_total) break;
+      const unsigned int it = xcd_order ? (wi & 7u) * per_xcd + (wi >> 3) : wi;
+      if (it >= n_work_host || (xcd_order && (wi >> 3) >= per_xcd)) continue;
+      u = work[it];
+    }
+    process((uint32_t)__builtin_amdgcn_readfirstlane((int)u));
+    ++n_cut;
+    __syncthreads();   // the next voxel reuses every array
+  }
+  if (tid == 0 && n_cut) atomicAdd(&counters[63], (unsigned long long)n_cut);
+}
+
+#endif

@@ -81,6 +81,11 @@
 #define LW_MASTER_ROT 0
 #endif
 
+// hand-over marks of the one-wavefront classes: pending[u] = 1 + list + LW_HO_BINS * why; k_ho_lists counts the reasons into these words
+#define LW_PENDING_LISTED 0xff   // pending[u] of a voxel that is already in a hand-over list (k_ho_lists leaves it alone)
+#define LW_HO_VOTE 0x100
+#define LW_VOTE_BASE 64    // counter words 64 .. 127
+enum { LW_WHY_GAVE_UP = 0, LW_WHY_VOTED, LW_WHY_SIZE, LW_N_WHY };   // (one reason for every way the lazy schedule gives a voxel up: the kernel has no register to spare for more)
 struct LwParams {
   LcParams lc;
   float r2_graph;   // graph_size^2: scale of the first shell
@@ -94,8 +99,16 @@ struct LwParams {
   NearLists near;   // per-voxel lists of the heavy pairs within two lattice steps (nearlist.hpp): the first shell walks them
   uint8_t* pending; // per used voxel: set when the voxel is handed over (its connect row is final only after the hand-over kernel)
   int near_min_own; // multi-wavefront classes: first shells from the near-pair lists only if the vertices' lists hold this many entries on average
-  int ho_bins;      // one-wavefront classes: hand-over lists by neighbourhood size (LW_HO_BINS, largest first) or 1
+  // One-wavefront classes, bit LW_HO_VOTE of ho_bins: is the lazy schedule worth trying on this scene at all?  Every sixteenth voxel of
+  // these classes is a SAMPLE: it runs in an instantiation of its own (SAMPLED, launched beside the others), always tries, and books how it
+  // ended -- finished / gave the voxel up -- in one of 64 counter words (LW_VOTE_BASE; low / high half).  The others read one of the words
+  // when they start and, once seven of eight samples gave up, hand their voxel over without trying.  Under centimetres of range noise
+  // 98 % of the voxels work through their shells only to be handed over; the hand-over kernel reads pair lists and does not care.
+  // Scheduling only: both paths give the same connect list.  (The bookkeeping is in an instantiation of its own because the kernel has
+  // no register to spare: two more scalars alive to its end cost the bulk launch four spilled vector registers.)
+  int ho_bins;      // one-wavefront classes: hand-over lists by neighbourhood size (LW_HO_BINS, largest first) or 1; | LW_HO_VOTE
   int ho_stride;    // distance between those lists in the hand-over array (= the number of used voxels)
+                    // (one-wavefront classes with ho_bins > 1: a hand-over only marks pending[u] = 1 + list + LW_HO_BINS * why and k_ho_lists builds the lists)
   // the connect list once more as a bit per ball offset, for crossValidation's lattice lookup (vgs_context.hpp: conn_bits); null: off
   uint32_t* cbits;
   int cb_R;
@@ -123,7 +136,7 @@ __device__ __forceinline__ float lw_readlane_f(float x, int l) {
 // order-free sections -- pair enumeration, weight evaluation, sort -- take their share, and wait again.  The merge and
 // the bookkeeping between shells stay on wavefront 0.  Candidates are then appended through an LDS counter, so their
 // order in the list depends on timing; the sort that follows removes that (keys are unique).
-template <int MAXM, int LCAP, int NW = 1>
+template <int MAXM, int LCAP, int NW = 1, bool SAMPLED = false>
 __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM == 320 ? LW_WAVES_C0 : 4) : 2)) void k_localcut_wave(const uint32_t* __restrict__ work_first, int n_first,
                                                       const uint32_t* __restrict__ work, int n_work,
                                                       const unsigned int* __restrict__ n_work_dev,
@@ -226,6 +239,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
   const float cut = P.lc.cut;
   const VgsWeightParams& W = P.lc.W;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  auto diag = [&](int word) {   // lane 0 calls
+    if constexpr (SMALL && NW == 1) { if ((P.ho_bins & 0xff) > 1) return; }   // (k_ho_lists counts the marks: no same-address atomics from a hundred thousand voxels)
+    atomicAdd(&counters[word], 1ull);
+  };
 #ifdef VGS_PROF
   unsigned long long prof[16] = {0};
 #endif
@@ -239,11 +256,25 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
   const int m = n;
   if (m > MAXM || (P.dbg_max_m > 0 && m > P.dbg_max_m)) {  // beyond this kernel's arrays: hand over to the general kernel
     if (threadIdx.x == 0) {
-      const int bin = (SMALL && NW == 1 && P.ho_bins > 1) ? lw_ho_bin(m) : 0;
-      fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u;
-      P.pending[u] = 1;
+      const int bin = (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) ? lw_ho_bin(m) : 0;
+      if (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) P.pending[u] = (uint8_t)(1 + bin + LW_HO_BINS * LW_WHY_SIZE);
+      else { fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u; P.pending[u] = LW_PENDING_LISTED; }
     }
     return;
+  }
+  if constexpr (SMALL && NW == 1) {
+    if (!SAMPLED && (P.ho_bins & LW_HO_VOTE) != 0 && m >= 2) {
+      // the scene's samples (see LwParams::ho_bins): a scalar load that bypasses the scalar cache, which does not see the samples'
+      // atomics -- no vector register is held for it, and the wavefront that hands over leaves here
+      unsigned long long vote_word;
+      const unsigned long long* vp = counters + LW_VOTE_BASE + (blockIdx.x & 63u);
+      asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(vote_word) : "s"(vp) : "memory");
+      const uint32_t fin = (uint32_t)vote_word, gave = (uint32_t)(vote_word >> 32);
+      if ((fin + gave >= 8u) && (gave * 8u >= (fin + gave) * 7u)) {
+        if (lane == 0) P.pending[u] = (uint8_t)(1 + lw_ho_bin(m) + LW_HO_BINS * LW_WHY_VOTED);
+        return;
+      }
+    }
   }
   const float thr0 = vm_cut_threshold(1.0f, cut, 1);  // a singleton's threshold: seg_int = 1 (VS:1918)
   // cut / size, looked up across lanes.  (A table in LDS instead -- one read where the cross-lane lookup costs two ds_bpermute -- was
@@ -344,7 +375,6 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
   unsigned int n_evals = 0;   // pair evaluations of this voxel (wave-uniform)
   int merges = 0;
   bool bail = false;
-
   // Descending sort of the edge list [0, cnt): the bitonic network in its one-direction form (each merge starts with a
   // mirror step, every comparator puts the larger key at the lower index).  Slots >= cnt then act as keys below every
   // real one that never move, so cnt need not be a power of two and nothing is padded.
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       // passes hand it to the workgroup-per-voxel kernel, which holds 8192 edges and evaluates every pair once
       // (examining all remaining pairs in this kernel and keeping the survivors only was tried: the neighbourhoods that
       // get here hold more edges above thr0 than the list, or overflow it in phase B, and are handed over anyway)
-      if (++rounds > (MAXM > 128 ? 14 : P.max_rounds)) { if (lane == 0) atomicAdd(&counters[3], 1ull); bail = true; break; }
+      if (++rounds > (MAXM > 128 ? 14 : P.max_rounds)) { if (lane == 0) diag(3); bail = true; break; }
       // ---- 1. enumerate the pairs of this shell ----
       const int free_slots = LCAP - n_list;
       const bool use_minor = (big >= 0) && (2 * n_min < n_act);
@@ -943,10 +973,10 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       LW_CNT(8, 1);  // rounds
       if (count > free_slots) {
         // the shell holds more pairs than the list: shrink it (assume uniform density in d2) and redo
-        if (++shrink > 24 || free_slots < 32) { if (lane == 0) atomicAdd(&counters[free_slots < 32 ? 4 : 3], 1ull); bail = true; break; }
+        if (++shrink > 24 || free_slots < 32) { if (lane == 0) diag(free_slots < 32 ? 4 : 3); bail = true; break; }
         const float hi = final_round ? P.d2_all : cut_hi;
         cut_hi = cut_lo + (hi - cut_lo) * (0.75f * (float)free_slots / (float)count);
-        if (!(cut_hi > cut_lo)) { if (lane == 0) atomicAdd(&counters[5], 1ull); bail = true; break; }
+        if (!(cut_hi > cut_lo)) { if (lane == 0) diag(5); bail = true; break; }
         continue;
       }
       shrink = 0;
@@ -1114,7 +1144,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
           qq += 64;
         }
         if (count > LCAP) {
-          if (lane == 0) atomicAdd(&counters[6], 1ull);
+          if (lane == 0) diag(6);
           bail = true;
         } else {
           wave_sync();
@@ -1127,9 +1157,13 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
   }
   if (bail) {
     if (lane == 0) {
-      const int bin = (SMALL && NW == 1 && P.ho_bins > 1) ? lw_ho_bin(m) : 0;
-      fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u;
-      P.pending[u] = 1;
+      const int bin = (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) ? lw_ho_bin(m) : 0;
+      // One-wavefront classes: only the mark; k_ho_lists builds the hand-over lists from the marks afterwards.  (Appending here is one
+      // RETURNING atomic on one of four addresses per handed-over voxel: on a noisy scene 130 k of them serialise at ~30 ns each and
+      // the launch cannot end before they have -- 4 ms, whatever the wavefronts do.)
+      if (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) P.pending[u] = (uint8_t)(1 + bin);
+      else { fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u; P.pending[u] = LW_PENDING_LISTED; }
+      if constexpr (SAMPLED) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & 63u)], 1ull << 32);   // a sample that gave up
     }
     return;
   }
@@ -1156,6 +1190,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
     }
   }
   if (lane == 0) evals_out[u] = n_evals;  // summed on the host on request: no same-address atomics on the hot path
+  if constexpr (SAMPLED) { if (lane == 0 && m >= 2) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & 63u)], 1ull); }   // a sample that finished
 #ifdef VGS_PROF
   if (lane == 0 && dbg_out) { long long tnow = clock64(); dbg_out[4 * (size_t)u + 0] = (uint32_t)m; dbg_out[4 * (size_t)u + 1] = (uint32_t)prof[8]; dbg_out[4 * (size_t)u + 2] = (uint32_t)((tnow - t_start) >> 4); dbg_out[4 * (size_t)u + 3] = (uint32_t)n_evals; }
   if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }

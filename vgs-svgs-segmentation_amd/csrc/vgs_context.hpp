@@ -18,6 +18,7 @@
 
 #include "../../include/vgs.h"
 #include "vgs_math.h"
+#include "pairlist.hpp"
 
 typedef VgsNode NodeRec;
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be 64 bytes");
@@ -95,6 +96,11 @@ struct VgsKnobs {
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
+  bool no_pairlists = false; // VGS_NO_PAIRLISTS: no pair lists (pairlist.hpp); hand-overs and wide classes take the kernels of round 4
+  bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
+  int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
+  int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
+  int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
   bool debug = false;        // VGS_DEBUG
 };
 
@@ -193,6 +199,15 @@ struct vgs_ctx {
   bool nl_enabled = false;
   int nl_reach_steps = 0;     // lattice steps up to which the lists are complete (nearlist.hip)
   bool nl_direct = false;     // the ball fits the direct offset map of the one-wavefront classes
+
+  // pair lists (pairlist.hip): every heavy pair inside a voxel's ball, built on demand for the rows k_localcut_pg reads
+  DevBuf<uint8_t> pl_state;    // [V] index (uint2: first entry, count) | [V] wanted marks | [V] "part of a heavy pair" flags: one fill resets all three
+  DevBuf<float4> pl_ent;       // the pool of entries
+  DevBuf<uint32_t> pl_work;    // work list of rows, redo list
+  bool pl_enabled = false;
+  bool pl_enabled_at_launch = false;   // this run queued the pair-list chain for its hand-overs (stream4 joins stream3 before the stage's last event)
+  hipEvent_t ev_ho = nullptr, ev_ho2 = nullptr;   // hand-over lists built / pair-list chain done
+  float pl_w_ring = 0.0f;      // PairLists::w_ring of this run
 
   // local cut / merge
   DevBuf<uint8_t> conn;
@@ -324,6 +339,10 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
                              int64_t n_ids = 0);
 bool vgs_unused_are_inert(const vgs_params& p);
 vgs_status vgs_stage_nearlists(vgs_ctx* c);   // part of the local-cut stage
+vgs_status vgs_pairlists_begin(vgs_ctx* c, hipStream_t strm);   // pairlist.hip, part of the local-cut stage
+vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* const* ids, const unsigned int* const* n_dev, const unsigned int* n_host,
+                               int n_lists, bool all_rows, const float* ctab, float ctab_scale, float d2_stop, int slot, const LcGate& gate,
+                               bool big_rows_too);
 vgs_status vgs_stage_localcut(vgs_ctx* c);   // launches everything; its hand-over kernels may still run when it returns
 vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred);  // waits for them, checks the stage's flags (called by the merge stage)
 vgs_status vgs_stage_merge(vgs_ctx* c);
