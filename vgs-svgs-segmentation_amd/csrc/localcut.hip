@@ -509,7 +509,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 #endif
 #define DN_SMALL 128, LD_SMALL_LCAP, 2048, 256   // hand-overs of the one-wavefront classes
 #define DN_LARGE 512, 4096, 2048, 512   // hand-overs of classes C and D up to 512 neighbours
-#define PG_SMALL 128, 2048, 4, 5, true   // the pair-list kernel for the hand-overs of the one-wavefront classes
+#ifndef PG_SMALL_OCC
+#define PG_SMALL_OCC 5
+#endif
+#define PG_SMALL 128, 2048, 4, PG_SMALL_OCC, true   // the pair-list kernel for the hand-overs of the one-wavefront classes
 
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
@@ -543,9 +546,10 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
 // The hand-over lists of the one-wavefront classes, built from the marks their kernels left (pending[u] = 1 + list + LW_HO_BINS * why,
 // localcut_wave.hpp): voxel order, one atomic per list and 1024 voxels; the reasons are counted into the schedule counters on the way.
 // The marks become plain "pending" flags for the merge stage.
-__global__ __launch_bounds__(1024) void k_ho_lists(uint8_t* __restrict__ pending, int64_t U, uint32_t* __restrict__ ids, int64_t stride,
-                                                   unsigned int* __restrict__ n_lists, unsigned long long* __restrict__ counters) {
-  __shared__ unsigned int s_cnt[16][LW_HO_BINS];
+__global__ __launch_bounds__(256) void k_ho_lists(uint8_t* __restrict__ pending, int64_t U, uint32_t* __restrict__ ids, int64_t stride,
+                                                   unsigned int* __restrict__ n_lists, unsigned long long* __restrict__ counters,
+                                                   unsigned int* __restrict__ gate /* [0] the word of LcGate, [1] ticket */, unsigned int many) {
+  __shared__ unsigned int s_cnt[4][LW_HO_BINS];
   __shared__ unsigned int s_base[LW_HO_BINS];
   __shared__ unsigned int s_why[LW_N_WHY];
   if (threadIdx.x < LW_N_WHY) s_why[threadIdx.x] = 0u;
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(1024) void k_ho_lists(uint8_t* __restrict__ pending
   if (threadIdx.x < LW_HO_BINS) {
     const int k = threadIdx.x;
     unsigned int tot = 0;
-    for (int w = 0; w < 16; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
+    for (int w = 0; w < 4; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
     s_base[k] = tot ? atomicAdd(&n_lists[k], tot) : 0u;
   }
   __syncthreads();
@@ -574,6 +578,15 @@ __global__ __launch_bounds__(1024) void k_ho_lists(uint8_t* __restrict__ pending
   if (threadIdx.x < LW_N_WHY && s_why[threadIdx.x] != 0u) {
     const int word[LW_N_WHY] = {3, 62, -1};   // the lazy schedule gave the voxel up (whatever the reason), voted over, (size: not counted)
     if (word[threadIdx.x] >= 0) atomicAdd(&counters[word[threadIdx.x]], (unsigned long long)s_why[threadIdx.x]);
+  }
+  // the last workgroup through sees every list complete and says which way the hand-overs go (LcGate)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&gate[1], 1u) == gridDim.x - 1u) {
+    __threadfence();
+    unsigned int tot = 0;
+    for (int k = 0; k < LW_HO_BINS; ++k) tot += __hip_atomic_load(&n_lists[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&gate[0], tot > many ? LC_MANY : LC_FEW, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -754,6 +767,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_nf = (unsigned int*)(c->counters.p + 14);        // lengths of the LW_HO_BINS lists (words 14-15)
   unsigned int* d_ng = (unsigned int*)(c->counters.p + 11) + 1;    // word 11, upper half
   unsigned int* d_nf2 = (unsigned int*)(c->counters.p + 12);       // sent on by the dense kernels: word 12, small | large
+  unsigned int* d_gate = (unsigned int*)(c->counters.p + 57);      // LcGate's word (low half) and k_ho_lists' ticket (high half)
   unsigned int* d_ng2 = d_nf2 + 1;
   uint32_t* ids_g2 = c->work_ids.p + 4 * U;   // sent on by the large dense kernel
   static_assert(LW_HO_BINS == 4, "four 32-bit list lengths in counter words 14-15");
@@ -943,7 +957,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       if (!dense) st = launch_block(c->stream2, ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
       else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
         hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(ncd < 4 * GRID_G ? ncd : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
-                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0, 0u, 0});
+                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u});
     }
     if (st != VGS_OK) return st;
   }
@@ -985,7 +999,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
     if (dense && nab > 0)
-      hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt);
+      hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt, d_gate,
+                         (c->pl_enabled && c->K.pg_min_frac > 0) ? (unsigned int)(U / c->K.pg_min_frac) : 0xffffffffu);
     vgs_status st = VGS_OK;
     if (!dense) {
       st = launch_block(c->stream3, ids_f, grid_f, true, d_nf, 0);
@@ -997,8 +1012,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       // every neighbourhood wants all of its heavy pairs): the rows are built, every heavy pair ONCE instead of once per neighbourhood,
       // and one workgroup per voxel reads them in bands of descending weight (localcut_pg.hpp).  What either cannot take goes on to the
       // general kernel through the same list.
-      const unsigned int many = c->K.pg_min_frac > 0 ? (unsigned int)(U / c->K.pg_min_frac) : 0xffffffffu;
-      const LcGate g_few = {d_nf, LW_HO_BINS, many, 0}, g_many = {d_nf, LW_HO_BINS, many, 1};
+      const LcGate g_few = {d_gate, LC_FEW}, g_many = {d_gate, LC_MANY};
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few);
       // (the pair-list chain on a stream of its own: when it is not wanted its four empty launches end beside the dense kernel, not behind it)
@@ -1006,7 +1020,9 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho, 0));
       const uint32_t* ids4[LW_HO_BINS]; const unsigned int* nd4[LW_HO_BINS];
       for (int k = 0; k < LW_HO_BINS; ++k) { ids4[k] = ids_f + (size_t)k * U; nd4[k] = d_nf + k; }
-      st = vgs_pairlists_build(c, c->stream4, ids4, nd4, nullptr, LW_HO_BINS, false, LP.ctab, LP.ctab_scale, LP.d2_stop, 1, g_many, false);
+      // (many hand-overs: their neighbourhoods cover practically every row, so every row is built -- marking the wanted ones is 15 M
+      // scattered byte stores, a millisecond on the noisy surface)
+      st = vgs_pairlists_build(c, c->stream4, ids4, nd4, nullptr, LW_HO_BINS, true, LP.ctab, LP.ctab_scale, LP.d2_stop, 1, g_many, false);
       if (st == VGS_OK && c->pl_enabled) {
         const PairLists PLs = {(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring};
         const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
@@ -1019,7 +1035,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       }
     } else if (grid_f > 0) {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, LcGate{nullptr, 0, 0u, 0});
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, LcGate{nullptr, 0u});
     }
     if (st != VGS_OK) return st;
     if (grid_f > 0 && dense && c->pl_enabled_at_launch) {   // stream3 ends when both chains have
@@ -1040,6 +1056,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                          c->cb_R, c->cb_words, c->conn_bits.p, CbLists{}, 0);
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
+  c->lc_tail.gated = false;
+  // crossValidation's first pass looks at the word k_ho_lists writes (merge.hip) WITHOUT waiting for it: a workgroup that finds it still
+  // undecided goes ahead as for LC_FEW, and should the word turn out LC_MANY the full pass that follows redoes whatever it did
+  if (c->pl_enabled_at_launch) c->lc_tail.gated = true;
   c->lc_tail.grid_f = grid_f;
   for (int k = 0; k < 5; ++k) c->lc_tail.nabc[k] = nabc[k];
   c->lc_tail.nabc[2] += nabc[5];
@@ -1104,6 +1124,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   unsigned long long hc[64] = {0};   // (words 58-63: the pair lists' pool and the pair-list kernel's counts)
   VGS_READBACK(c, hc, cnt, sizeof(hc));
   const unsigned long long lc_why[4] = {hc[3], hc[4], hc[5], hc[6]};   // (the first words of hc are read again behind the kernels launched below)
+  c->lc_tail.many = c->lc_tail.gated && (unsigned int)(hc[57] & 0xffffffffull) == LC_MANY;
   c->lc_diag[9] = (int64_t)hc[63]; c->lc_diag[10] = (int64_t)(hc[58] & 0xffffffffull); c->lc_diag[11] = (int64_t)hc[62]; c->lc_diag[12] = (int64_t)hc[60];
   const unsigned long long* h = hc;
   // hand-overs of the one-wavefront classes (all size lists together), of classes C/D

@@ -25,11 +25,23 @@
 
 #include "pairlist.hpp"
 
+#ifndef PG_PF
+#define PG_PF 2   // (4: five spilled registers at 96)
+#endif
 struct PgGeom {   // what the in-ball test of the ring stage needs: the voxel lattice as adjacency.hip sees it
   const uint64_t* vox_code;
   float res_f, min_x, min_y, min_z;
   float r2;       // float(graph_size^2): the FLANN predicate's right-hand side
 };
+
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global store and load of the
+// wavefront (vmcnt(0)): behind the row's stores or the list entries' loads that is a memory round trip per barrier, and this
+// kernel's barriers all publish LDS data (what comes from memory is waited for where it is used).
+__device__ __forceinline__ void pg_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 #ifdef VGS_PROF
 __device__ unsigned long long g_pg_prof[24];
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
   __shared__ float ctab3[3][32];              // voxel centres along each axis, offsets -16 .. 15 from the voxel (adjacency.hip's table)
   __shared__ int s_i[8];
   __shared__ unsigned int s_L;
-  enum { S_CNT = 0, S_NACT, S_BAD, S_POS, S_MERGES, S_NQ, S_FLAG };
+  enum { S_CNT = 0, S_NACT, S_BAD, S_POS, S_MERGES, S_NQ, S_FLAG, S_PAIRS };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (!lc_gate_open(gate)) return;
@@ -104,8 +116,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     static_assert(sizeof(uint64_t) * LCAP >= 4 * 1024, "the bit row (<= 31^3 offsets) fits the edge list");
     // ---- the neighbourhood: lists, offsets, hash, segment state ----
     for (int k = tid; k < HCAP; k += TB) htab[k] = 0u;
-    if (tid == 0) { s_i[S_BAD] = 0; s_i[S_MERGES] = 0; }
-    __syncthreads();
+    if (tid == 0) { s_i[S_BAD] = 0; s_i[S_MERGES] = 0; s_i[S_PAIRS] = 0; }
+    pg_barrier();
     {
       bool bad = false;
       for (int c = tid; c < m; c += TB) {
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
       const uint32_t key = vm_compact21(code >> (2 - a)) + (uint32_t)(k - 16);
       ctab3[a][k] = vm_voxel_center(key, G.res_f, a == 0 ? G.min_x : (a == 1 ? G.min_y : G.min_z));
     }
-    __syncthreads();
+    pg_barrier();
     if (s_i[S_BAD]) { hand_on(); return; }
     unsigned int my_pairs = 0;
     bool done = m < 2 || PL.any[(uint32_t)row[0]] != 1;   // no heavy pair holds the voxel: it stays alone (uniform)
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         }
         if (lane == 0) { s_i[S_POS] = pos; s_i[S_MERGES] = merges; }
       }
-      __syncthreads();
+      pg_barrier();
     };
     auto sort_list = [&](int cnt) __attribute__((always_inline)) {
-      regsort::sort_desc_block<NW>(lk, cnt, wave, lane, [&]() { __syncthreads(); });
+      regsort::sort_desc_block<NW>(lk, cnt, wave, lane, [&]() { pg_barrier(); });
     };
     // pair p of the row-major triangle over nv vertices (a < b), decoded from the end (localcut_wave.hpp: enum_section)
     auto decode = [&](uint32_t p, int nv, uint32_t Pn, int& a, int& b) {
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         ++bands;
         // ---- the vertices that still have unread entries and can still merge (fact F) ----
         if (tid == 0) { s_i[S_NACT] = 0; }
-        __syncthreads();
+        pg_barrier();
         for (int base = 0; base < m; base += TB) {
           const int v = base + tid;
           bool act = false;
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           b = __builtin_amdgcn_readfirstlane(b);
           if (act) alist[b + __popcll(mk & lt_mask)] = (uint16_t)v;
         }
-        __syncthreads();
+        pg_barrier();
         const int n_act = s_i[S_NACT];
         const float floor = ring_done ? thr0 : floor_ring;
         int free_slots = LCAP - n_carry;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         while (true) {   // (repeated with a smaller offer when the band overflows the list)
           const int q = 1 << lq;
           if (tid == 0) { s_L = vm_bits(floor); s_i[S_CNT] = 0; }
-          __syncthreads();
+          pg_barrier();
           // -- 1. L: the heaviest entry behind the offers --
           {
             uint32_t best = 0u;
@@ -273,21 +285,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)best, o, 64); best = x > best ? x : best; }
             if (lane == 0 && best != 0u) atomicMax(&s_L, best);
           }
-          __syncthreads();
+          pg_barrier();
           L = vm_from_bits(s_L);
           // -- 2. the offered entries heavier than L --
           const int items = n_act << lq;
-          for (int base = 0; base < items; base += TB) {
-            const int item = base + tid;
-            bool take = false, inr = false;
-            int v = 0;
-            uint32_t pid = 0;
-            float w = 0.0f;
-            if (item < items) {
-              v = alist[item >> lq];
-              const uint32_t g = lpos[v] + (uint32_t)(item & (q - 1));
-              if (g < lend[v]) {
-                const float4 E = PL.ent[g];
+          // PG_PF trips' entries are requested together: the loop waits for memory once per PG_PF trips, not once per trip
+          for (int base = 0; base < items; base += TB * PG_PF) {
+            float4 E4[PG_PF];
+            int v4[PG_PF];
+            bool has4[PG_PF];
+#pragma unroll
+            for (int k = 0; k < PG_PF; ++k) {
+              const int item = base + k * TB + tid;
+              has4[k] = item < items;
+              v4[k] = has4[k] ? (int)alist[item >> lq] : 0;
+              const uint32_t g = lpos[v4[k]] + (uint32_t)(item & (q - 1));
+              has4[k] = has4[k] && g < lend[v4[k]];
+              E4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (has4[k]) E4[k] = PL.ent[g];
+            }
+#pragma unroll
+            for (int k = 0; k < PG_PF; ++k) {
+              if (base + k * TB >= items) break;   // uniform
+              const int item = base + k * TB + tid;
+              const int v = v4[k];
+              const float4 E = E4[k];
+              bool take = false, inr = false;
+              uint32_t pid = 0;
+              float w = 0.0f;
+              if (has4[k]) {
                 take = (E.x > E.y ? E.x : E.y) > L;
                 if (take) {
                   const uint32_t la = hlat[v], of = __float_as_uint(E.z);
@@ -307,31 +333,31 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
                   }
                 }
               }
+              // an entry is consumed when it is heavier than L: a prefix of the vertex's offer (the offers of one vertex sit in one wavefront)
+              const unsigned long long tk = __ballot(take);
+              if (item < items && (item & (q - 1)) == 0) lcons[v] = (uint16_t)__popcll(tk & (((q == 64 ? 0ull : (1ull << q)) - 1ull) << (lane & 63)));
+              const unsigned long long mk = __ballot(inr);
+              int b = 0;
+              if (mk != 0ull && lane == 0) b = atomicAdd(&s_i[S_CNT], __popcll(mk));
+              b = __builtin_amdgcn_readfirstlane(b);
+              if (inr) { const int at = n_carry + b + __popcll(mk & lt_mask); if (at < LCAP) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid); }
             }
-            // an entry is consumed when it is heavier than L: a prefix of the vertex's offer (the offers of one vertex sit in one wavefront)
-            const unsigned long long tk = __ballot(take);
-            if (item < items && (item & (q - 1)) == 0) lcons[v] = (uint16_t)__popcll(tk & (((q == 64 ? 0ull : (1ull << q)) - 1ull) << (lane & 63)));
-            const unsigned long long mk = __ballot(inr);
-            int b = 0;
-            if (mk != 0ull && lane == 0) b = atomicAdd(&s_i[S_CNT], __popcll(mk));
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (inr) { const int at = n_carry + b + __popcll(mk & lt_mask); if (at < LCAP) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid); }
           }
-          __syncthreads();
+          pg_barrier();
           cnt = n_carry + s_i[S_CNT];
           if (cnt <= LCAP) break;
           if (lq == 0 || lq <= min_lq) { handed = true; break; }   // more edges than the list holds at one entry per vertex
           --lq;
-          __syncthreads();
+          pg_barrier();
         }
         if (handed) break;
         {
           bool any_c = false;
           for (int it = tid; it < n_act; it += TB) { const int v = alist[it]; const uint32_t cn = (uint32_t)lcons[v]; lpos[v] += cn; any_c = any_c || cn != 0u; }
           if (tid == 0) s_i[S_FLAG] = 0;
-          __syncthreads();
+          pg_barrier();
           if (any_c) s_i[S_FLAG] = 1;
-          __syncthreads();
+          pg_barrier();
           if (s_i[S_FLAG] == 0 && L > floor && n_act > 0) {   // uniform: nothing consumed although entries are left
             min_lq = lq + 1;
             if (min_lq > 6) { handed = true; break; }   // more than 64 equal keys in one list: degenerate ties
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           PGP_ACC(3);
         } else {
           if (tid == 0) s_i[S_POS] = 0;
-          __syncthreads();
+          pg_barrier();
         }
         const int pos = s_i[S_POS];
         lev = L;
@@ -381,7 +407,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             }
             if (lane == 0) s_i[S_POS] = kept;
           }
-          __syncthreads();
+          pg_barrier();
           n_carry = s_i[S_POS];
         }
         PGP_ACC(4);
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         ring_done = true;
         {
           if (tid == 0) { s_i[S_NACT] = 0; s_i[S_NQ] = 0; s_i[S_CNT] = 0; }
-          __syncthreads();
+          pg_barrier();
           for (int base = 0; base < m; base += TB) {
             const int v = base + tid;
             const bool act = v < m && thr[seg[v]] < lev;
@@ -401,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             b = __builtin_amdgcn_readfirstlane(b);
             if (act) alist[b + __popcll(mk & lt_mask)] = (uint16_t)v;
           }
-          __syncthreads();
+          pg_barrier();
           const int na = s_i[S_NACT];
           const uint32_t Pn = (uint32_t)(na * (na - 1) / 2);
           // the queue of screened pairs sits in the upper half of the edge list; edges grow behind the carried ones in the lower half
@@ -457,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
                 if (keep) { const int at = qb + __popcll(mk & lt_mask); if (at < QCAP) queue[at] = ((uint32_t)a << PSH) | (uint32_t)b; }
               }
             }
-            __syncthreads();
+            pg_barrier();
             const int nq = s_i[S_NQ];
             if (nq > QCAP) { over = true; break; }
             for (int e = tid; e < nq; e += TB) {
@@ -468,15 +494,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
                 if (at < LCAP / 2) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - pid);
               }
             }
-            __syncthreads();
+            pg_barrier();
             if (tid == 0) s_i[S_NQ] = 0;
             if (n_carry + s_i[S_CNT] > LCAP / 2) over = true;   // uniform: written before the barrier above
-            __syncthreads();
+            pg_barrier();
           }
           if (over) { handed = true; break; }
           n_carry += s_i[S_CNT];
           PGP_CNT(11, s_i[S_CNT]);
-          __syncthreads();
+          pg_barrier();
         }
         PGP_ACC(5);
       }
@@ -511,7 +537,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           }
           if (lane == 0) { s_i[S_NACT] = nb; s_i[S_NQ] = n0; }
         }
-        __syncthreads();
+        pg_barrier();
         const int nb = s_i[S_NACT], n0 = s_i[S_NQ];
         {
           // the voxel's segment changes only through an edge of its own heavier than its threshold (localcut_dense.hpp)
@@ -528,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             }
           }
           if (hit) s_i[S_FLAG] = 2;
-          __syncthreads();
+          pg_barrier();
         }
         if (s_i[S_FLAG] == 2) {
           const uint32_t Pb = (uint32_t)(nb * (nb - 1) / 2);
@@ -546,7 +572,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
               }
             }
           }
-          __syncthreads();
+          pg_barrier();
           const int nlB = s_i[S_CNT];
           if (nlB > LCAP) { hand_on(); return; }   // the banded phase B of the dense kernel is behind the fallback list
           sort_list(nlB);
@@ -564,20 +590,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         // ... and as one bit per ball offset for crossValidation's lattice lookup (localcut_wave.hpp writes the same row): the edge
         // list's LDS is free now
         uint32_t* const cb = (uint32_t*)lk;
-        __syncthreads();
+        pg_barrier();
         for (int k = tid; k < cb_words; k += TB) cb[k] = 0u;
-        __syncthreads();
+        pg_barrier();
         for (int c = tid; c < m; c += TB)
           if (seg[c] == s0) { const uint32_t bi = vgs_cb_index(orow[c], cb_R); atomicOr(&cb[bi >> 5], 1u << (bi & 31u)); }
-        __syncthreads();
+        pg_barrier();
         uint32_t* const outb = cbits + (size_t)u * (size_t)cb_words;
         for (int k = tid; k < cb_words; k += TB) outb[k] = cb[k];
       }
     }
     for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
-    if (tid == 0) evals_out[u] = 0;
-    __syncthreads();
-    if (lane == 0 && my_pairs) atomicAdd(&evals_out[u], my_pairs);
+    if (lane == 0 && my_pairs) atomicAdd(&s_i[S_PAIRS], (int)my_pairs);
+    pg_barrier();
+    if (tid == 0) evals_out[u] = (uint32_t)s_i[S_PAIRS];
     PGP_CNT(14, 1);
     PGP_ACC(7);
   };   // process
@@ -602,7 +628,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     }
     process((uint32_t)__builtin_amdgcn_readfirstlane((int)u));
     ++n_cut;
-    __syncthreads();   // the next voxel reuses every array
+    pg_barrier();   // the next voxel reuses every array
   }
   if (tid == 0 && n_cut) atomicAdd(&counters[63], (unsigned long long)n_cut);
 }

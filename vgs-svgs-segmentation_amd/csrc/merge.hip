@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
                                               unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work,
                                               const uint16_t* __restrict__ adj_off, int cb_R,
-                                              const uint32_t* __restrict__ cbits, int cb_words, uint8_t* __restrict__ defer_flag) {
+                                              const uint32_t* __restrict__ cbits, int cb_words, uint8_t* __restrict__ defer_flag, LcGate gate) {
+  if (!lc_gate_open_early(gate)) return;
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
   // (work != null): the rows put off.
@@ -289,7 +290,8 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                      const uint8_t* __restrict__ mutual, const int32_t* __restrict__ attach,
                                                      const uint8_t* __restrict__ owned, uint32_t* __restrict__ parent, int do_attach,
-                                                     const uint8_t* __restrict__ skip, const uint32_t* __restrict__ work, int n_work) {
+                                                     const uint8_t* __restrict__ skip, const uint32_t* __restrict__ work, int n_work, LcGate gate) {
+  if (!lc_gate_open_early(gate)) return;
   constexpr int W = 64 / UM_ROWS;
   // plain order: neighbouring voxels on one XCD at the same time contend for the same roots (measured slower)
   int64_t u = (int64_t)blockIdx.x * UM_ROWS + (threadIdx.x / W);
@@ -496,10 +498,14 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     const uint32_t* cb_bits = use_bits ? c->conn_bits.p : (const uint32_t*)nullptr;
     // crossValidation starts while the hand-over kernels of the local cut still run (vgs_stage_localcut): rows that touch a
     // handed-over voxel are put off, ...
+    // (When the hand-overs are MANY -- LcGate's word, written on the device by k_ho_lists -- this first pass would put off every row, one
+    // atomic each, and the unions behind it would find nothing final: both return at once, and the plain pass over all rows follows
+    // below, behind the hand-over kernels.)
+    const LcGate g_first = {(c->lc_tail.open && c->lc_tail.gated) ? (const unsigned int*)(c->counters.p + 57) : (const unsigned int*)nullptr, LC_FEW};
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                        c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0,
-                       cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr);
+                       cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr, g_first);
     if (early_union) {
       // The unions of the rows that are final go here, beside the hand-over kernels of the local cut (which leave most of the GPU
       // idle and end the critical path of the stage): pointer jumping over the first hooks, then every mutual edge of a row that
@@ -507,7 +513,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       // may have moved by then).
       hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
       hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0);
+                         c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0, g_first);
       compressed = true; united = true;
     }
     // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
@@ -516,13 +522,24 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       vgs_status sf = vgs_localcut_finish(c, &n_defer);
       if (sf != VGS_OK) return sf;
     }
+    if (c->lc_tail.many) {
+      // the first pass and its unions did not run (see above) -- or ran in part, for workgroups that started before the word was written:
+      // whatever they left (hooks, unions of rows whose flags nobody wrote this run) goes, and crossValidation takes every row now
+      hipLaunchKernelGGL(k_merge_init, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, c->csize.p, c->attach.p, c->cc_flags.p, c->csz.p, V);
+      hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+                         c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
+                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr,
+                         LcGate{nullptr, 0u});
+      compressed = false; united = false;
+      n_defer = 0;
+    }
     if (n_defer > 0) {
       hipLaunchKernelGGL(k_cross, dim3((n_defer + CX_ROWS - 1) / CX_ROWS), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->conn.p, mutual, c->csize.p, early_union ? (uint32_t*)nullptr : cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
-                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr);
+                         (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr, LcGate{nullptr, 0u});
       if (early_union)
         hipLaunchKernelGGL(k_union_mutual, dim3((n_defer + UM_ROWS - 1) / UM_ROWS), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                           c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, c->lc_defer.p, (int)n_defer);
+                           c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, c->lc_defer.p, (int)n_defer, LcGate{nullptr, 0u});
     }
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
@@ -559,7 +576,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
           vgs_status sb = vgs_readback_begin(c, d_chg4 + 3, 4);
           if (sb != VGS_OK) return sb;
           hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                             c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0);
+                             c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0, LcGate{nullptr, 0u});
           united = true;
           vgs_status se = vgs_readback_end(c, &ch, 4);
           if (se != VGS_OK) return se;
@@ -582,7 +599,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   if (U > 0 && !compressed) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
   if (U > 0 && !united)
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0);
+                       c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0, LcGate{nullptr, 0u});
   else if (U > 0 && n_cand > 0)
     hipLaunchKernelGGL(k_union_attach, dim3((n_cand + TB - 1) / TB), dim3(TB), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->attach.p, c->parent.p);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);

@@ -29,11 +29,23 @@ struct PlParams {
   float res_f, min_x, min_y, min_z, cube_tol;
 };
 
+#define PL_CHUNK_OF(cap) ((cap) <= 512 ? 1024u : 4u * (unsigned int)(cap))   // entries a workgroup takes from the pool at a time
+#define PL_GRID_SMALL 8192   // workgroups of the one-wavefront builders (they stride over the work list)
+#define PL_GRID_BIG 512
+
 // pool bookkeeping in the context's counter words (zeroed with the local cut's counters at the start of the stage)
 #define PL_W_CURSOR 58   // entries handed out
 #define PL_W_WORK 59     // length of the work list (low half), of the redo list (high half)
 #define PL_W_FULL 60     // rows that found the pool exhausted
 #define PL_W_WORK2 61    // the second build's work / redo list lengths
+
+// (barriers that order LDS traffic only: see pg_barrier in localcut_pg.hpp; one wavefront needs no s_barrier at all)
+template <int NWV>
+__device__ __forceinline__ void pl_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  if constexpr (NWV == 1) __builtin_amdgcn_wave_barrier(); else __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 template <int NWV, int CAP>
 __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restrict__ work, const unsigned int* __restrict__ n_work_dev, int n_work,
@@ -47,6 +59,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
   __shared__ uint64_t lk[CAP];        // sort keys of the kept pairs: bits of max(w1, w2) << 32 | ~(candidate index)
   __shared__ float wab[CAP], wba[CAP];
   __shared__ uint16_t c_slot[CAP];    // candidate -> position in the row
+  __shared__ uint32_t c_tid[CAP];     // candidate -> voxel id (the row is read once)
   __shared__ uint16_t s_cand[CAP];    // survivor of the screen -> candidate
   __shared__ float s_ctab[PL_TBINS];
   __shared__ int s_nc, s_ns, s_nk;
@@ -55,13 +68,14 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (tid < PL_TBINS) s_ctab[tid] = P.ctab[tid];
   const unsigned int n_items = n_work_dev ? *n_work_dev : (unsigned int)n_work;
+  unsigned int chunk_pos = 0u, chunk_end = 0u;   // this workgroup's piece of the pool (uniform)
   for (unsigned int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t u = work ? (int64_t)work[item] : (int64_t)item;
     const uint32_t vid = used_ids[u];
     const int n = (int)adj_cnt[u];
     const uint64_t* row = adj_key + u * adj_stride;
     const uint16_t* orow = adj_off + u * adj_stride;
-    __syncthreads();   // the previous row's arrays are free
+    pl_barrier<NWV>();   // the previous row's arrays are free
     if (tid == 0) { s_nc = 0; s_ns = 0; s_nk = 0; }
     const NodeRec& A = node[vid];
     bool usable = orow[0] != 0xffffu;
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
       if (tid == 0) idx[vid] = make_uint2(0u, PL_UNUSABLE);
       continue;
     }
-    __syncthreads();
+    pl_barrier<NWV>();
     // ---- 1. candidates: row entries at a positive lattice offset ----
     for (int base = 1; base < n; base += TB) {   // entry 0 is the voxel itself
       const int k = base + tid;
@@ -93,9 +107,9 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
       int b = 0;
       if (mk != 0ull && lane == 0) b = atomicAdd(&s_nc, __popcll(mk));
       b = __builtin_amdgcn_readfirstlane(b);
-      if (pos) { const int at = b + __popcll(mk & lt); if (at < CAP) c_slot[at] = (uint16_t)k; }
+      if (pos) { const int at = b + __popcll(mk & lt); if (at < CAP) { c_slot[at] = (uint16_t)k; c_tid[at] = (uint32_t)row[k]; } }
     }
-    __syncthreads();
+    pl_barrier<NWV>();
     const int nc = s_nc;
     if (nc > CAP) {   // uniform: a row this kernel's arrays cannot hold goes to the next larger instantiation, or has no list
       if (tid == 0) { if (redo) redo[atomicAdd(n_redo, 1u)] = (uint32_t)u; else idx[vid] = make_uint2(0u, PL_UNUSABLE); }
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
       const int q = base + tid;
       bool keep = false;
       if (q < nc) {
-        const NodeRec& B = node[(uint32_t)row[c_slot[q]]];
+        const NodeRec& B = node[c_tid[q]];
         const float dx = ax - B.c[0], dy = ay - B.c[1], dz = az - B.c[2];
         const float d2 = (dx * dx + dy * dy) + dz * dz;
         const uint32_t both = A.flags & B.flags;
@@ -128,16 +142,16 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
       b = __builtin_amdgcn_readfirstlane(b);
       if (keep) s_cand[b + __popcll(mk & lt)] = (uint16_t)q;
     }
-    __syncthreads();
+    pl_barrier<NWV>();
     const int ns = s_ns;
     // ---- 3. both orientations of the survivors' weights ----
     for (int e = tid; e < 2 * ns; e += TB) {
       const int q = s_cand[e >> 1];
-      const NodeRec& B = node[(uint32_t)row[c_slot[q]]];
+      const NodeRec& B = node[c_tid[q]];
       const float w = (e & 1) ? vm_pair_weight(B, A, P.W) : vm_pair_weight(A, B, P.W);
       if (e & 1) wba[q] = w; else wab[q] = w;
     }
-    __syncthreads();
+    pl_barrier<NWV>();
     // ---- 4. the heavy ones, sorted by their heavier orientation ----
     for (int base = 0; base < ns; base += TB) {
       const int s = base + tid;
@@ -160,7 +174,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
       b = __builtin_amdgcn_readfirstlane(b);
       if (heavy) lk[b + __popcll(mk & lt)] = key;
     }
-    __syncthreads();
+    pl_barrier<NWV>();
     const int nk = s_nk;
     if (nk > 1) {
       if constexpr (NWV == 1) {
@@ -171,20 +185,31 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
         else regsort::sort_desc<8>(lk, nk, lane);
         regsort::lds_fence();
       } else {
-        regsort::sort_desc_block<NWV>(lk, nk, wave, lane, [&]() { __syncthreads(); });
+        regsort::sort_desc_block<NWV>(lk, nk, wave, lane, [&]() { pl_barrier<NWV>(); });
       }
     }
-    if (tid == 0) s_base = nk ? atomicAdd(cursor, (unsigned int)nk) : 0u;
-    __syncthreads();
-    const unsigned int base_e = s_base;
-    if ((unsigned long long)base_e + (unsigned long long)nk > (unsigned long long)pool_cap) {   // uniform
+    // The pool is handed out in chunks of PL_CHUNK entries, one atomic per chunk: a workgroup fills its chunk row by row and takes
+    // a new one when the next row does not fit (what is left of the old one is lost: less than a row in PL_CHUNK).  One atomic per
+    // ROW was 133 k returning atomics on one address on the noisy surface -- they serialise at ~15 ns each and took two of the
+    // kernel's 2.0 ms.
+    constexpr unsigned int PL_CHUNK = PL_CHUNK_OF(CAP);
+    if (nk > 0 && chunk_pos + (unsigned int)nk > chunk_end) {   // uniform
+      if (tid == 0) s_base = atomicAdd(cursor, PL_CHUNK);
+      pl_barrier<NWV>();
+      chunk_pos = s_base;
+      chunk_end = s_base + PL_CHUNK;
+      pl_barrier<NWV>();
+    }
+    const unsigned int base_e = chunk_pos;
+    chunk_pos += (unsigned int)nk;
+    if (nk > 0 && (unsigned long long)chunk_end > (unsigned long long)pool_cap) {   // uniform: the chunk lies (partly) behind the pool's end
       if (tid == 0) { idx[vid] = make_uint2(0u, PL_UNUSABLE); atomicAdd(n_full, 1ull); }
       continue;
     }
     for (int r = tid; r < nk; r += TB) {
       const int q = (int)(0xffffffffu - (uint32_t)lk[r]);
       const int slot = c_slot[q];
-      const uint32_t t = (uint32_t)row[slot];
+      const uint32_t t = c_tid[q];
       ent[(size_t)base_e + (size_t)r] = make_float4(wab[q], wba[q], __uint_as_float((uint32_t)orow[slot]), __uint_as_float(t));
       any[t] = 1;
     }
@@ -271,7 +296,8 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
   uint32_t* const wl = c->pl_work.p + (slot ? 2 * (size_t)U : 0);
   // the pool: at most half of a row's entries are at positive offsets; never more than the 32-bit index of an entry can name
   {
-    const double want = (double)U * (double)((c->adj_stride - 1) / 2 + 1);
+    // (every builder workgroup may leave one chunk partly used)
+    const double want = (double)U * (double)((c->adj_stride - 1) / 2 + 1) + (double)PL_GRID_SMALL * PL_CHUNK_OF(512) + (double)PL_GRID_BIG * PL_CHUNK_OF(4096);
     const size_t cap = (size_t)(want < 4.0e9 ? want : 4.0e9);
     if (c->pl_ent.cap < cap) {
       size_t freeb = 0, totb = 0;
@@ -280,7 +306,7 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
       // the lists are a cache of weights: when the device cannot hold one for every ball offset the pool is what fits, and rows that
       // find it exhausted keep the paths of round 4 (counted in PL_W_FULL)
       if (take * sizeof(float4) > freeb / 2) take = freeb / 2 / sizeof(float4);
-      if (take < (size_t)U) { c->pl_enabled = false; return VGS_OK; }
+      if (take < (size_t)U + (size_t)PL_GRID_SMALL * PL_CHUNK_OF(512) + (size_t)PL_GRID_BIG * PL_CHUNK_OF(4096)) { c->pl_enabled = false; return VGS_OK; }
       if (c->pl_ent.cap < take) VGS_HIP_TRY(c, c->pl_ent.ensure(take));
     }
   }
@@ -308,14 +334,18 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
   P.cube_tol = PL_CUBE_TOL * c->P.voxel_size;
   unsigned long long* n_full = (unsigned long long*)(c->counters.p + PL_W_FULL);
   // rows of up to 1024 entries (512 at positive offsets) in a one-wavefront workgroup; longer ones are passed on to eight wavefronts
-  const unsigned int grid1 = (unsigned int)std::min<int64_t>(U, 16384);
+  const unsigned int grid1 = (unsigned int)std::min<int64_t>(U, PL_GRID_SMALL);
   // (big_rows_too false: rows with more than 512 candidates get no list and their neighbourhoods keep the kernels of round 4 -- the
   // hand-overs of the one-wavefront classes, whose vertices rarely have such rows, do not pay for the eight-wavefront launch)
   const bool big_rows = big_rows_too && (c->adj_stride - 1) / 2 > 512;
-  hipLaunchKernelGGL((k_pair_lists<1, 512>), dim3(grid1), dim3(64), 0, strm, wl, n_work, 0, c->used_ids.p, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
-                     c->adj_off.p, c->node.p, c->vox_code.p, P, idx, c->pl_ent.p, any, cursor, pool_cap, n_full, big_rows ? wl + U : (uint32_t*)nullptr, n_redo);
+  if ((c->adj_stride - 1) / 2 <= 272)   // (a ball of five voxels: 515 offsets, 257 of them positive -- half the LDS, twice the wavefronts per CU)
+    hipLaunchKernelGGL((k_pair_lists<1, 272>), dim3(grid1), dim3(64), 0, strm, wl, n_work, 0, c->used_ids.p, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+                       c->adj_off.p, c->node.p, c->vox_code.p, P, idx, c->pl_ent.p, any, cursor, pool_cap, n_full, (uint32_t*)nullptr, n_redo);
+  else
+    hipLaunchKernelGGL((k_pair_lists<1, 512>), dim3(grid1), dim3(64), 0, strm, wl, n_work, 0, c->used_ids.p, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
+                       c->adj_off.p, c->node.p, c->vox_code.p, P, idx, c->pl_ent.p, any, cursor, pool_cap, n_full, big_rows ? wl + U : (uint32_t*)nullptr, n_redo);
   if (big_rows)
-    hipLaunchKernelGGL((k_pair_lists<8, 4096>), dim3((unsigned int)std::min<int64_t>(U, 1024)), dim3(512), 0, strm, wl + U, n_redo, 0, c->used_ids.p, c->adj_key.p,
+    hipLaunchKernelGGL((k_pair_lists<8, 4096>), dim3((unsigned int)std::min<int64_t>(U, PL_GRID_BIG)), dim3(512), 0, strm, wl + U, n_redo, 0, c->used_ids.p, c->adj_key.p,
                        c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, c->vox_code.p, P, idx, c->pl_ent.p, any, cursor, pool_cap, n_full, (uint32_t*)nullptr,
                        (unsigned int*)nullptr);
   VGS_HIP_TRY(c, hipGetLastError());

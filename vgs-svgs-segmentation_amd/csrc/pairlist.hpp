@@ -42,17 +42,18 @@ struct PairLists {
   float w_ring;           // every pair of voxels NOT in each other's ball weighs at most this (+inf: no such bound)
 };
 
-// A launch that is queued before anybody knows whether it is wanted: it looks at hand-over list lengths on the device and returns
-// at once when their sum is on the wrong side of a threshold (few hand-overs: the dense kernel of localcut_dense.hpp evaluates their
-// pairs itself; many: the pair lists are built and k_localcut_pg reads them).  cnt == null: always open.
-struct LcGate { const unsigned int* cnt; int n; unsigned int thresh; int want_above; };
+// A launch that is queued before anybody knows whether it is wanted: it looks at ONE word on the device and returns at once when the
+// word does not hold the value it was queued for.  The word is written once per run by k_ho_lists (localcut.hip) when the hand-over lists
+// of the one-wavefront classes are complete: LC_FEW -- the dense kernel of localcut_dense.hpp evaluates the hand-overs' pairs itself and
+// crossValidation's first pass runs beside it; LC_MANY (more than 1 / pg_min_frac of the used voxels) -- the pair lists are built,
+// k_localcut_pg reads them, and crossValidation waits for them (its first pass would put off every row).  word == null: always open.
+#define LC_FEW 1u
+#define LC_MANY 2u
+struct LcGate { const unsigned int* word; unsigned int want; };
 #if defined(__HIPCC__)
-__device__ __forceinline__ bool lc_gate_open(const LcGate& g) {
-  if (!g.cnt) return true;
-  unsigned int s = 0;
-  for (int k = 0; k < g.n; ++k) s += g.cnt[k];
-  return (s > g.thresh) == (g.want_above != 0);
-}
+__device__ __forceinline__ bool lc_gate_open(const LcGate& g) { return g.word == nullptr || *g.word == g.want; }
+// ... for a launch that may run BEFORE the word is written and is harmless when it ran in vain (crossValidation's first pass): undecided counts as LC_FEW
+__device__ __forceinline__ bool lc_gate_open_early(const LcGate& g) { return g.word == nullptr || __hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != LC_MANY; }
 #endif
 
 #endif

@@ -217,7 +217,7 @@ struct vgs_ctx {
   DevBuf<uint8_t> lc_pending;
   DevBuf<uint8_t> lc_defer_flag;   // per row: the first pass of crossValidation put it off (written by every row of that pass)
   DevBuf<uint32_t> lc_defer;
-  struct { bool open = false; bool dense = true; unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
+  struct { bool open = false; bool dense = true; bool gated = false; /* merge's first pass looks at LcGate's word */ bool many = false; /* ... and found LC_MANY */ unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
   int64_t lc_diag[16] = {0};   // vgs_get_schedule_counters[_ex]
   DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
   float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;
