@@ -93,7 +93,8 @@ def test_case_reaches_the_class(run):
         # construction (localcut_pg.hpp); the slab's neighbourhoods above 512 go on to the general kernel
         assert sc["banded"] > 0 or sc["pair_list_cut"] > 0, sc
     if run["name"] == "slab_r10":
-        assert sc["dense_sent_on"] > 0 and sc["handed_over_large"] > 0, sc
+        # (round 5: the pair-list kernel takes neighbourhoods of up to 1024 voxels itself and has nothing to send on here)
+        assert (sc["dense_sent_on"] > 0 and sc["handed_over_large"] > 0) or sc["pair_list_cut"] > 100, sc
 
 
 @pytest.mark.parametrize("which", ["connect_cut", "connect_final"])

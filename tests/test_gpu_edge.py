@@ -152,12 +152,19 @@ def test_tables_that_cannot_fit_are_refused_with_an_estimate(gpu):
     assert c["adj"] > c["used"] and c["clusters"] >= c["used"], c
 
 
-def test_neighbourhoods_above_2048_voxels(gpu, oracle):
+_BLOCK_REF = {}
+
+
+@pytest.mark.parametrize("wide", ["pair_lists", "general_kernel"])
+def test_neighbourhoods_above_2048_voxels(gpu, oracle, monkeypatch, wide):
     """A solid block seen through a ball of eight voxels: 275 voxels have more than 2048 used neighbours.  The reference sizes its
     matrix to any n (voxel_segmentation.h:1815-1818, 1913-1933); until round 3 one such voxel ended the run with VGS_E_UNSUPPORTED.
-    Now they are cut by the extra-large instantiation of the general kernel: connect lists and labels identical to the oracle
-    (DevMath + lean; its local cuts on every core -- 1.2e10 pair weights)."""
+    Round 4 cut them with the extra-large instantiation of the general kernel (every pair weight again in every histogram round:
+    3 ms a voxel); round 5 cuts them from the pair lists (k_localcut_pg<4224, ...>: whole balls of up to ten voxels).  Both ways:
+    connect lists and labels identical to the oracle (DevMath + lean; its local cuts on every core -- 1.2e10 pair weights)."""
     import os
+    if wide == "general_kernel":
+        monkeypatch.setenv("VGS_PG_WIDE", "0")
     rng = np.random.default_rng(12)
     xyz = (rng.uniform(0, 1, (300_000, 3)) * 1.15 + np.array([1.0, -2.0, 0.2])).astype(np.float32)
     p = gpu.default_params(2, voxel_size=0.0625, graph_size=0.5)
@@ -166,8 +173,15 @@ def test_neighbourhoods_above_2048_voxels(gpu, oracle):
     eng.run()
     n = eng.adjacency_counts()
     sc = eng.schedule_counters()
-    assert n.max() > 2048 and sc["extra_large"] == int((n > 2048).sum()) and sc["outside_limits"] == 0, (n.max(), sc)
-    ref = oracle.run_vgs(xyz, oracle_params(oracle, p, threads=os.cpu_count() or 1))
+    n_xl = int((n > 2048).sum())
+    assert n.max() > 2048 and sc["outside_limits"] == 0, (n.max(), sc)
+    if wide == "general_kernel":
+        assert sc["extra_large"] == n_xl and sc["pair_list_cut"] == 0, sc
+    else:
+        assert sc["extra_large"] == 0 and sc["pair_list_cut"] >= n_xl, sc
+    if "ref" not in _BLOCK_REF:
+        _BLOCK_REF["ref"] = oracle.run_vgs(xyz, oracle_params(oracle, p, threads=os.cpu_count() or 1))
+    ref = _BLOCK_REF["ref"]
     for which in ("connect_cut", "connect_cross", "connect_final"):
         off, idx = eng.lists(which)
         roff, ridx = ref.lists(which)

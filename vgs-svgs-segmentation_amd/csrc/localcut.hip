@@ -47,6 +47,7 @@ struct LcParams {
   float ctab_scale;
   const float* ctab;   // LC_TBINS floats on the device
   int xl_from;         // tests (VGS_DBG_XL_FROM): a kernel with an overflow list passes neighbourhoods above this on (0: its own limit only)
+  int dbg_max_m;       // tests (VGS_DBG_MAXM): the pair-list kernel hands neighbourhoods above this on, as the shell classes do (0: its own limit only)
 };
 
 __device__ __forceinline__ int lc_bin1(float w) {
@@ -513,6 +514,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 #define PG_SMALL_OCC 5
 #endif
 #define PG_SMALL 128, 2048, 4, PG_SMALL_OCC, true   // the pair-list kernel for the hand-overs of the one-wavefront classes
+#define PG_C0 320, 2048, 4, 5, false            // ... for neighbourhoods of 129-320 voxels (29 KB of LDS: five workgroups per CU)
+#define PG_C 512, 2048, 4, 4, false             // ... of up to 512 (34 KB: four)
+#define PG_D 1024, 4096, 8, 4, false            // ... of up to 1024 (68 KB: two workgroups of eight wavefronts)
+#define PG_XL 4224, 2048, 4, 1, false, 21        // ... of whole balls of up to ten voxels (4189 offsets; 154 KB: one workgroup per CU)
 
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
@@ -547,43 +552,56 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
 // localcut_wave.hpp): voxel order, one atomic per list and 1024 voxels; the reasons are counted into the schedule counters on the way.
 // The marks become plain "pending" flags for the merge stage.
 __global__ __launch_bounds__(256) void k_ho_lists(uint8_t* __restrict__ pending, int64_t U, uint32_t* __restrict__ ids, int64_t stride,
-                                                   unsigned int* __restrict__ n_lists, unsigned long long* __restrict__ counters,
-                                                   unsigned int* __restrict__ gate /* [0] the word of LcGate, [1] ticket */, unsigned int many) {
-  __shared__ unsigned int s_cnt[4][LW_HO_BINS];
+                                                  unsigned int* __restrict__ n_lists, unsigned long long* __restrict__ counters,
+                                                  unsigned int* __restrict__ gate /* [0] the word of LcGate, [1] ticket */, unsigned int many) {
+  // a thread takes four consecutive voxels (one 32-bit load of their marks); slot k of the thread = voxel 4 * t + k
+  __shared__ unsigned int s_cnt[4][4][LW_HO_BINS];   // [wave][slot][list]: count, then offset inside the workgroup's piece of the list
   __shared__ unsigned int s_base[LW_HO_BINS];
   __shared__ unsigned int s_why[LW_N_WHY];
   if (threadIdx.x < LW_N_WHY) s_why[threadIdx.x] = 0u;
-  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int bin = -1, why = -1;
-  if (u < U) { const int p = (int)pending[u]; if (p != 0 && p != LW_PENDING_LISTED) { bin = (p - 1) % LW_HO_BINS; why = (p - 1) / LW_HO_BINS; pending[u] = LW_PENDING_LISTED; } }
-  unsigned long long mk[LW_HO_BINS];
-  for (int k = 0; k < LW_HO_BINS; ++k) {
-    mk[k] = __ballot(bin == k);
-    if (lane == 0) s_cnt[wave][k] = (unsigned int)__popcll(mk[k]);
+  uint32_t marks = 0u;
+  if (4 * t + 3 < U) marks = ((const uint32_t*)pending)[t];
+  else for (int k = 0; k < 4; ++k) if (4 * t + k < U) marks |= (uint32_t)pending[4 * t + k] << (8 * k);
+  int bin[4], why[4];
+  for (int k = 0; k < 4; ++k) {
+    const int p = (int)((marks >> (8 * k)) & 0xffu);
+    bin[k] = -1; why[k] = -1;
+    if (p != 0 && p != LW_PENDING_LISTED) { bin[k] = (p - 1) % LW_HO_BINS; why[k] = (p - 1) / LW_HO_BINS; }
+  }
+  // (byte stores, and only of the marks taken: the multi-wavefront classes may still be running and set their own voxels' bytes)
+  for (int k = 0; k < 4; ++k) if (bin[k] >= 0) pending[4 * t + k] = (uint8_t)LW_PENDING_LISTED;
+  __syncthreads();
+  unsigned long long mk[4][LW_HO_BINS];
+  for (int k = 0; k < 4; ++k)
+    for (int b = 0; b < LW_HO_BINS; ++b) {
+      mk[k][b] = __ballot(bin[k] == b);
+      if (lane == 0) s_cnt[wave][k][b] = (unsigned int)__popcll(mk[k][b]);
+    }
+  for (int y = 0; y < LW_N_WHY; ++y) {
+    unsigned int n = 0;
+    for (int k = 0; k < 4; ++k) n += (unsigned int)__popcll(__ballot(why[k] == y));
+    if (lane == 0 && n) atomicAdd(&s_why[y], n);
   }
   __syncthreads();
-  for (int k = 0; k < LW_N_WHY; ++k) {
-    const unsigned long long wk = __ballot(why == k);
-    if (lane == 0 && wk != 0ull) atomicAdd(&s_why[k], (unsigned int)__popcll(wk));
-  }
   if (threadIdx.x < LW_HO_BINS) {
-    const int k = threadIdx.x;
+    const int b = threadIdx.x;
     unsigned int tot = 0;
-    for (int w = 0; w < 4; ++w) { const unsigned int x = s_cnt[w][k]; s_cnt[w][k] = tot; tot += x; }
-    s_base[k] = tot ? atomicAdd(&n_lists[k], tot) : 0u;
+    for (int w = 0; w < 4; ++w) for (int k = 0; k < 4; ++k) { const unsigned int x = s_cnt[w][k][b]; s_cnt[w][k][b] = tot; tot += x; }
+    s_base[b] = tot ? atomicAdd(&n_lists[b], tot) : 0u;
   }
   __syncthreads();
-  if (bin >= 0) ids[(int64_t)bin * stride + s_base[bin] + s_cnt[wave][bin] + __popcll(mk[bin] & ((1ull << lane) - 1ull))] = (uint32_t)u;
+  // (inside a workgroup's piece the order is wave, slot, lane -- not quite voxel order: nobody depends on it)
+  for (int k = 0; k < 4; ++k)
+    if (bin[k] >= 0) ids[(int64_t)bin[k] * stride + s_base[bin[k]] + s_cnt[wave][k][bin[k]] + __popcll(mk[k][bin[k]] & ((1ull << lane) - 1ull))] = (uint32_t)(4 * t + k);
   if (threadIdx.x < LW_N_WHY && s_why[threadIdx.x] != 0u) {
     const int word[LW_N_WHY] = {3, 62, -1};   // the lazy schedule gave the voxel up (whatever the reason), voted over, (size: not counted)
     if (word[threadIdx.x] >= 0) atomicAdd(&counters[word[threadIdx.x]], (unsigned long long)s_why[threadIdx.x]);
   }
-  // the last workgroup through sees every list complete and says which way the hand-overs go (LcGate)
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0 && atomicAdd(&gate[1], 1u) == gridDim.x - 1u) {
-    __threadfence();
+  // the last workgroup through sees every list's length complete (the counts travel in device-scope atomics: no fence) and says which way
+  // the hand-overs go (LcGate)
+  if (threadIdx.x == 0 && __hip_atomic_fetch_add(&gate[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
     unsigned int tot = 0;
     for (int k = 0; k < LW_HO_BINS; ++k) tot += __hip_atomic_load(&n_lists[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&gate[0], tot > many ? LC_MANY : LC_FEW, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -740,11 +758,12 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   if (vgs_unused_are_inert(c->P) != c->adj_pruned) { c->err = "adjacency rows do not match the current sigma/cut parameters"; return VGS_E_STATE; }
   LP.prune_unused = 0;
   LP.xl_from = c->K.dbg_xl_from;
+  LP.dbg_max_m = c->K.dbg_max_m;
   LP.d2_stop = __builtin_huge_valf();   // set below, once the neighbourhood's reach is known
   LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure((10 + LW_HO_BINS) * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure((11 + LW_HO_BINS) * (size_t)U + 16));
   VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
   VGS_HIP_TRY(c, c->counters.ensure(128));   // words 64-127: the one-wavefront classes' samples (LwParams::vote)
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 128 * sizeof(uint64_t), c->stream));
@@ -922,6 +941,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).
   // from here on the side streams carry work of this run: a failure below must make the next run wait for them
   c->pl_enabled_at_launch = false;
+  c->lc_tail.gated = false;
   c->lc_tail.open = true; c->lc_tail.dense = dense; c->lc_tail.grid_f = 0; c->lc_tail.grid_g = GRID_G; c->lc_tail.tail_ms = 0.f;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
@@ -929,7 +949,52 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // the bulk class waits on an event that crosses queues once more, so it starts a few microseconds after the others
   VGS_HIP_TRY(c, hipEventRecord(c->ev[9], c->stream3));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[9], 0));
-  {
+  // Neighbourhoods above 128 voxels from the PAIR LISTS (round 5) when they are a real share of the scene (a ball of ten voxels: all of
+  // config 2): every row is built once -- 12 M weight evaluations where the shell classes did 68 M -- and the classes below read bands
+  // of descending weight instead of walking distance shells and evaluating what the near-pair lists do not reach.  What the kernel
+  // cannot take (a row without a list, a list that overflows at one entry per vertex) joins the hand-over list of the wide classes.
+  const unsigned int n_wide = nabc[2] + nabc[3] + nabc[5];
+  bool pg_wide = c->pl_enabled && c->K.pg_wide != 0 && dense && n_wide > 0 && (uint64_t)n_wide * (uint64_t)c->K.pg_wide_frac > (uint64_t)U;
+  if (pg_wide) {
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev[2], 0));
+    vgs_status sb = vgs_pairlists_build(c, c->stream2, nullptr, nullptr, nullptr, 0, true, LP.ctab, LP.ctab_scale, LP.d2_stop, 0, LcGate{nullptr, 0u}, true);
+    if (sb != VGS_OK) return sb;
+    pg_wide = c->pl_enabled;   // (the pool did not fit: the shell classes below)
+  }
+  if (pg_wide) {
+    const PairLists PLw = {(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring};
+    const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
+    uint32_t* const wbits = c->cb_enabled ? c->conn_bits.p : (uint32_t*)nullptr;
+    // neighbourhoods above 1024 voxels: queued by the instantiation below them for the extra-large one (whole balls of up to ten voxels:
+    // 4189 offsets), in a list of its own behind the samples' 
+    uint32_t* const ids_xl_pg = c->work_ids.p + (10 + LW_HO_BINS) * U;
+    unsigned int* const d_nxl = (unsigned int*)(c->counters.p + 56);
+    VGS_HIP_TRY(c, hipEventRecord(c->ev_ho2, c->stream2));   // the rows are built
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho2, 0));
+    // the largest neighbourhoods first on the builder's stream, the bulk of them (up to 320 voxels) beside them on the other
+    if (nabc[3] > 0)
+      hipLaunchKernelGGL((k_localcut_pg<PG_D>), dim3(vgs_xcd_grid(nabc[3])), dim3(512), 0, c->stream2, ids_d, 0, 1, (const unsigned int*)nullptr, nabc[3], 1, c->adj_key.p,
+                         c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
+                         c->cb_words, LcGate{nullptr, 0u}, ids_xl_pg, d_nxl);
+    if (nabc[3] > 0 && c->adj_R <= 10)   // what was too big for it: whole balls of up to ten voxels (the length of the list is on the device)
+      hipLaunchKernelGGL((k_localcut_pg<PG_XL>), dim3(256), dim3(256), 0, c->stream2, ids_xl_pg, 0, 1, d_nxl, 0u, 0, c->adj_key.p,
+                         c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
+                         c->cb_words, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
+    if (nabc[2] > 0)
+      hipLaunchKernelGGL((k_localcut_pg<PG_C>), dim3(vgs_xcd_grid(nabc[2])), dim3(256), 0, c->stream2, ids_c, 0, 1, (const unsigned int*)nullptr, nabc[2], 1, c->adj_key.p,
+                         c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
+                         c->cb_words, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
+    if (nabc[5] > 0)
+      hipLaunchKernelGGL((k_localcut_pg<PG_C0>), dim3(vgs_xcd_grid(nabc[5])), dim3(256), 0, c->stream4, ids_c0, 0, 1, (const unsigned int*)nullptr, nabc[5], 1, c->adj_key.p,
+                         c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
+                         c->cb_words, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[12], c->stream4));
+    VGS_HIP_TRY(c, hipEventRecord(c->ev[5], c->stream2));
+    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));
+    // what they could not take: the dense kernel of the wide classes, as for the shell classes' hand-overs
+    hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(n_wide < 4 * GRID_G ? n_wide : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
+                       c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u});
+  } else {
     // class D (more than 512 neighbours) on its own stream: eight wavefronts per voxel up to 1024 neighbours; beyond
     // that the kernel hands the voxel over (list g) to the workgroup kernel with its histogram rounds
     if (nabc[3] + nabc[5] > 0) {
@@ -999,7 +1064,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
     if (dense && nab > 0)
-      hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt, d_gate,
+      hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 1023) / 1024)), dim3(256), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt, d_gate,
                          (c->pl_enabled && c->K.pg_min_frac > 0) ? (unsigned int)(U / c->K.pg_min_frac) : 0xffffffffu);
     vgs_status st = VGS_OK;
     if (!dense) {
@@ -1013,25 +1078,31 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       // and one workgroup per voxel reads them in bands of descending weight (localcut_pg.hpp).  What either cannot take goes on to the
       // general kernel through the same list.
       const LcGate g_few = {d_gate, LC_FEW}, g_many = {d_gate, LC_MANY};
+      const uint32_t* ids4[LW_HO_BINS]; const unsigned int* nd4[LW_HO_BINS];
+      for (int k = 0; k < LW_HO_BINS; ++k) { ids4[k] = ids_f + (size_t)k * U; nd4[k] = d_nf + k; }
+      // (the pool may be allocated by the first build of a context: its pointer is read behind the builds)
+      auto pair_lists = [&]() { return PairLists{(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring}; };
+      const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
+      // (Few hand-overs through the pair lists as well -- mark the rows their neighbourhoods touch, build, read -- was measured in round 5:
+      // 8.0 against 6.9 ms on URB10M.  Its 5 k hand-overs sit in tree crowns whose 100 k voxels are all somebody's neighbour: twenty rows
+      // built per voxel cut.)
+      {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few);
       // (the pair-list chain on a stream of its own: when it is not wanted its four empty launches end beside the dense kernel, not behind it)
       VGS_HIP_TRY(c, hipEventRecord(c->ev_ho, c->stream3));   // the lists are built
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho, 0));
-      const uint32_t* ids4[LW_HO_BINS]; const unsigned int* nd4[LW_HO_BINS];
-      for (int k = 0; k < LW_HO_BINS; ++k) { ids4[k] = ids_f + (size_t)k * U; nd4[k] = d_nf + k; }
       // (many hand-overs: their neighbourhoods cover practically every row, so every row is built -- marking the wanted ones is 15 M
       // scattered byte stores, a millisecond on the noisy surface)
       st = vgs_pairlists_build(c, c->stream4, ids4, nd4, nullptr, LW_HO_BINS, true, LP.ctab, LP.ctab_scale, LP.d2_stop, 1, g_many, false);
       if (st == VGS_OK && c->pl_enabled) {
-        const PairLists PLs = {(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring};
-        const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
         hipLaunchKernelGGL((k_localcut_pg<PG_SMALL>), dim3(grid_f), dim3(256), 0, c->stream4, ids_f, (int)U, LW_HO_BINS, d_nf, 0u, 0, c->adj_key.p, c->adj_cnt.p,
-                           c->adj_stride, c->adj_off.p, c->node.p, LP, PLs, G, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, (uint8_t*)nullptr,
-                           (uint32_t*)nullptr, 0, 0, g_many);
+                           c->adj_stride, c->adj_off.p, c->node.p, LP, pair_lists(), G, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, (uint8_t*)nullptr,
+                           (uint32_t*)nullptr, 0, 0, g_many, (uint32_t*)nullptr, (unsigned int*)nullptr);
       } else if (st == VGS_OK) {   // (the pool did not fit: the dense kernel takes them all)
         hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream4, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
                            c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_many);
+      }
       }
     } else if (grid_f > 0) {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
@@ -1056,7 +1127,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                          c->cb_R, c->cb_words, c->conn_bits.p, CbLists{}, 0);
     VGS_HIP_TRY(c, hipMemsetAsync(c->lc_pending.p, 0, (size_t)U, c->stream));
   }
-  c->lc_tail.gated = false;
   // crossValidation's first pass looks at the word k_ho_lists writes (merge.hip) WITHOUT waiting for it: a workgroup that finds it still
   // undecided goes ahead as for LC_FEW, and should the word turn out LC_MANY the full pass that follows redoes whatever it did
   if (c->pl_enabled_at_launch) c->lc_tail.gated = true;
@@ -1087,6 +1157,7 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   LP.cut = c->P.cut_thred;
   LP.prune_unused = 0;
   LP.xl_from = c->K.dbg_xl_from;
+  LP.dbg_max_m = c->K.dbg_max_m;
   {
     const float reach = 2.0f * c->P.graph_size + 4.0f * c->P.voxel_size;
     LP.d2_stop = lc_d2_stop(LP.W, LP.cut, reach * reach * 1.01f);

@@ -56,7 +56,9 @@ __device__ unsigned long long g_pg_prof[24];
 
 // MAXM vertices, LCAP edges in flight (<= 512 * NW: the sort's block size), NW wavefronts, OCC workgroups per CU the registers allow;
 // RING_LDS: centroids and normals of the vertices staged in LDS for the ring stage (not for the extra-large instantiation)
-template <int MAXM, int LCAP, int NW, int OCC, bool RING_LDS>
+// DMAP: 0 = the vertex at a lattice offset is found through a hash; otherwise the side of a cube of 16-bit slots indexed by the offset
+// itself (the extra-large instantiation: a hash for 4 k vertices would take 32 KB, the 21^3 cube of a ball of ten voxels 18 KB)
+template <int MAXM, int LCAP, int NW, int OCC, bool RING_LDS, int DMAP = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __restrict__ work, int work_stride, int n_lists,
                                                              const unsigned int* __restrict__ n_work_dev, unsigned int n_work_host, int xcd_order,
                                                              const uint64_t* __restrict__ adj_key, const uint32_t* __restrict__ adj_cnt, int adj_stride,
@@ -64,12 +66,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
                                                              PairLists PL, PgGeom G, uint8_t* __restrict__ conn,
                                                              unsigned long long* __restrict__ counters, uint32_t* __restrict__ fallback,
                                                              unsigned int* __restrict__ n_fallback, uint32_t* __restrict__ evals_out,
-                                                             uint8_t* __restrict__ pending_mark, uint32_t* __restrict__ cbits, int cb_R, int cb_words, LcGate gate) {
+                                                             uint8_t* __restrict__ pending_mark, uint32_t* __restrict__ cbits, int cb_R, int cb_words, LcGate gate,
+                                                             uint32_t* __restrict__ too_big, unsigned int* __restrict__ n_too_big) {
   constexpr int TB = 64 * NW;
   constexpr int PSH = 16;
   constexpr uint32_t PMASK = 0xffffu, PCOMP = 0xffffffffu;
-  constexpr int HCAP = MAXM <= 128 ? 256 : (MAXM <= 512 ? 1024 : (MAXM <= 1024 ? 2048 : (MAXM <= 4096 ? 8192 : 16384)));
-  static_assert(HCAP >= 2 * MAXM || MAXM > 4096, "hash load <= 1/2");
+  constexpr int HCAP = DMAP ? 1 : (MAXM <= 128 ? 256 : (MAXM <= 512 ? 1024 : (MAXM <= 1024 ? 2048 : (MAXM <= 4096 ? 8192 : 16384))));
+  static_assert(DMAP != 0 || HCAP >= 2 * MAXM, "hash load <= 1/2");
+  constexpr int DCELLS = DMAP ? DMAP * DMAP * DMAP : 1, DR = (DMAP - 1) / 2;
+  __shared__ uint16_t dmap[DCELLS + (DCELLS & 1)];   // DMAP: vertex at every offset of the cube, 0xffff = none
   static_assert(LCAP <= 512 * NW, "one block of 512 keys per wavefront (regsort.hpp)");
   __shared__ uint64_t lk[LCAP];               // weight bits << 32 | ~pair id
   __shared__ uint32_t htab[HCAP];             // (packed offset + 1) << 16 | vertex, 0 = empty
@@ -92,13 +97,25 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
   unsigned int n_cut = 0;   // voxels this workgroup cut (counters[63], one atomic per workgroup)
 
   auto h_slot = [&](uint32_t key15) -> uint32_t { return (key15 * 2654435761u) >> 12; };
+  auto d_cell = [&](uint32_t key15) -> int {   // cell of a packed offset in the cube, -1 outside
+    const int dx = (int)(key15 & 31u) - 16 + DR, dy = (int)((key15 >> 5) & 31u) - 16 + DR, dz = (int)((key15 >> 10) & 31u) - 16 + DR;
+    if ((unsigned)dx >= (unsigned)DMAP || (unsigned)dy >= (unsigned)DMAP || (unsigned)dz >= (unsigned)DMAP) return -1;
+    return (dz * DMAP + dy) * DMAP + dx;
+  };
   auto h_find = [&](uint32_t key15) -> int {
-    uint32_t h = h_slot(key15);
-    while (true) {
-      const uint32_t e = htab[h & (HCAP - 1)];
-      if (e == 0u) return -1;
-      if ((e >> 16) == key15 + 1u) return (int)(e & 0xffffu);
-      ++h;
+    if constexpr (DMAP != 0) {
+      const int cell = d_cell(key15);
+      if (cell < 0) return -1;
+      const int v = (int)dmap[cell];
+      return v == 0xffff ? -1 : v;
+    } else {
+      uint32_t h = h_slot(key15);
+      while (true) {
+        const uint32_t e = htab[h & (HCAP - 1)];
+        if (e == 0u) return -1;
+        if ((e >> 16) == key15 + 1u) return (int)(e & 0xffffu);
+        ++h;
+      }
     }
   };
 
@@ -112,10 +129,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     auto hand_on = [&]() {   // all threads; the row is written by whoever takes the voxel from the fallback list
       if (tid == 0) { fallback[atomicAdd(n_fallback, 1u)] = u; atomicAdd(&counters[7], 1ull); if (pending_mark) pending_mark[u] = 0xff; }
     };
-    if (m > MAXM || orow[0] == 0xffffu) { hand_on(); return; }
+    if (m > MAXM && too_big != nullptr && orow[0] != 0xffffu) {   // the next larger instantiation takes it
+      if (tid == 0) too_big[atomicAdd(n_too_big, 1u)] = u;
+      return;
+    }
+    if (m > MAXM || orow[0] == 0xffffu || (P.dbg_max_m > 0 && m > P.dbg_max_m)) { hand_on(); return; }
     static_assert(sizeof(uint64_t) * LCAP >= 4 * 1024, "the bit row (<= 31^3 offsets) fits the edge list");
     // ---- the neighbourhood: lists, offsets, hash, segment state ----
-    for (int k = tid; k < HCAP; k += TB) htab[k] = 0u;
+    if constexpr (DMAP != 0) { for (int k = tid; k < (DCELLS + 1) / 2; k += TB) ((uint32_t*)dmap)[k] = 0xffffffffu; }
+    else { for (int k = tid; k < HCAP; k += TB) htab[k] = 0u; }
     if (tid == 0) { s_i[S_BAD] = 0; s_i[S_MERGES] = 0; s_i[S_PAIRS] = 0; }
     pg_barrier();
     {
@@ -127,8 +149,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         lpos[c] = ix.x; lend[c] = ix.x + (ix.y >= PL_UNUSABLE ? 0u : ix.y);
         const uint32_t key15 = orow[c];
         hlat[c] = (uint16_t)key15;
-        uint32_t h = h_slot(key15);
-        while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
+        if constexpr (DMAP != 0) {
+          const int cell = d_cell(key15);
+          if (cell >= 0) dmap[cell] = (uint16_t)c; else bad = true;   // (an offset outside the cube: not this instantiation's ball)
+        } else {
+          uint32_t h = h_slot(key15);
+          while (atomicCAS(&htab[h & (HCAP - 1)], 0u, ((key15 + 1u) << 16) | (uint32_t)c) != 0u) ++h;
+        }
         seg[c] = (uint16_t)c; rep[c] = (uint16_t)c; ssz[c] = 1; thr[c] = thr0; claim[c] = 0xffffffffu;
         if constexpr (RING_LDS) {
           const NodeRec& rcd = node[t];
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
       float lev = __builtin_huge_valf();      // every edge heavier than this has been processed
       int n_carry = 0;
       int bands = 0;
-      int min_lq = 0;
+      int min_lq = 0, lq_hint = 0;
       while (true) {
         ++bands;
         // ---- the vertices that still have unread entries and can still merge (fact F) ----
@@ -265,8 +292,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         const int n_act = s_i[S_NACT];
         const float floor = ring_done ? thr0 : floor_ring;
         int free_slots = LCAP - n_carry;
-        int lq = 5;   // log2 of the entries a vertex offers per band
+        // log2 of the entries a vertex offers per band: as many as fit the list if every offered entry became an edge -- or one step
+        // more than last time when the last band left three quarters of the list empty (most offers are no edges: partners outside
+        // the neighbourhood, ends already in one segment, frozen ends); a band that overflows the list is offered again, halved
+        int lq = 5;
         while (lq > 1 && (n_act << lq) > free_slots) --lq;
+        if (lq < lq_hint) lq = lq_hint < 5 ? lq_hint : 5;
         if (lq < min_lq) lq = min_lq;   // (a band that consumed nothing: equal keys filled the offer -- the next offer is wider)
         float L = floor;
         int cnt = n_carry;
@@ -348,6 +379,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           if (cnt <= LCAP) break;
           if (lq == 0 || lq <= min_lq) { handed = true; break; }   // more edges than the list holds at one entry per vertex
           --lq;
+          lq_hint = lq;
           pg_barrier();
         }
         if (handed) break;
@@ -365,6 +397,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             min_lq = 0;
           }
         }
+        lq_hint = (cnt - n_carry) * 4 < free_slots ? lq + 1 : lq;
         PGP_ACC(1);
         PGP_CNT(10, cnt);
         // -- 3. sort, merge down to L --

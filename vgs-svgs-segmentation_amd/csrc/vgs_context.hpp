@@ -101,6 +101,7 @@ struct VgsKnobs {
   int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
   int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
   int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
+  int pg_wide_frac = 8;      // VGS_PG_WIDEFRAC: ... when they are more than 1/N of the used voxels
   bool debug = false;        // VGS_DEBUG
 };
 
