@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-clusters", action="store_true", help="skip the getClusterIdx timing (extras, outside the metric)")
+    ap.add_argument("--clusters-reference", action="store_true", help="also time getClusterIdx in the reference's own element order")
     ap.add_argument("--dry-run", action="store_true", help="CPU only: exercise the launch path and the collectives (gloo), no engine")
     ap.add_argument("--native", action="store_true", help="tiled runs through libvgs_tiles.so (the default for --gpus > 1; with --gpus 1: a one-rank communicator)")
     ap.add_argument("--python-twin", action="store_true", help="tiled runs through the Python twin of the native driver (dist.py)")
@@ -369,7 +371,8 @@ def main():
 
     per_rank = None
     if tiles_drv is not None:
-        mine = {"rank": rank, "device": local_rank, "points": int(xyz.shape[0]), **tiles_drv.info(),
+        _free, _total = torch.cuda.mem_get_info(dev)   # device memory in use on this rank's GPU behind the timed steps: tile + halo, every grow-only table
+        mine = {"rank": rank, "device": local_rank, "points": int(xyz.shape[0]), "hbm_in_use_gb": (_total - _free) / 1e9, "hbm_total_gb": _total / 1e9, **tiles_drv.info(),
                 "stage_ms": {k: val / args.steps for k, val in stage_acc.items()}, "tiles_ms": {k: val / args.steps for k, val in tiles_acc.items()}}
         per_rank = [mine]
         if dist is not None:
@@ -523,6 +526,22 @@ def main():
             out["ranks"] = rccl_ranks if rccl_ranks is not None else world
         elif world > 1:
             out["driver"] = {"kind": "python twin: vgs-svgs-segmentation_amd/dist.py (test harness)"}
+        if world == 1 and not native and not args.no_clusters:
+            # getClusterIdx, the reference's end product (voxel_segmentation.h:117; test:74-76) -- outside the metric, beside it:
+            # the lists made on the device and left in HBM (csrc/clusters.hip), the same copied to host memory (vgs_get_clusters),
+            # and, on request, the reference's own element order (host walk over lists the device compacts: csrc/cutorder.hip)
+            cl = {}
+            runner.clusters_device()           # (warm-up: the list buffers are grow-only allocations of the context, like every table)
+            runner.run()                       # fresh labels: the lists are cached per run
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter(); runner.clusters_device(); cl["device_ms"] = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter(); off, idx = runner.clusters("voxel_id"); cl["to_host_ms"] = (time.perf_counter() - t1) * 1e3
+            cl["clusters"], cl["points_listed"] = int(off.shape[0] - 1), int(off[-1])
+            cl["order"] = "clusters by ascending smallest voxel id, inside a cluster ascending voxel id then point index"
+            if args.clusters_reference:
+                t1 = time.perf_counter(); off_r, idx_r = runner.clusters("reference"); cl["reference_order_to_host_ms"] = (time.perf_counter() - t1) * 1e3
+                cl["reference_order_same_sets"] = bool(np.array_equal(off, off_r))
+            out["clusters_ms"] = cl
         if h2h is not None:
             out["host_to_host"] = h2h
         if world == 1 and not native and not args.no_cpu_baseline:

@@ -2,11 +2,13 @@
 //   pcd_tool convert <in.pcd|in.ply> <out.pcd> [ascii|binary] read any supported PCD or PLY, write x y z
 //   pcd_tool colour <in.pcd> <clusters.txt> <out.pcd> <seed> clusters.txt: one cluster per line, point indices
 //   pcd_tool task <task file>                                 print "<lines> <method> <input name> <output name>"
+//   pcd_tool scene <TOWN|PC1M|URB10M|URB80M> <points|0> <out.pcd> a synthetic BASELINE scene (include/vgs_scenes.hpp), binary PCD
 #include <cstdio>
 #include <fstream>
 #include <sstream>
 
 #include "point_clouds_io.hpp"
+#include "vgs_scenes.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
@@ -27,6 +29,14 @@ int main(int argc, char** argv) {
     std::string line;
     while (std::getline(f, line)) { std::istringstream ss(line); std::vector<int> v; int x; while (ss >> x) v.push_back(x); clusters.push_back(v); }
     return saveColoredClusters(argv[4], c, clusters, std::strtoull(argv[5], nullptr, 10), true) == 0 ? 0 : 1;
+  }
+  if (cmd == "scene" && argc >= 5) {
+    std::vector<float> xyz;
+    if (!vgs_scenes::make_scene(argv[2], std::atoll(argv[3]), xyz)) return 2;
+    PCXYZPtr c(new PCXYZ);
+    c->points.resize(xyz.size() / 3);
+    for (size_t i = 0; i < c->points.size(); ++i) c->points[i] = pcl::PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return outputPointCloudData(argv[4], c, true) == 0 ? 0 : 1;
   }
   if (cmd == "task") {
     const auto t = inputTaskTxtFile(argv[2]);

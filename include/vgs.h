@@ -196,6 +196,10 @@ vgs_status vgs_get_clusters(vgs_ctx* ctx, int64_t* offsets, int32_t* point_idx);
  * points of each node in ascending index (VS:981-999; SS:2109-2126) -- element for element what getClusterIdx() holds.
  * (Output formatting: the walk runs on the host over the downloaded lists.) */
 vgs_status vgs_get_clusters_ordered(vgs_ctx* ctx, int32_t order, int64_t* offsets, int32_t* point_idx);
+/* getClusterIdx left in HBM (round 5; csrc/clusters.hip): the lists of vgs_get_clusters (default order) as device pointers --
+ * offsets_dev[kept + 1] (int64), point_idx_dev[offsets[kept]] (int32) -- made by one stable sort of the leaf order by label; valid
+ * until the next run of the stages.  vgs_get_clusters[_ordered] with the default order copies exactly these to the host. */
+vgs_status vgs_get_clusters_device(vgs_ctx* ctx, const int64_t** offsets_dev, const int32_t** point_idx_dev);
 
 /* ---- multi-GPU support (spatial tiles) -------------------------------------- */
 /* The reference is single-process; these entry points are what a tiled driver needs around the same stages.

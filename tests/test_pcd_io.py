@@ -165,3 +165,29 @@ def test_task_file_reader_strips_cr(tool, tmp_path):
     f.write_bytes("\r\n".join(lines).encode())                 # the shipped task files have CRLF line ends
     out = subprocess.check_output([tool, "task", str(f)], text=True).split()
     assert out == ["61", "3", "Town_Test.pcd", "Town_Test_SVGS.pcd"]
+
+
+@pytest.mark.parametrize("name,n,res", [("TOWN", 60_000, 0.15), ("PC1M", 80_000, 0.05), ("URB10M", 120_000, 0.1)])
+def test_cpp_scene_generator(tool, pcd, tmp_path, name, n, res):
+    """include/vgs_scenes.hpp (the scenes as self-contained C++, so that the C++ examples need no Python): deterministic,
+    the requested size, the viewpoint (0, 0, 1.5) inside it, the density per voxel face of the numpy generator the bench uses
+    (same geometry and layout rules, its own random stream), and shuffled (the octree's origin depends on the first point)."""
+    import vgs_svgs_segmentation_amd as v
+    a, b = tmp_path / "a.pcd", tmp_path / "b.pcd"
+    subprocess.check_call([tool, "scene", name, str(n), str(a)])
+    subprocess.check_call([tool, "scene", name, str(n), str(b)])
+    assert a.read_bytes() == b.read_bytes()
+    fields, _ = pcd.read_pcd(a)
+    xyz = np.stack([fields["x"], fields["y"], fields["z"]], axis=1)
+    assert xyz.shape == (n, 3) and xyz.dtype == np.float32 and np.isfinite(xyz).all()
+    lo, hi = xyz.min(axis=0), xyz.max(axis=0)
+    assert (lo[:2] < 0).all() and (hi[:2] > 0).all() and lo[2] < 0.1   # (the viewpoint (0, 0, 1.5) is above the ground of every scene; scaled-down scenes are lower than it)
+    ref = {"TOWN": v.scenes.town_scene, "PC1M": v.scenes.pc_scene, "URB10M": v.scenes.urban_scene}[name](n)
+    # same extents (the layouts draw their building heights from different streams: x / y only), same occupied-voxel count within 15 %
+    tol = max(0.05, 0.08 * float((hi - lo)[:2].max()))   # (tree crowns and poles are placed by the layout stream: they may stick out of the ground)
+    np.testing.assert_allclose(lo[:2], ref.min(axis=0)[:2], atol=tol)
+    np.testing.assert_allclose(hi[:2], ref.max(axis=0)[:2], atol=tol)
+    vox = lambda p: len(np.unique(np.floor(p / res).astype(np.int64), axis=0))
+    assert abs(vox(xyz) - vox(ref)) < 0.15 * vox(ref), (vox(xyz), vox(ref))
+    # shuffled: consecutive points are not neighbours
+    assert np.median(np.linalg.norm(np.diff(xyz[:2000], axis=0), axis=1)) > 5 * res

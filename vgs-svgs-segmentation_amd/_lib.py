@@ -93,6 +93,7 @@ SYMBOLS = [
     ("vgs_get_point_labels_device", C.c_int, [_P, C.POINTER(_P)]),
     ("vgs_get_clusters", C.c_int, [_P, _P, _P]),
     ("vgs_get_clusters_ordered", C.c_int, [_P, C.c_int32, _P, _P]),
+    ("vgs_get_clusters_device", C.c_int, [_P, _P, _P]),
     ("vgs_grid_state_init", C.c_int, [C.POINTER(VgsGridState)]),
     ("vgs_grid_advance", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_points_bbox", C.c_int, [_P, _P, C.POINTER(C.c_int64)]),

@@ -253,6 +253,12 @@ class Engine:
         self._ck(self._L.vgs_get_clusters_ordered(self._h, o, _ptr(off), _ptr(idx)))
         return off, idx[:int(off[-1])]
 
+    def clusters_device(self):
+        """getClusterIdx left in HBM: (device pointer of the offsets [kept + 1] int64, device pointer of the point indices int32)."""
+        po, pi = C.c_void_p(), C.c_void_p()
+        self._ck(self._L.vgs_get_clusters_device(self._h, C.byref(po), C.byref(pi)))
+        return po.value, pi.value
+
     # ---- a sequence of clouds: uploads of the next cloud and downloads of the last labels overlap the stages
     def stage_points(self, xyz):
         """Start the copy of the NEXT cloud (ideally a pinned array, see pinned_empty) and return at once."""

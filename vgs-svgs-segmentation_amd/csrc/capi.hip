@@ -81,7 +81,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
   k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
   k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m); k.dbg_xl_from = geti("VGS_DBG_XL_FROM", k.dbg_xl_from);
   k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
-  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac);
+  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.no_dense_to_pg = has("VGS_NO_DENSE_TO_PG"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac);
   k.debug = has("VGS_DEBUG");
 }
 
@@ -222,7 +222,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->node.release(); c->used_ids.release(); c->used_rank.release();
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_off.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->nl_cnt.release(); c->nl_tot.release(); c->nl_ent.release(); c->lc_ctab.release(); c->pl_state.release(); c->pl_ent.release(); c->pl_work.release();
-  c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->lc_defer_flag.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
+  c->cl_off.release(); c->cl_idx.release(); c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->lc_defer_flag.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
   c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_tile_start.release(); c->vc_cell.release(); c->vc_plive.release(); c->vc_tile_of.release(); c->vc_tchg.release(); c->vc_nbr_tiles.release(); c->vc_halo.release(); c->vc_tile_meta.release(); c->vc_pool.release(); c->vc_label.release();
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release(); c->vc_accu.release(); c->vc_live.release(); c->vc_alive.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
@@ -614,6 +614,31 @@ static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::ve
   std::vector<uint64_t> keys;
   std::vector<uint8_t> flag;
   std::vector<int32_t> attach;
+  if (ordered && which >= 1 && U > 0) {
+    // the reference's own element order: the lists are put together on the device (cutorder.hip: merge-history order, crossValidation's
+    // filter in that order) and come down compact -- ids only
+    VGS_HIP_TRY(c, hipSetDevice(c->device));
+    VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> ord;
+    std::vector<uint32_t> kk, lcnt;
+    std::vector<int32_t> lids;
+    const uint8_t* lflag = which == 1 ? (const uint8_t*)nullptr : c->conn.p + (size_t)U * c->adj_stride;
+    vgs_status so = vgs_cut_order(c, ord, kk, true, lflag, &lcnt, &lids);
+    if (so != VGS_OK) return so;
+    L.assign((size_t)V, {});
+    size_t at = 0;
+    for (int64_t u = 0; u < U; ++u) {
+      L[used_ids[(size_t)u]].assign(lids.begin() + (ptrdiff_t)at, lids.begin() + (ptrdiff_t)(at + lcnt[(size_t)u]));
+      at += lcnt[(size_t)u];
+    }
+    if (which == 3) {
+      attach.resize((size_t)V);
+      VGS_HIP_TRY(c, hipMemcpy(attach.data(), c->attach.p, (size_t)V * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < V; ++i)   // closestCheck appends (VS:2293-2294): i gets its target, the target gets i, in voxel order
+        if (attach[i] >= 0) { L[i].push_back(attach[i]); L[attach[i]].push_back((int32_t)i); }
+    }
+    return VGS_OK;
+  }
   if (U > 0) {
     VGS_HIP_TRY(c, hipSetDevice(c->device));
     VGS_HIP_TRY(c, hipMemcpy(used_ids.data(), c->used_ids.p, (size_t)U * 4, hipMemcpyDeviceToHost));
@@ -632,19 +657,6 @@ static vgs_status vgs_build_lists(vgs_ctx* c, int32_t which, std::vector<std::ve
   }
   // per-voxel lists; closestCheck appends (VS:2293-2294): i gets its target, the target gets i, in voxel order
   L.assign((size_t)V, {});
-  if (ordered && which >= 1 && U > 0) {
-    std::vector<uint16_t> ord;
-    std::vector<uint32_t> kk;
-    vgs_status so = vgs_cut_order(c, ord, kk);
-    if (so != VGS_OK) return so;
-    for (int64_t u = 0; u < U; ++u) {
-      const uint32_t i = used_ids[u];
-      for (uint32_t r = 0; r < kk[u]; ++r) {
-        const size_t s = (size_t)u * c->adj_stride + ord[(size_t)u * c->adj_stride + r];
-        if (which == 1 || flag[s]) L[i].push_back((int32_t)(uint32_t)keys[s]);   // crossValidation filters in list order (VS:2119-2152)
-      }
-    }
-  } else
   for (int64_t u = 0; u < U; ++u) {
     const uint32_t i = used_ids[u];
     for (uint32_t k = 0; k < cnt[u]; ++k) {
@@ -745,6 +757,14 @@ vgs_status vgs_get_clusters_ordered(vgs_ctx* c, int32_t order, int64_t* offsets,
   if (order == VGS_ORDER_REFERENCE && c->have_region) { c->err = "vgs_get_clusters: reference order needs the whole cloud in one context (not a tile)"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
   const int64_t K = c->counts[VGS_N_KEPT];
+  if (order == VGS_ORDER_VOXEL_ID) {
+    // the lists are made on the device (clusters.hip: one stable sort of the leaf order by label); only the answer comes down
+    vgs_status sd = vgs_clusters_on_device(c);
+    if (sd != VGS_OK) return sd;
+    VGS_HIP_TRY(c, hipMemcpy(offsets, c->cl_off.p, ((size_t)K + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (point_idx && offsets[K] > 0) VGS_HIP_TRY(c, hipMemcpy(point_idx, c->cl_idx.p, (size_t)offsets[K] * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return VGS_OK;
+  }
   std::vector<int64_t> cnt((size_t)K + 1, 0);
   std::vector<uint32_t> perm((size_t)c->Nf), pv((size_t)c->Nf);
   std::vector<int32_t> vl((size_t)c->V);

@@ -136,6 +136,43 @@ __global__ __launch_bounds__(64) void k_co_merge(int64_t u0, const uint32_t* __r
   }
 }
 
+// The lists themselves, compact (round 5): what the host walk of getClusterIdx's reference order needs is, per used voxel, the voxel ids
+// of its list in that order -- after crossValidation only the entries whose mutual flag is set (it filters in list order, VS:2119-2152).
+// Counted, scanned, written here; the host downloads these few ids instead of the whole tables of keys, flags and positions
+// (2.4 GB at the 10 M-point config, the ids 85 MB).
+__global__ __launch_bounds__(64) void k_co_list_count(const uint16_t* __restrict__ ord, const uint32_t* __restrict__ kk, const uint8_t* __restrict__ flag,
+                                                      int adj_stride, int64_t U, uint32_t* __restrict__ cnt) {
+  const int64_t u = (int64_t)blockIdx.x;
+  if (u >= U) return;
+  const int k = (int)kk[u];
+  int n = 0;
+  for (int r = threadIdx.x; r < k; r += 64) n += (flag == nullptr || flag[u * adj_stride + ord[u * adj_stride + r]]) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if (threadIdx.x == 0) cnt[u] = (uint32_t)n;
+}
+__global__ __launch_bounds__(64) void k_co_list_fill(const uint16_t* __restrict__ ord, const uint32_t* __restrict__ kk, const uint8_t* __restrict__ flag,
+                                                     const uint64_t* __restrict__ adj_key, int adj_stride, int64_t U, const uint64_t* __restrict__ start,
+                                                     int32_t* __restrict__ ids) {
+  const int64_t u = (int64_t)blockIdx.x;
+  if (u >= U) return;
+  const int k = (int)kk[u];
+  const int lane = threadIdx.x;
+  uint64_t at = start[u];
+  for (int base = 0; base < k; base += 64) {   // in list order: a ballot keeps it
+    const int r = base + lane;
+    bool keep = false;
+    uint32_t t = 0;
+    if (r < k) {
+      const int64_t s = u * adj_stride + ord[u * adj_stride + r];
+      keep = flag == nullptr || flag[s] != 0;
+      t = (uint32_t)adj_key[s];
+    }
+    const unsigned long long mk = __ballot(keep);
+    if (keep) ids[at + (uint64_t)__popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)t;
+    at += (uint64_t)__popcll(mk);
+  }
+}
+
 static VgsWeightParams co_weight_params(const vgs_params& p) {
   VgsWeightParams W;
   W.inv_sig_p = 1.0f / p.sig_p; W.inv_sig_n = 1.0f / p.sig_n; W.inv_sig_o = 1.0f / p.sig_o;
@@ -146,9 +183,14 @@ static VgsWeightParams co_weight_params(const vgs_params& p) {
 }
 
 // host: ord_host[u * stride + r] for r < k_host[u]
-vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host) {
+// list_flag / list_cnt / list_ids (optional): instead of the positions, the compact lists -- list_flag null: every member of the cut's
+// list (connect_cut), else the flags that filter it (the mutual flags of crossValidation)
+vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host, bool want_lists, const uint8_t* list_flag,
+                         std::vector<uint32_t>* list_cnt, std::vector<int32_t>* list_ids) {
   const int64_t U = c->U;
   ord_host.clear(); k_host.assign((size_t)U, 0);
+  if (list_cnt) list_cnt->assign((size_t)U, 0);
+  if (list_ids) list_ids->clear();
   if (U == 0) return VGS_OK;
   // rows hold at most CO_MAXK entries: a longer one fails the local cut itself (VGS_E_UNSUPPORTED there); the row STRIDE (all
   // lattice offsets of the ball) may well be larger
@@ -199,6 +241,27 @@ vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vecto
     unsigned int bad = 0;
     if ((e = hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost)) != hipSuccess) { fail(e, "copy"); break; }
     if (bad) { c->err = "vgs_cut_order: the replay of " + std::to_string(bad) + " local cuts does not end in the connect set the hot path found"; st = VGS_E_STATE; break; }
+    if (want_lists && list_cnt && list_ids) {
+      DevBuf<uint32_t> d_cnt; DevBuf<uint64_t> d_start; DevBuf<int32_t> d_ids;
+      do {
+        if ((e = d_cnt.ensure(U)) != hipSuccess || (e = d_start.ensure(U + 1)) != hipSuccess) { fail(e, "alloc"); break; }
+        hipLaunchKernelGGL(k_co_list_count, dim3((unsigned)U), dim3(64), 0, c->stream, d_ord.p, d_k.p, list_flag, c->adj_stride, U, d_cnt.p);
+        if ((e = hipMemcpyAsync(list_cnt->data(), d_cnt.p, (size_t)U * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { fail(e, "copy"); break; }
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { fail(e, "count lists"); break; }
+        std::vector<uint64_t> start((size_t)U + 1, 0ull);
+        for (int64_t u = 0; u < U; ++u) start[(size_t)u + 1] = start[(size_t)u] + (*list_cnt)[(size_t)u];
+        const uint64_t total = start[(size_t)U];
+        list_ids->resize((size_t)total);
+        if (total == 0) break;
+        if ((e = d_ids.ensure((size_t)total)) != hipSuccess) { fail(e, "alloc"); break; }
+        if ((e = hipMemcpyAsync(d_start.p, start.data(), ((size_t)U + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) { fail(e, "copy"); break; }
+        hipLaunchKernelGGL(k_co_list_fill, dim3((unsigned)U), dim3(64), 0, c->stream, d_ord.p, d_k.p, list_flag, c->adj_key.p, c->adj_stride, U, d_start.p, d_ids.p);
+        if ((e = hipMemcpyAsync(list_ids->data(), d_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) { fail(e, "copy"); break; }
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { fail(e, "fill lists"); break; }
+      } while (false);
+      d_cnt.release(); d_start.release(); d_ids.release();
+      break;
+    }
     ord_host.resize((size_t)U * c->adj_stride);
     if ((e = hipMemcpy(ord_host.data(), d_ord.p, ord_host.size() * 2, hipMemcpyDeviceToHost)) != hipSuccess) { fail(e, "copy"); break; }
   } while (false);

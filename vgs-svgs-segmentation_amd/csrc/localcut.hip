@@ -763,7 +763,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   LP.ctab = nullptr; LP.ctab_scale = 0.0f;
 
   VGS_HIP_TRY(c, c->conn.ensure(2 * (size_t)U * c->adj_stride));  // [0,U*stride) connect flags, second half: mutual flags (merge stage)
-  VGS_HIP_TRY(c, c->work_ids.ensure((11 + LW_HO_BINS) * (size_t)U + 16));
+  VGS_HIP_TRY(c, c->work_ids.ensure((12 + LW_HO_BINS) * (size_t)U + 16));
   VGS_HIP_TRY(c, c->evals.ensure((size_t)U));  // per-voxel evaluation counters (index u), summed on request (vgs_get_counts)
   VGS_HIP_TRY(c, c->counters.ensure(128));   // words 64-127: the one-wavefront classes' samples (LwParams::vote)
   VGS_HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 128 * sizeof(uint64_t), c->stream));
@@ -993,7 +993,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[12], 0));
     // what they could not take: the dense kernel of the wide classes, as for the shell classes' hand-overs
     hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(n_wide < 4 * GRID_G ? n_wide : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
-                       c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u});
+                       c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
   } else {
     // class D (more than 512 neighbours) on its own stream: eight wavefronts per voxel up to 1024 neighbours; beyond
     // that the kernel hands the voxel over (list g) to the workgroup kernel with its histogram rounds
@@ -1022,7 +1022,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       if (!dense) st = launch_block(c->stream2, ids_g, ncd < GRID_G ? ncd : GRID_G, false, d_ng, 0);
       else   // the grid strides over the list: two voxels per CU at a time, a few rounds of them
         hipLaunchKernelGGL((k_localcut_dense<DN_LARGE>), dim3(ncd < 4 * GRID_G ? ncd : 4 * GRID_G), dim3(512), 0, c->stream2, ids_g, 0, 1, d_ng, c->adj_key.p,
-                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u});
+                           c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_g2, d_ng2, c->evals.p, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
     }
     if (st != VGS_OK) return st;
   }
@@ -1066,6 +1066,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     if (dense && nab > 0)
       hipLaunchKernelGGL(k_ho_lists, dim3((unsigned)((U + 1023) / 1024)), dim3(256), 0, c->stream3, c->lc_pending.p, U, ids_f, U, d_nf, cnt, d_gate,
                          (c->pl_enabled && c->K.pg_min_frac > 0) ? (unsigned int)(U / c->K.pg_min_frac) : 0xffffffffu);
+    if (dense && nab > 0) VGS_HIP_TRY(c, hipEventRecord(c->ev_ho, c->stream3));   // the hand-over lists are built, the word of LcGate is written
     vgs_status st = VGS_OK;
     if (!dense) {
       st = launch_block(c->stream3, ids_f, grid_f, true, d_nf, 0);
@@ -1087,10 +1088,23 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       // 8.0 against 6.9 ms on URB10M.  Its 5 k hand-overs sit in tree crowns whose 100 k voxels are all somebody's neighbour: twenty rows
       // built per voxel cut.)
       {
+      // the dense kernel queues the neighbourhoods with more heavy edges than its list holds (a handful: 179 of 5 k on URB10M, and the
+      // slowest of its launch by far -- every band of theirs is one more sweep over all pairs) for the pair-list kernel: their rows are
+      // marked and built behind it (a few thousand), and k_localcut_pg reads them
+      uint32_t* const ids_tp = c->work_ids.p + (11 + LW_HO_BINS) * U;
+      unsigned int* const d_ntp = (unsigned int*)(c->counters.p + 47);
+      const bool to_pg = !c->K.no_dense_to_pg;
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few);
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few, to_pg ? ids_tp : (uint32_t*)nullptr, d_ntp);
+      if (to_pg) {
+        const uint32_t* tp_ids[1] = {ids_tp}; const unsigned int* tp_n[1] = {d_ntp};
+        st = vgs_pairlists_build(c, c->stream3, tp_ids, tp_n, nullptr, 1, false, LP.ctab, LP.ctab_scale, LP.d2_stop, 2, g_few, false);
+        if (st == VGS_OK && c->pl_enabled)
+          hipLaunchKernelGGL((k_localcut_pg<PG_SMALL>), dim3(std::min<unsigned int>(grid_f, 2048u)), dim3(256), 0, c->stream3, ids_tp, 0, 1, d_ntp, 0u, 0, c->adj_key.p, c->adj_cnt.p,
+                             c->adj_stride, c->adj_off.p, c->node.p, LP, pair_lists(), G, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, (uint8_t*)nullptr,
+                             (uint32_t*)nullptr, 0, 0, g_few, (uint32_t*)nullptr, (unsigned int*)nullptr);
+      }
       // (the pair-list chain on a stream of its own: when it is not wanted its four empty launches end beside the dense kernel, not behind it)
-      VGS_HIP_TRY(c, hipEventRecord(c->ev_ho, c->stream3));   // the lists are built
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho, 0));
       // (many hand-overs: their neighbourhoods cover practically every row, so every row is built -- marking the wanted ones is 15 M
       // scattered byte stores, a millisecond on the noisy surface)
@@ -1101,12 +1115,12 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                            (uint32_t*)nullptr, 0, 0, g_many, (uint32_t*)nullptr, (unsigned int*)nullptr);
       } else if (st == VGS_OK) {   // (the pool did not fit: the dense kernel takes them all)
         hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream4, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                           c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_many);
+                           c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_many, (uint32_t*)nullptr, (unsigned int*)nullptr);
       }
       }
     } else if (grid_f > 0) {
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, LcGate{nullptr, 0u});
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
     }
     if (st != VGS_OK) return st;
     if (grid_f > 0 && dense && c->pl_enabled_at_launch) {   // stream3 ends when both chains have

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
                                                           int adj_stride, const NodeRec* __restrict__ node, LcParams P,
                                                           uint8_t* __restrict__ conn, unsigned long long* __restrict__ counters,
                                                           uint32_t* __restrict__ fallback, unsigned int* __restrict__ n_fallback,
-                                                          uint32_t* __restrict__ evals_out, LcGate gate) {
+                                                          uint32_t* __restrict__ evals_out, LcGate gate,
+                                                          uint32_t* __restrict__ to_pg, unsigned int* __restrict__ n_to_pg) {
   if (!lc_gate_open(gate)) return;
   constexpr bool SMALL = MAXM <= 255;   // vertex indices and segment sizes fit a byte, pair ids 16 bits
   typedef typename std::conditional<SMALL, uint8_t, uint16_t>::type idx_t;
@@ -368,6 +369,12 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
       DNP_ACC(3);
       merge_list(nlA, true);
       DNP_ACC(4);
+    } else if (to_pg != nullptr) {
+      // More heavy edges than the list holds, and the pair lists are at hand (round 5): instead of the bands below -- every band one more
+      // sweep over all pairs, and the launch ends with its slowest voxel -- the voxel is queued for k_localcut_pg, which reads bands of
+      // descending weight from lists (the rows of these few neighbourhoods are built behind this kernel)
+      if (tid == 0) to_pg[atomicAdd(n_to_pg, 1u)] = u;
+      return;
     } else {
       // More heavy edges than the list holds (a large neighbourhood on one smooth surface that the lazy schedule could not
       // finish): bands of descending weight as in phase B below, from a histogram of the weights above thr0.  Each band

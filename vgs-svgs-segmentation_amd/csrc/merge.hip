@@ -453,6 +453,7 @@ extern "C" vgs_status vgs_get_local_weights(vgs_ctx* c, int32_t node_id, int32_t
 }
 
 vgs_status vgs_stage_merge(vgs_ctx* c) {
+  c->cl_valid = false;   // (clusters.hip: the cluster lists on the device belong to the labels of the last run)
   const int64_t V = c->V, U = c->U, N = c->N;
   c->bnd_unique = -1;  // tile protocol results belong to the previous segmentation
   c->counts[VGS_N_CLUSTERS] = 0; c->counts[VGS_N_KEPT] = 0; c->counts[VGS_N_ISOLATED] = 0; c->counts[VGS_N_REATTACHED] = 0;

@@ -424,6 +424,7 @@ vgs_status vgs_get_boundary_roots(vgs_ctx* c, int64_t* n_records, uint64_t* code
 }
 
 vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* root, const int32_t* label, int64_t n_roots) {
+  if (c) c->cl_valid = false;
   if (!c || (n_roots > 0 && (!root || !label))) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED || c->bnd_unique < 0) { c->err = "vgs_apply_tile_labels: vgs_get_boundary_roots first"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));
@@ -484,6 +485,7 @@ vgs_status vgs_get_owned_roots(vgs_ctx* c, int64_t* n_roots, int32_t* root, int3
 }
 
 vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t* root, const int32_t* label, int64_t n_roots) {
+  if (c) c->cl_valid = false;
   if (!c || (n_roots > 0 && (!root || !label))) return VGS_E_ARG;
   if (c->stage < ST_SEGMENTED) { c->err = "vgs_apply_root_labels: segment first"; return VGS_E_STATE; }
   VGS_HIP_TRY(c, hipSetDevice(c->device));

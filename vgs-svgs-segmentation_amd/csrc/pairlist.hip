@@ -38,6 +38,8 @@ struct PlParams {
 #define PL_W_WORK 59     // length of the work list (low half), of the redo list (high half)
 #define PL_W_FULL 60     // rows that found the pool exhausted
 #define PL_W_WORK2 61    // the second build's work / redo list lengths
+#define PL_W_WORK3 42    // the third's (three builds of one run may overlap on their streams: the wide classes' rows, the many hand-overs' rows,
+                         // the rows of the neighbourhoods the dense kernel passes on)
 
 // (barriers that order LDS traffic only: see pg_barrier in localcut_pg.hpp; one wavefront needs no s_barrier at all)
 template <int NWV>
@@ -263,7 +265,7 @@ vgs_status vgs_pairlists_begin(vgs_ctx* c, hipStream_t strm) {
   const int64_t V = c->V;
   VGS_HIP_TRY(c, c->pl_state.ensure((size_t)V * 10));
   VGS_HIP_TRY(c, hipMemsetAsync(c->pl_state.p, 0xff, (size_t)V * 10, strm));
-  VGS_HIP_TRY(c, c->pl_work.ensure(4 * (size_t)c->U + 16));
+  VGS_HIP_TRY(c, c->pl_work.ensure(6 * (size_t)c->U + 16));
   {
     // Pairs of one neighbourhood that are not in each other's ball: their centres are at least sqrt(r2) apart (the float predicate
     // of adjacency.hip failed), their centroids lie in their cubes widened by the tolerance the builder checks, so the centroids are
@@ -291,9 +293,9 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
   uint8_t* any = c->pl_state.p + (size_t)V * 9;
   unsigned int* cursor = (unsigned int*)(c->counters.p + PL_W_CURSOR);
   // two builds of one run (the wide classes' rows, the hand-overs' rows) may overlap on their streams: each has its own work lists
-  unsigned int* n_work = (unsigned int*)(c->counters.p + (slot ? PL_W_WORK2 : PL_W_WORK));
+  unsigned int* n_work = (unsigned int*)(c->counters.p + (slot == 2 ? PL_W_WORK3 : (slot ? PL_W_WORK2 : PL_W_WORK)));
   unsigned int* n_redo = n_work + 1;
-  uint32_t* const wl = c->pl_work.p + (slot ? 2 * (size_t)U : 0);
+  uint32_t* const wl = c->pl_work.p + (size_t)slot * 2 * (size_t)U;
   // the pool: at most half of a row's entries are at positive offsets; never more than the 32-bit index of an entry can name
   {
     // (every builder workgroup may leave one chunk partly used)

@@ -100,6 +100,7 @@ struct VgsKnobs {
   bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
   int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
   int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
+  bool no_dense_to_pg = false;   // VGS_NO_DENSE_TO_PG: the dense hand-over kernel takes its overflowing neighbourhoods in bands itself
   int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
   int pg_wide_frac = 8;      // VGS_PG_WIDEFRAC: ... when they are more than 1/N of the used voxels
   bool debug = false;        // VGS_DEBUG
@@ -231,6 +232,10 @@ struct vgs_ctx {
   DevBuf<int32_t> vox_label;
   DevBuf<int32_t> pt_label;      // labels of the current cloud
   DevBuf<int32_t> pt_label_alt;  // the buffer the next run writes while an asynchronous download still reads pt_label
+  // getClusterIdx on the device (clusters.hip): offsets and point indices of the kept clusters, default order; rebuilt after a run on request
+  DevBuf<int64_t> cl_off;
+  DevBuf<int32_t> cl_idx;
+  bool cl_valid = false;
   DevBuf<uint64_t> counters;   // device-side counters (pairs, flags)
   DevBuf<uint32_t> work_ids;   // scratch index lists
 
@@ -329,7 +334,8 @@ static inline vgs_status vgs_readback_end(vgs_ctx* c, void* dst, size_t bytes) {
 }
 static inline bool vgs_can_split_readback(const vgs_ctx* c) { return c->pin != nullptr && c->ev_rb != nullptr; }
 
-vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host);   // cutorder.hip
+vgs_status vgs_cut_order(vgs_ctx* c, std::vector<uint16_t>& ord_host, std::vector<uint32_t>& k_host, bool want_lists = false,
+                         const uint8_t* list_flag = nullptr, std::vector<uint32_t>* list_cnt = nullptr, std::vector<int32_t>* list_ids = nullptr);   // cutorder.hip
 void vgs_read_env_knobs(vgs_ctx* c);   // capi.hip; called by vgs_create only
 
 // stage implementations (one .hip file each)
@@ -347,6 +353,7 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
 vgs_status vgs_stage_localcut(vgs_ctx* c);   // launches everything; its hand-over kernels may still run when it returns
 vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred);  // waits for them, checks the stage's flags (called by the merge stage)
 vgs_status vgs_stage_merge(vgs_ctx* c);
+vgs_status vgs_clusters_on_device(vgs_ctx* c);   // clusters.hip
 vgs_status vgs_stage_vccs(vgs_ctx* c);
 vgs_status vgs_stage_svgs_group(vgs_ctx* c);
 vgs_status vgs_stage_svgs_neighbours(vgs_ctx* c);
