@@ -99,6 +99,7 @@ SYMBOLS = [
     ("vgs_points_bbox", C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
     ("vgs_grid_advance_bbox", C.c_int, [C.POINTER(VgsGridState), C.c_double, _P, C.POINTER(C.c_int32)]),
     ("vgs_set_grid", C.c_int, [_P, C.POINTER(VgsGridState)]),
+    ("vgs_set_grid_covering", C.c_int, [_P, C.POINTER(VgsGridState)]),
     ("vgs_set_owned_region", C.c_int, [_P, _P, _P]),
     ("vgs_set_own_point_range", C.c_int, [_P, C.c_int64, C.c_int64]),
     ("vgs_get_boundary", C.c_int, [_P, _P, _P, _P]),

@@ -278,6 +278,7 @@ static vgs_status set_points_common(vgs_ctx* c, int64_t n, int32_t stride_bytes)
   c->N = n;
   c->stride_f = stride_bytes / 4;
   c->stage = ST_POINTS;
+  c->grid_covers = false;   // (vgs_set_grid_covering vouches for one cloud)
   c->counts[VGS_N_POINTS] = n;
   for (int i = 0; i < VGS_T_COUNT; ++i) { c->times[i] = 0; c->tev_pending[i] = false; }
   // a supervoxel labelling belongs to the cloud it was made for (SS:279-331 rebuilds it per createSupervoxels call)

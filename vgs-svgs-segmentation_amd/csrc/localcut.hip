@@ -526,7 +526,7 @@ struct CbLists { const uint32_t* ids[5]; unsigned int end[5]; };   // end[k] = n
 __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pending, int64_t U, const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                   const uint8_t* __restrict__ conn, const uint16_t* __restrict__ adj_off,
                                                   int cb_R, int cb_words, uint32_t* __restrict__ cbits, CbLists L, int use_lists) {
-  __shared__ uint32_t cb[256];
+  __shared__ uint32_t cb[VGS_CB_MAX_WORDS];
   int64_t u = (int64_t)blockIdx.x;
   if (use_lists) {
     const unsigned int b = blockIdx.x;
@@ -885,7 +885,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const bool dense = !c->K.no_dense;   // diagnostics: the general workgroup kernel takes the hand-overs (one list)
   WP.near_min_own = c->K.near_min_own;
   // connect bits for crossValidation's lattice lookup: voxel lattice (method 2), rows with lattice offsets, a ball that fits the LUT
-  c->cb_enabled = c->P.method == 2 && c->adj_have_off && c->cb_words > 0 && c->cb_words <= 256 && c->adj_R <= 15 && !c->K.no_connbits;
+  c->cb_enabled = c->P.method == 2 && c->adj_have_off && c->cb_words > 0 && c->cb_words <= VGS_CB_MAX_WORDS && c->adj_R <= 15 && !c->K.no_connbits;
   WP.cbits = nullptr; WP.cb_R = 0; WP.cb_words = 0;
   WP.n_first_dev = nullptr; WP.n_main_dev = nullptr;
   if (c->cb_enabled) {

@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       // ... and as bits by ball offset (the edge list's LDS is free now): all words of the row are written, zeros when the row
       // carries no lattice offsets (the centre bit -- the voxel itself, always a member -- then says "no bits": the reader searches instead)
       uint32_t* const cb = (uint32_t*)lk;
-      static_assert(sizeof(uint64_t) * LCAP >= 4 * 256, "the bit row (<= 8192 offsets) fits the edge list");
+      static_assert(sizeof(uint64_t) * LCAP >= 4 * VGS_CB_MAX_WORDS, "the bit row fits the edge list");
       wave_sync();
       for (int k = lane; k < P.cb_words; k += 64) cb[k] = 0u;
       wave_sync();

@@ -307,8 +307,15 @@ vgs_status vgs_set_grid(vgs_ctx* c, const vgs_grid_state* g) {
   if (!g->defined) { c->err = "vgs_set_grid: undefined grid state"; return VGS_E_ARG; }
   box_from_state(g, (double)c->P.voxel_size, c->box);
   c->grid_pinned = true;
+  c->grid_covers = false;
   if (c->stage > ST_POINTS) c->stage = ST_POINTS;
   return VGS_OK;
+}
+
+vgs_status vgs_set_grid_covering(vgs_ctx* c, const vgs_grid_state* g) {
+  vgs_status s = vgs_set_grid(c, g);
+  if (s == VGS_OK) c->grid_covers = true;
+  return s;
 }
 
 vgs_status vgs_set_owned_region(vgs_ctx* c, const double* lo, const double* hi) {

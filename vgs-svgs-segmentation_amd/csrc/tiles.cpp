@@ -413,7 +413,7 @@ static vgs_status chain_grid(vgs_tiles* t, vgs_status& carry) {
     if (buf[8] != 0.0) return agreed(t, carry, r, "grid");
     unpack(g, buf);
   }
-  TCARRY(vgs_set_grid(t->ctx, &g));   // a failure here travels with the boundary records
+  TCARRY(vgs_set_grid_covering(t->ctx, &g));   // (every rank's cloud went into g, scanned or by its bounding box) a failure here travels with the boundary records
   return VGS_OK;
 }
 

@@ -141,6 +141,7 @@ struct vgs_ctx {
   // octree
   OctreeBox box;
   bool grid_pinned = false;
+  bool grid_covers = false;   // ... and the caller vouches that it covers every finite point of the current cloud (vgs_set_grid_covering): no scan
   int n_epochs = 0;   // growth epochs of the last voxelize (the epochs themselves stay in grow_state on the device)
 
   // voxelize
@@ -308,6 +309,11 @@ static inline vgs_status vgs_readback(vgs_ctx* c, void* dst, const void* src_dev
   memcpy(dst, c->pin, bytes);
   return VGS_OK;
 }
+// Longest row of connect bits the kernels hold in LDS: 624 words = a cube of 27 cells a side = balls of up to 13 voxels (the edge list of
+// the smallest one-wavefront class, 312 keys of 8 bytes, is where its row is put together).  Wider balls (up to the engine's own limit
+// of graph_size / voxel_size = 12 ... 15 by rounding) keep crossValidation's search in the neighbour's row.  (Round 4: 256 words, 9 voxels --
+// config 2's ball of ten fell back silently.)
+#define VGS_CB_MAX_WORDS 624
 // bit of the lattice offset p (packed (dx+16) | (dy+16) << 5 | (dz+16) << 10, as the rows' adj_off holds it) in a row of connect bits
 #ifdef __HIPCC__
 __device__ __forceinline__ uint32_t vgs_cb_index(uint32_t p, int R) {

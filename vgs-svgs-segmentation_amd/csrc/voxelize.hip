@@ -274,6 +274,12 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   for (int a = 0; a < 3; ++a) { h.min[a] = box.min[a]; h.max[a] = box.max[a]; h.shift[a] = box.shift[a]; }
   h.res = box.res; h.depth = box.depth; h.defined = box.defined ? 1 : 0;
   h.found = ~0ull; h.start = 0; h.record = record_epochs ? 1 : 0;
+  const size_t hb_bytes = offsetof(GrowState, epochs) + sizeof(Epoch);
+  // The caller pinned a grid it has itself replayed over this very cloud or over its bounding box (vgs_set_grid_covering: the tiled
+  // driver, every step): nothing can grow and nothing needs checking -- the sixteen launches and the read-back of the scan below are
+  // 0.2 ms of a tile's step -- so the device gets the final state as it is: one epoch from the first point on, growth done.
+  const bool covering = c->grid_pinned && c->grid_covers && record_epochs && box.defined;
+  if (covering) h.done = 1;
   if (record_epochs && box.defined) {
     Epoch& e = h.epochs[h.n_epochs++];
     e.first = 0;
@@ -282,11 +288,15 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   {
     // header + the epoch a pinned grid starts with; through the pinned scratch when there is one (a copy out of pageable memory is
     // staged by the runtime and holds the stream's first kernel back by tens of microseconds)
-    const size_t hb = offsetof(GrowState, epochs) + sizeof(Epoch);
+    const size_t hb = hb_bytes;
     static_assert(offsetof(GrowState, epochs) + sizeof(Epoch) <= 1024, "the growth header fits its slot of the pinned scratch");
     const void* src = &h;
     if (c->pin) { memcpy((char*)c->pin + 1024, &h, hb); src = (char*)c->pin + 1024; }
     VGS_HIP_TRY(c, hipMemcpyAsync(d_g, src, hb, hipMemcpyHostToDevice, c->stream));
+  }
+  if (covering) {   // (the state just uploaded is final)
+    c->n_epochs = h.n_epochs;
+    return VGS_OK;
   }
   // (Round 4 measured the scan and the one-thread growth kernel as ONE launch -- the last workgroup through its scan replays the
   // growth: eight launches instead of sixteen, but the double-precision growth code inflates the scan kernel's registers and the
