@@ -38,15 +38,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-# measured on this pool with tools/valu_roof.hip (hand-placed registers; profiles/r04_valu_roof.txt): a SIMD issues one wave64 VALU
-# instruction per 2.2 cycles = 0.92 ns at 2.39 GHz for the full-rate classes (v_add/mul/fmac/mov/and, v_fma_f32 with its sources in
-# three VGPR banks) -- the guide's 2 cycles -- and one per 4.08 cycles = 1.71 ns for the half-rate ones (every v_cmp, v_cndmask with an
-# SGPR mask, DPP moves, v_readlane, shifts, v_bfe, v_mul_lo, v_mad_u32_u24, v_cvt, any VOP3 with two sources in one bank or an SGPR
-# source).  Round 3's 1.23 ns came from compiler-placed registers with bank conflicts.  The kernel's instructions are a mix of both
-# classes and the counters do not separate them (SQ_ACTIVE_INST_VALU books one quad-cycle per instruction whatever it costs), so the
-# issue utilisation is reported as a range: every instruction at the full rate (lower bound) and at the half rate (upper bound).
-VALU_NS_PER_WAVE_INSTR = 0.92
-VALU_NS_PER_WAVE_INSTR_HALF_RATE = 1.71
+# VALU issue rates measured on this pool with tools/valu_roof.hip (hand-placed registers; profiles/r04_valu_roof.txt): a SIMD issues
+# one wave64 VALU instruction per 2.2 cycles for the full-rate classes, per 4.1 cycles for the half-rate ones (every compare, select,
+# DPP form, v_readlane, shift, bit-field op, integer multiply, conversion, any VOP3 with an SGPR source or two sources in one VGPR bank)
+# and per 8.1 cycles for transcendentals.  The counters do not separate the classes, so ONE figure is made of the two things that
+# exist (tools/valu_mix.py -> profiles/rNN_valu_mix.json): the static full/half/quarter mix of each phase of the bulk kernel's ISA x
+# the dynamic SQ_INSTS_VALU of that phase (tools/pmc_phases.sh) = mean issue cycles per instruction; valu_issue_frac = instructions
+# per launch x that mean / 2.39 GHz / 1024 SIMDs / the kernel's duration of THIS run.
+VALU_CLOCK_GHZ = 2.39
 N_SIMD = 1024
 
 
@@ -135,19 +134,28 @@ def cpu_baseline(xyz_full, params, n_all_full, point_voxel, frac=0.05):
 
 def profiled_traffic(n_points):
     """HBM bytes (and VALU wave instructions) per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/rNN_traffic.json, written by tools/collect_profiles.sh from FETCH_SIZE + WRITE_SIZE of the same bench command);
-    None if the profile is missing or was taken on another workload."""
+    (profiles/rNN_traffic.json, written by tools/collect_round.sh from FETCH_SIZE + WRITE_SIZE of the same bench command), the
+    commit they were taken at, and the kernel's mean issue cycles per VALU instruction (profiles/rNN_valu_mix.json);
+    None if a profile is missing or was taken on another workload."""
     prof = os.path.join(ROOT, "profiles")
-    for tag in ("r04", "r03", "r02", "r01"):   # the newest round's profile that exists
+    for tag in ("r05", "r04", "r03", "r02", "r01"):   # the newest round's profile that exists
         try:
             with open(os.path.join(prof, f"{tag}_traffic.json")) as f:
                 t = json.load(f)
             if int(t.get("points", -1)) != int(n_points):
                 continue
-            return float(t["hbm_bytes_per_launch"]), t.get("valu_wave_instructions_per_launch"), f"profiles/{tag}_traffic.json"
+            mix = None
+            try:
+                with open(os.path.join(prof, f"{tag}_valu_mix.json")) as f:
+                    mix = json.load(f)
+            except (OSError, ValueError):
+                pass
+            return {"bytes": float(t["hbm_bytes_per_launch"]), "valu": t.get("valu_wave_instructions_per_launch"), "source": f"profiles/{tag}_traffic.json",
+                    "commit": t.get("commit"), "cycles_per_instr": mix.get("mean_cycles_per_instruction") if mix else None,
+                    "mix_source": f"profiles/{tag}_valu_mix.json" if mix else None, "mix_commit": mix.get("commit") if mix else None}
         except (OSError, ValueError, KeyError):
             continue
-    return None, None, None
+    return None
 
 
 def dry_run(args, world, rank):
@@ -483,10 +491,12 @@ def main():
         alg_bytes = int(alg_run * (c["class_a"] / max(c["used"], 1)))
         k_avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        traffic, valu, traffic_src = profiled_traffic(N) if (world == 1 and not native) else (None, None, None)
-        # the kernel works on-chip (VALU issue + LDS latency): its VALU wave instructions at the measured issue peak of a SIMD
-        valu_frac = (valu * VALU_NS_PER_WAVE_INSTR * 1e-9 / N_SIMD) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
-        valu_frac_hi = (valu * VALU_NS_PER_WAVE_INSTR_HALF_RATE * 1e-9 / N_SIMD) / (k_avg_ms * 1e-3) if (valu and k_avg_ms > 0) else None
+        prof = profiled_traffic(N) if (world == 1 and not native) else None
+        traffic, traffic_src = (prof["bytes"], prof["source"]) if prof else (None, None)
+        # the kernel works on-chip (VALU issue + LDS latency): its VALU wave instructions at the issue cost of ITS OWN instruction mix
+        valu_frac = None
+        if prof and prof["valu"] and prof["cycles_per_instr"] and k_avg_ms > 0:
+            valu_frac = (prof["valu"] * prof["cycles_per_instr"] / (VALU_CLOCK_GHZ * 1e9) / N_SIMD) / (k_avg_ms * 1e-3)
         sm = sorted(step_ms)
         out = {
             "metric": "segmented points/sec (end-to-end VGS)",
@@ -510,8 +520,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,448,1> (local affinity graph + threshold-merge cut, bulk class)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
-                         "valu_issue_frac": valu_frac, "valu_peak_ns_per_wave_instr_per_simd": VALU_NS_PER_WAVE_INSTR,
-                         "valu_issue_frac_if_all_half_rate": valu_frac_hi,
+                         "traffic_commit": prof["commit"] if prof else None,
+                         "valu_issue_frac": valu_frac, "valu_cycles_per_wave_instr": prof["cycles_per_instr"] if prof else None,
+                         "valu_mix_source": prof["mix_source"] if prof else None, "valu_mix_commit": prof["mix_commit"] if prof else None,
                          "algorithmic_bytes_per_step": alg_run,
                          "end_to_end_frac": alg_run / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "pair_evals_per_s": c["pairs"] / (k_avg_ms * 1e-3) if k_avg_ms > 0 else 0.0},

@@ -20,7 +20,7 @@ This script multiplies the two things that exist:
   issue cycles = sum over phases of count(phase) * (f_full * 2.2 + f_half * 4.1 + f_quarter * 8.1); valu_issue_frac = issue time on
   1024 SIMDs / kernel time.
 
-usage: tools/valu_mix.py <pmc_phases.txt> <kernel_ms> [out.json]     (CPU: compiles csrc/localcut.hip device-only to assembly)"""
+usage: tools/valu_mix.py <pmc_phases.txt> <kernel_ms> [out.json] [commit]     (CPU: compiles csrc/localcut.hip device-only to assembly)"""
 import json
 import os
 import re
@@ -96,6 +96,7 @@ def source_ranges():
 def main():
     phases_txt, kernel_ms = sys.argv[1], float(sys.argv[2])
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "lc.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-ffp-contract=off",
@@ -144,7 +145,7 @@ def main():
     cycles = sum(d[p] * sum(pm[p][k] * CYC[k] for k in CYC) for p in d)
     total = sum(d.values())
     issue_s = cycles / (CLOCK_GHZ * 1e9) / N_SIMD
-    res = {"kernel": "k_localcut_wave<96,448,1>", "valu_wave_instructions_per_launch": total, "kernel_ms": kernel_ms,
+    res = {"kernel": "k_localcut_wave<96,448,1>", "commit": commit, "valu_wave_instructions_per_launch": total, "kernel_ms": kernel_ms,
            "static_instructions": {p: static.get(p) for p in sorted(static)}, "dynamic_per_phase": d, "mix_per_phase": pm,
            "mean_cycles_per_instruction": cycles / total, "valu_issue_frac": issue_s / (kernel_ms * 1e-3),
            "share_half_or_slower_dynamic": sum(d[p] * (pm[p]["half"] + pm[p]["quarter"]) for p in d) / total,
