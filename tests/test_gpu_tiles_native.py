@@ -107,6 +107,30 @@ def test_a_failing_rank_takes_its_peers_out_with_it(gpu, monkeypatch, phase):
     assert isinstance(out[0], gpu.VgsError) and "VGS_E_PEER" in str(out[0]) and "rank 1" in str(out[0]), out[0]
 
 
+def test_a_failed_upload_travels_with_the_next_collective(gpu, monkeypatch):
+    """Rank 1's upload fails BEHIND the last collective of set_points (injected: VGS_TILES_FAIL_AT=upload).  set_points returns the
+    error there; a caller that goes on to run() all the same joins the grid's collective with that status in its word: it gets its
+    own error again, rank 0 gets VGS_E_PEER, nobody waits."""
+    monkeypatch.setenv("VGS_TILES_FAIL_RANK", "1")
+    monkeypatch.setenv("VGS_TILES_FAIL_AT", "upload")
+    n_per = 60_000
+    pitch = 50.0 * np.sqrt(n_per / 10_000_000)
+    parts = [gpu.scenes.tiled_urban_scene(n_per * 2, tiles=(2, 1), tile_index=r) for r in range(2)]
+    seen = [None, None]
+
+    def body(r, t, xyz):
+        try:
+            t.set_points(xyz)
+        except gpu.VgsError as ex:
+            seen[r] = str(ex)
+        t.run()
+        return "finished"
+    out = _two_rank_threads(gpu, parts, pitch, body)
+    assert seen[0] is None and seen[1] is not None and "upload" in seen[1], seen
+    assert isinstance(out[1], gpu.VgsError) and "VGS_E_STATE" in str(out[1]), out[1]
+    assert isinstance(out[0], gpu.VgsError) and "VGS_E_PEER" in str(out[0]) and "rank 1" in str(out[0]), out[0]
+
+
 def test_strict_region_refuses_points_outside_the_rank(gpu):
     """VGS_TILES_OPT_STRICT_REGION: a rank that holds points beyond its region makes every rank refuse the cloud (by default it is
     a warning on stderr and a count in vgs_tiles_get_info)."""

@@ -548,13 +548,21 @@ vgs_status vgs_stage_adjacency(vgs_ctx* c) {
     // The row tables are dense: U rows x (lattice offsets of the search ball) slots -- sorted keys 8 B, lattice offsets 2 B and the
     // connect / mutual flags of the local-cut stage 2 B per slot.  2.6 GB at the 10 M-point config, but U x 4189 x 12 B at
     // a ball of ten voxels: say so BEFORE allocating, in terms the caller can act on, instead of failing inside some hipMalloc.
-    const double need = (double)U * (double)c->adj_stride * 12.0;
-    const double held = (double)c->adj_key.cap * 8.0 + (double)c->adj_off.cap * 2.0 + (double)c->conn.cap;
+    // ... plus what the local-cut stage allocates per run whatever the scene: connect bits (cb_words 4-byte words per row), the group
+    // table, work lists (16 ids per used voxel), counters per voxel, the near-pair lists (16 entries of 16 B per voxel) and the pair
+    // lists' state.  (The pair lists' pool grows with the scene and is not in here; the check is ADVISORY -- free memory is read at
+    // this instant and a caching allocator of the same process holds memory it does not show -- and VGS_HIP_TRY's mapping of
+    // hipErrorOutOfMemory to VGS_E_NOMEM remains the backstop.)
+    const double fixed_rows = (double)U * ((double)(c->cb_words > 0 && c->cb_words <= VGS_CB_MAX_WORDS ? c->cb_words : 0) * 4.0 + (double)c->adj_gstride * 2.0 + 16.0 * 4.0 + 32.0)
+                              + (double)V * (16.0 * 16.0 + 8.0 + 10.0);
+    const double need = (double)U * (double)c->adj_stride * 12.0 + fixed_rows;
+    const double held = (double)c->adj_key.cap * 8.0 + (double)c->adj_off.cap * 2.0 + (double)c->conn.cap + (double)c->conn_bits.cap * 4.0 +
+                        (double)c->adj_gtab.cap * 2.0 + (double)c->work_ids.cap * 4.0 + (double)c->nl_ent.cap * 16.0 + (double)c->pl_state.cap;
     size_t free_b = 0, total_b = 0;
     VGS_HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
     if (need > held + (double)free_b * 0.97) {
       char msg[512];
-      snprintf(msg, sizeof(msg), "adjacency / connect tables need %.1f GB (%lld used voxels x %d lattice offsets of a search ball of %.1f voxels x 12 B) "
+      snprintf(msg, sizeof(msg), "adjacency / connect tables need %.1f GB (%lld used voxels x %d lattice offsets of a search ball of %.1f voxels x 12 B, + per-voxel lists) "
                "but %.1f GB are free on the device (%.1f GB in all): lower graph_size / voxel_size, or split the cloud into spatial tiles (include/vgs_tiles.h)",
                need / 1e9, (long long)U, c->adj_stride, (double)(c->P.graph_size / c->P.voxel_size), ((double)free_b + held) / 1e9, (double)total_b / 1e9);
       c->err = msg;

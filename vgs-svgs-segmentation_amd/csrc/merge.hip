@@ -503,7 +503,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     // atomic each, and the unions behind it would find nothing final: both return at once, and the plain pass over all rows follows
     // below, behind the hand-over kernels.)
     const LcGate g_first = {(c->lc_tail.open && c->lc_tail.gated) ? (const unsigned int*)(c->counters.p + 57) : (const unsigned int*)nullptr, LC_FEW};
-    hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
+    const size_t first_lds = (c->lc_tail.open && c->K.cross_lds_kb > 0) ? (size_t)c->K.cross_lds_kb * 1024 : 0;
+    hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), first_lds, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                        c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0,
                        cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr, g_first);
@@ -513,7 +514,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       // was not put off.  The rows put off follow behind their second crossValidation pass, without a first hook (their parents
       // may have moved by then).
       hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
-      hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
+      hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), first_lds, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0, g_first);
       compressed = true; united = true;
     }

@@ -209,7 +209,8 @@ struct vgs_tiles {
   int64_t own_first = 0, n_own = 0, n_outside = 0, n_records = 0, kept = 0;
   double times[VGS_TILES_T_COUNT] = {0};   // last run, milliseconds of host wall time per phase (vgs_tiles_get_times)
   int strict_region = 0;      // VGS_TILES_OPT_STRICT_REGION
-  int fail_phase = 0;         // tests (VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT): 1 grid, 2 stages, 3 points
+  int fail_phase = 0;         // tests (VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT): 1 grid, 2 stages, 3 points, 4 upload (behind the last collective of set_points)
+  vgs_status pending = VGS_OK;   // a local failure behind a call's last collective: the status word of the next collective carries it
   bool warned_outside = false;
   std::string err;
 };
@@ -260,7 +261,7 @@ vgs_status vgs_tiles_create(const vgs_params* p, int comm_kind, void* comm_handl
     // failure injection for the tests of the agreed-status protocol; read once, here
     const char* fr = std::getenv("VGS_TILES_FAIL_RANK");
     const char* fa = std::getenv("VGS_TILES_FAIL_AT");
-    if (fr && fa && std::atoi(fr) == rank) t->fail_phase = !std::strcmp(fa, "grid") ? 1 : !std::strcmp(fa, "stages") ? 2 : !std::strcmp(fa, "points") ? 3 : 0;
+    if (fr && fa && std::atoi(fr) == rank) t->fail_phase = !std::strcmp(fa, "grid") ? 1 : !std::strcmp(fa, "stages") ? 2 : !std::strcmp(fa, "points") ? 3 : !std::strcmp(fa, "upload") ? 4 : 0;
   }
   vgs_status s = vgs_create(p, &t->ctx);
   if (s != VGS_OK) { delete t->comm; delete t; return s; }
@@ -358,12 +359,18 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
   for (int64_t k = 0; k < n; ++k) { t->local.push_back(xyz[k * sf]); t->local.push_back(xyz[k * sf + 1]); t->local.push_back(xyz[k * sf + 2]); }
   for (int r = c.rank + 1; r < c.world; ++r) take_strip(r);
   t->n_own = n;
-  // failures from here on are local and no collective follows inside this call: the next one (the grid's) is in vgs_tiles_run,
-  // which this rank's caller does not reach
-  TCTX(vgs_set_points(t->ctx, t->local.data(), (int64_t)(t->local.size() / 3), 12));
-  TCTX(vgs_set_owned_region(t->ctx, t->lo, t->hi));
-  TCTX(vgs_set_own_point_range(t->ctx, t->own_first, t->n_own));
-  return VGS_OK;
+  // failures from here on are local and no collective follows inside this call: the rank returns its error AND keeps it
+  // (t->pending), so that a caller who goes on to vgs_tiles_run all the same joins the grid's collective with that status in its
+  // word instead of leaving its peers inside it
+  t->pending = VGS_OK;
+  auto local_step = [&](vgs_status s, const char* what) {
+    if (s != VGS_OK && t->pending == VGS_OK) { t->pending = s; t->err = std::string(what) + ": " + vgs_last_error_string(t->ctx); }
+  };
+  if (t->fail_phase == 4) { t->pending = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=upload"; }
+  if (t->pending == VGS_OK) local_step(vgs_set_points(t->ctx, t->local.data(), (int64_t)(t->local.size() / 3), 12), "vgs_set_points");
+  if (t->pending == VGS_OK) local_step(vgs_set_owned_region(t->ctx, t->lo, t->hi), "vgs_set_owned_region");
+  if (t->pending == VGS_OK) local_step(vgs_set_own_point_range(t->ctx, t->own_first, t->n_own), "vgs_set_own_point_range");
+  return t->pending;
 }
 
 // The shared grid: what inserting the ranks' clouds one after the other does to the octree box.  One all-gather
@@ -420,7 +427,7 @@ static vgs_status chain_grid(vgs_tiles* t, vgs_status& carry) {
 vgs_status vgs_tiles_run(vgs_tiles* t) {
   if (!t) return VGS_E_ARG;
   Comm& c = *t->comm;
-  vgs_status carry = VGS_OK;
+  vgs_status carry = t->pending;   // a local failure behind the last collective of the previous call (upload, label write-back) travels now
   double t0 = now_ms();
   vgs_status s = chain_grid(t, carry);
   if (s != VGS_OK) return s;
@@ -486,9 +493,12 @@ vgs_status vgs_tiles_run(vgs_tiles* t) {
   std::vector<int32_t>& br = uroot[(size_t)c.rank];
   std::vector<int32_t>& bl = ulabel[(size_t)c.rank];
   int32_t dummy = 0;
-  // (a failure here is local and the run's last collective is behind us: this rank returns it, the caller's process exits
-  // non-zero, and the peers -- whose results are complete -- meet that at their next collective or at the launcher)
-  TCTX(vgs_apply_tile_labels(t->ctx, (int32_t)base[(size_t)c.rank], br.empty() ? &dummy : br.data(), bl.empty() ? &dummy : bl.data(), (int64_t)br.size()));
+  // (a failure here is local and the run's last collective is behind us: this rank returns it and keeps it in t->pending; the
+  // peers -- whose results are complete -- see it in the status word of the next run's first collective, or at the launcher)
+  {
+    vgs_status sa = vgs_apply_tile_labels(t->ctx, (int32_t)base[(size_t)c.rank], br.empty() ? &dummy : br.data(), bl.empty() ? &dummy : bl.data(), (int64_t)br.size());
+    if (sa != VGS_OK) { t->pending = sa; return tfail(t, sa, std::string("vgs_apply_tile_labels: ") + vgs_last_error_string(t->ctx)); }
+  }
   double t6 = now_ms();
   t->times[VGS_TILES_T_LABELS] = t6 - t5;
   t->times[VGS_TILES_T_TOTAL] = t6 - t0;

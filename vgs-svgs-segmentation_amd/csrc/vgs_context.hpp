@@ -93,6 +93,8 @@ struct VgsKnobs {
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
+  int cross_lds_kb = 0;          // VGS_CROSS_LDS: KB of (unused) LDS per wavefront of crossValidation's FIRST pass and its unions -- caps how many
+                                 // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
