@@ -1,0 +1,39 @@
+"""How much of the independent leg's tolerance (tests/test_gpu_vccs.py: >= 80 % of the voxels in matching supervoxels) is arithmetic and
+how much is the algorithm ("nobody measured").  CPU only, oracle only: the float restatement the GPU equals label for label
+(oracle/refcpu_vccs.cpp) against the double + libm leg (oracle/refcpu_vccs_ref.cpp), and each of them against ITSELF on the same cloud
+with every coordinate moved by a micrometre (sigma 1e-6 m, three orders below the scene's range noise).
+
+Measured (120 k-point urban scene, Task_File_SVGS.txt parameters): float vs double 0.88; double vs jittered double 0.86; float vs
+jittered float 0.81.  Changing the arithmetic moves FEWER voxels between supervoxels than a micrometre of input noise does: 54 rounds of
+nearest-seed decisions on a lattice, re-seeded five times, amplify any flip, whatever caused it.  The tolerance is the algorithm's
+conditioning, not drift of the float restatement; it cannot be raised by better arithmetic."""
+import numpy as np
+
+from helpers import oracle_params, p2_protocol
+
+
+def _agree(a, b, pv):
+    return p2_protocol(a.astype(np.int64) - 1, b.astype(np.int64) - 1, pv, min_voxels=10 ** 9)["agreement"]
+
+
+def test_arithmetic_moves_fewer_voxels_than_a_micrometre_of_noise(oracle, vgs):
+    xyz = vgs.scenes.urban_scene(120_000)
+    p = vgs.default_params(3)
+    op = oracle_params(oracle, p)
+    f, fmax = oracle.vccs(xyz, op)
+    d, dmax = oracle.vccs_refmath(xyz, op)
+    assert fmax == dmax
+    pv = oracle.voxelize(xyz, p.voxel_size).voxel_table()["point_voxel"]
+    float_vs_double = _agree(f, d, pv)
+    rng = np.random.default_rng(0)
+    xj = (xyz + rng.normal(0, 1e-6, xyz.shape)).astype(np.float32)
+    fj, fjmax = oracle.vccs(xj, op)
+    dj, djmax = oracle.vccs_refmath(xj, op)
+    assert fjmax == fmax and djmax == dmax          # (the same seed cells are occupied)
+    double_vs_itself = _agree(d, dj, pv)            # (p2_protocol asserts that the points of a voxel still share a label: same binning)
+    float_vs_itself = _agree(f, fj, pv)
+    print(f"float vs double {float_vs_double:.3f}; double vs jittered double {double_vs_itself:.3f}; float vs jittered float {float_vs_itself:.3f}")
+    assert float_vs_double >= 0.80                  # the GPU test's bar, on the CPU pair
+    # the switch of arithmetic is no worse than a micrometre of noise (0.03: the spread between seeds of the jitter)
+    assert float_vs_double >= min(double_vs_itself, float_vs_itself) - 0.03
+    assert max(double_vs_itself, float_vs_itself) < 0.95   # (if this ever holds the algorithm has become well conditioned: raise the bars)

@@ -1093,7 +1093,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       // marked and built behind it (a few thousand), and k_localcut_pg reads them
       uint32_t* const ids_tp = c->work_ids.p + (11 + LW_HO_BINS) * U;
       unsigned int* const d_ntp = (unsigned int*)(c->counters.p + 47);
-      const bool to_pg = !c->K.no_dense_to_pg;
+      const bool to_pg = c->K.dense_to_pg;   // (measured on URB10M: no gain from it, and its chain of launches sits behind the dense kernel)
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few, to_pg ? ids_tp : (uint32_t*)nullptr, d_ntp);
       if (to_pg) {

@@ -356,9 +356,14 @@ __global__ void k_flatten(uint32_t* __restrict__ parent, int64_t V, const uint8_
   if (v >= V) return;
   const uint32_t r = uf_root(parent, (uint32_t)v);
   __hip_atomic_store(&parent[v], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address)
-  unsigned long long todo = __ballot(!owned || owned[v]);   // tiled runs count owned voxels only
-  if (owned && !owned[v]) return;
+  // one atomic per distinct root per wavefront (large segments would otherwise serialise on one address).  A voxel that is its own
+  // root counts itself on its own: half of a scanned scene's voxels are unused singletons, 64 distinct roots per wavefront, and
+  // walked the loop below 64 times (round 5)
+  const bool counted = !owned || owned[v];   // tiled runs count owned voxels only
+  const bool self = r == (uint32_t)v;
+  if (counted && self) atomicAdd(&csz[r], 1u);
+  unsigned long long todo = __ballot(counted && !self);
+  if (!counted || self) return;
   const int lane = threadIdx.x & 63;
   while (todo) {
     const int l0 = __ffsll((long long)todo) - 1;

@@ -102,7 +102,8 @@ struct VgsKnobs {
   bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
   int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
   int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
-  bool no_dense_to_pg = false;   // VGS_NO_DENSE_TO_PG: the dense hand-over kernel takes its overflowing neighbourhoods in bands itself
+  bool dense_to_pg = false;      // VGS_DENSE_TO_PG: the dense hand-over kernel queues its overflowing neighbourhoods for the pair-list kernel (off: five
+                                 // launches on the step's critical path for a handful of voxels; it takes them in bands itself)
   int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
   int pg_wide_frac = 8;      // VGS_PG_WIDEFRAC: ... when they are more than 1/N of the used voxels
   bool debug = false;        // VGS_DEBUG
