@@ -74,9 +74,31 @@ struct Octree {
 };
 }  // namespace
 
-void build_voxel_table(const float* xyz, int64_t n, int stride, float voxel_size, VoxelTable& T) {
+static void build_voxel_table_impl(const float* xyz, int64_t n, int stride, float voxel_size, VoxelTable& T, bool bbox_first);
+void build_voxel_table(const float* xyz, int64_t n, int stride, float voxel_size, VoxelTable& T) { build_voxel_table_impl(xyz, n, stride, voxel_size, T, false); }
+// pcl::octree::OctreePointCloudAdjacency::addPointsFromInputCloud (the octree pcl::SupervoxelClustering builds for itself, SS:265-284;
+// PCL 1.8.1, recalled -- unpinned like B.1): the bounding box of the finite points is computed first (float min / max) and handed to
+// defineBoundingBox, whose getKeyBitSize on the still empty tree pads it symmetrically to the cube of 2^depth voxels (the same code
+// that pads the box around the first point above); then the points are inserted as in B.1, growth included should one not fit.
+void build_voxel_table_bbox(const float* xyz, int64_t n, int stride, float voxel_size, VoxelTable& T) { build_voxel_table_impl(xyz, n, stride, voxel_size, T, true); }
+static void build_voxel_table_impl(const float* xyz, int64_t n, int stride, float voxel_size, VoxelTable& T, bool bbox_first) {
   Octree oc;
   oc.res = (double)voxel_size;  // ctor takes double(voxel_size) (T:51, VS:84)
+  if (bbox_first) {
+    float mn[3] = {3.4028235e38f, 3.4028235e38f, 3.4028235e38f}, mx[3] = {-3.4028235e38f, -3.4028235e38f, -3.4028235e38f};
+    bool any = false;
+    for (int64_t i = 0; i < n; ++i) {
+      const float* p = xyz + i * stride;
+      if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+      any = true;
+      for (int a = 0; a < 3; ++a) { mn[a] = p[a] < mn[a] ? p[a] : mn[a]; mx[a] = p[a] > mx[a] ? p[a] : mx[a]; }
+    }
+    if (any) {
+      for (int a = 0; a < 3; ++a) { oc.min[a] = (double)mn[a]; oc.max[a] = (double)mx[a]; }
+      oc.key_bit_size_first();
+      oc.defined = true;
+    }
+  }
   // addPointsFromInputCloud: points in index order; non-finite points skipped.  Each point's key is
   // generated with the bounding box AS IT IS WHEN THE POINT IS INSERTED (genOctreeKeyforPoint); every
   // later growth step that lowers min on an axis re-roots the tree with the old root in the upper
@@ -85,6 +107,7 @@ void build_voxel_table(const float* xyz, int64_t n, int stride, float voxel_size
   std::vector<uint32_t> pk((size_t)n * 3, 0);
   std::vector<uint64_t> pshift;  // 3 per epoch
   std::vector<int> pepoch((size_t)n, -1);
+  if (oc.defined) { pshift.push_back(oc.shift[0]); pshift.push_back(oc.shift[1]); pshift.push_back(oc.shift[2]); }   // (bbox_first: the box exists before the first point)
   for (int64_t i = 0; i < n; ++i) {
     const float* p = xyz + i * stride;
     if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;

@@ -68,6 +68,7 @@ struct VoxelTable {
 };
 
 void build_voxel_table(const float* xyz, int64_t n, int stride_floats, float voxel_size, VoxelTable& T);
+void build_voxel_table_bbox(const float* xyz, int64_t n, int stride_floats, float voxel_size, VoxelTable& T);   // OctreePointCloudAdjacency: box from the cloud's bounding box
 
 // ------------------------------ features (A.2) --------------------------------------------
 void compute_node(const float* xyz, int stride_floats, const int* idx, int count, int math, bool svgs, Node& out);

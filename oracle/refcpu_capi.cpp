@@ -59,6 +59,14 @@ void* ref_voxelize(const float* xyz, int64_t n, int stride_floats, float voxel_s
   return h;
 }
 
+// the adjacency octree of pcl::SupervoxelClustering: box defined from the cloud's bounding box (vccs_mode 1)
+void* ref_voxelize_bbox(const float* xyz, int64_t n, int stride_floats, float voxel_size) {
+  RefHandle* h = new RefHandle();
+  h->kind = 0; h->n = n;
+  build_voxel_table_bbox(xyz, n, stride_floats, voxel_size, h->vgs.T);
+  return h;
+}
+
 // VCCS-style supervoxel stage: labels (N ints, 0 = unassigned); returns max_label
 int ref_vccs(const float* xyz, int64_t n, int stride_floats, const RefParamsC* p, int* labels) {
   std::vector<int> lab;

@@ -62,6 +62,8 @@ def lib():
         L.ref_svgs_run_from_labels.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.POINTER(RefParams)]
         L.ref_voxelize.restype = C.c_void_p
         L.ref_voxelize.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
+        L.ref_voxelize_bbox.restype = C.c_void_p
+        L.ref_voxelize_bbox.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float]
         L.ref_vccs.restype = C.c_int
         L.ref_vccs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_vccs_refmath.restype = C.c_int
@@ -205,9 +207,11 @@ def vccs_pcl(xyz, params):
     return lab, int(mx)
 
 
-def voxelize(xyz, voxel_size):
+def voxelize(xyz, voxel_size, bbox_first=False):
+    """bbox_first: the octree pcl::SupervoxelClustering builds for itself (box defined from the cloud's bounding box; vccs_mode 1)."""
     xyz = _xyz(xyz)
-    h = lib().ref_voxelize(_p(xyz), xyz.shape[0], xyz.shape[1], C.c_float(voxel_size))
+    f = lib().ref_voxelize_bbox if bbox_first else lib().ref_voxelize
+    h = f(_p(xyz), xyz.shape[0], xyz.shape[1], C.c_float(voxel_size))
     return Result(h, xyz.shape[0], 0)
 
 

@@ -150,7 +150,7 @@ void vccs_supervoxels(const float* xyz, int64_t n, int stride, const Params& P, 
 // are integer fixed point (order-free on the GPU).
 void vccs_pcl_supervoxels(const float* xyz, int64_t n, int stride, const Params& P, std::vector<int>& label, int& max_label) {
   VoxelTable T;
-  build_voxel_table(xyz, n, stride, P.voxel_size, T);
+  build_voxel_table_bbox(xyz, n, stride, P.voxel_size, T);   // the adjacency octree's own lattice (round 5): box from the cloud's bounding box
   const int V = T.V();
   label.assign((size_t)n, 0);
   max_label = 0;
@@ -295,14 +295,39 @@ void vccs_pcl_supervoxels(const float* xyz, int64_t n, int stride, const Params&
     for (int a = 0; a < 3; ++a) { sc[3 * k + a] = cen[3 * seeds[k] + a]; sn[3 * k + a] = nrm[3 * seeds[k] + a]; }
   }
   expand_all();
-  for (int pass = 0; pass < 5; ++pass) {   // refineSupervoxels(5)
-    std::vector<uint64_t> rk((size_t)K, ~0ull);
+  std::vector<VccsAccu> A1((size_t)V);
+  for (int pass = 0; pass < 5; ++pass) {   // refineSupervoxels(5): refineNormals of every supervoxel, reseedSupervoxels, expandSupervoxels
+    // SupervoxelHelper::refineNormals: the normal of every leaf again, from the leaves of ITS supervoxel only -- indices = for every
+    // neighbour t of the leaf (itself included) owned by the supervoxel: [t] + the neighbours of t owned by it (round 5)
+    for (int t = 0; t < V; ++t) {
+      vccs_accu_zero(&A1[t]);
+      const int k = owner[t];
+      if (k < 0) continue;
+      for (int o = 0; o < 27; ++o) { const int u = n27[(size_t)27 * t + o]; if (u >= 0 && owner[u] == k) vccs_accu_point(&A1[t], &cen[3 * u]); }
+    }
     for (int v = 0; v < V; ++v) {
-      const int l = owner[v];
-      if (l < 0) continue;
-      const float dx = cen[3 * v] - sc[3 * l], dy = cen[3 * v + 1] - sc[3 * l + 1], dz = cen[3 * v + 2] - sc[3 * l + 2];
-      const uint64_t key = ((uint64_t)vm_bits((dx * dx + dy * dy) + dz * dz) << 32) | (uint64_t)(uint32_t)v;
-      if (key < rk[l]) rk[l] = key;
+      const int k = owner[v];
+      if (k < 0) continue;
+      VccsAccu A;
+      vccs_accu_zero(&A);
+      for (int o = 0; o < 27; ++o) {
+        const int t = n27[(size_t)27 * v + o];
+        if (t < 0 || owner[t] != k) continue;
+        vccs_accu_point(&A, &cen[3 * t]);
+        vccs_accu_add(&A, &A1[t]);
+      }
+      vccs_accu_normal(&A, &cen[3 * v], &nrm[3 * v]);
+    }
+    // reseedSupervoxels: the voxel nearest to the supervoxel's centroid among ALL voxels (vccs_nearest_voxel); supervoxels take their
+    // new seed in label order, so a voxel two of them name goes to the later one (addLeaf overwrites owner_) and the earlier one is left
+    // without a voxel -- removed at the next centroid update.  (PCL keeps the leaf in the earlier helper's own set as well and would let
+    // it expand from a voxel it does not own: not followed.)
+    std::vector<uint64_t> rk((size_t)K, ~0ull);
+    for (int k = 0; k < K; ++k) {
+      if (!alive[k]) continue;
+      const uint32_t kx = vm_axis_key(sc[3 * k], T.min[0], T.resolution), ky = vm_axis_key(sc[3 * k + 1], T.min[1], T.resolution),
+                     kz = vm_axis_key(sc[3 * k + 2], T.min[2], T.resolution);
+      rk[k] = vccs_nearest_voxel(&sc[3 * k], kx, ky, kz, lim, res, find, [&](int v) { return (const float*)&cen[3 * (size_t)v]; });
     }
     std::fill(owner.begin(), owner.end(), -1);
     std::fill(dist.begin(), dist.end(), FMAX);

@@ -99,7 +99,8 @@ def test_end_to_end_matches_oracle_pipeline(run, oracle):
     assert c["clusters"] == ref.clusters_num
 
 
-# ---- vccs_mode 1: pcl::SupervoxelClustering's own order (sequential owners, 2-ring normals, seed rejection) -----------------
+# ---- vccs_mode 1: pcl::SupervoxelClustering's own order (sequential owners, 2-ring normals, seed rejection; round 5: its own lattice,
+# refineNormals, re-seeding by the nearest of ALL voxels) ----------------------------------------------------------------------
 @pytest.fixture(scope="module", params=[("urban", 200_000), ("pc", 120_000), ("town", 150_000)], ids=["urban", "pc", "town"])
 def run_pcl(request, gpu, oracle):
     name, n = request.param
@@ -122,6 +123,24 @@ def test_pcl_order_labels_match_the_sequential_restatement(run_pcl, oracle):
     # the two modes are different algorithms: they must not agree by accident of falling through to the same code
     sync_labels, _ = oracle.vccs(run_pcl["xyz"], oracle_params(oracle, run_pcl["p"]))
     assert (sync_labels != ref_labels).mean() > 0.05
+
+
+def test_pcl_order_bins_on_the_adjacency_octrees_own_lattice(run_pcl, oracle):
+    """vccs_mode 1 (round 5): pcl::SupervoxelClustering's OctreePointCloudAdjacency defines its box from the cloud's bounding box (padded
+    symmetrically to 2^depth voxels) before the first point goes in; the class's own octree grows from the first point.  Supervoxels are
+    unions of voxels: on the bbox-first lattice (the oracle's restatement of it) every voxel's points carry ONE label, on the grown
+    lattice -- the same cells shifted by a fraction of a voxel -- many voxels are split between two supervoxels."""
+    xyz, labels, res = run_pcl["xyz"], run_pcl["labels"], run_pcl["p"].voxel_size
+
+    def mixed(pv):
+        ok = pv >= 0
+        order = np.lexsort((labels[ok], pv[ok]))
+        v, l = pv[ok][order], labels[ok][order]
+        return int(((v[1:] == v[:-1]) & (l[1:] != l[:-1])).sum())
+    own = oracle.voxelize(xyz, res, bbox_first=True).voxel_table()["point_voxel"]
+    grown = oracle.voxelize(xyz, res).voxel_table()["point_voxel"]
+    assert mixed(own) == 0
+    assert mixed(grown) > 100
 
 
 def test_pcl_order_end_to_end(run_pcl, oracle):

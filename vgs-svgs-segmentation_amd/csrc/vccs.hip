@@ -614,25 +614,32 @@ __device__ __forceinline__ int vccs_nbr27(const int32_t* __restrict__ nbr, int64
   return nbr[(int64_t)vccs_index26(dx, dy, dz) * V + v];
 }
 
-__global__ void k_pcl_accu1(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, VccsAccu* __restrict__ A1) {
+// owner == null: computeVoxelData's two-ring normals of every voxel.  owner != null (round 5): SupervoxelHelper::refineNormals -- only the
+// leaves of the voxel's own supervoxel count, in both rings, the voxel itself is not listed up front, an unowned voxel keeps its normal
+__global__ void k_pcl_accu1(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, VccsAccu* __restrict__ A1,
+                            const int32_t* __restrict__ owner) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= V) return;
+  const int k = owner ? owner[t] : 0;
+  if (k < 0) return;
   VccsAccu A;
   vccs_accu_zero(&A);
-  for (int o = 0; o < 27; ++o) { const int u = vccs_nbr27(nbr, V, t, o); if (u >= 0) vccs_accu_point(&A, &cen[3 * (int64_t)u]); }
+  for (int o = 0; o < 27; ++o) { const int u = vccs_nbr27(nbr, V, t, o); if (u >= 0 && (!owner || owner[u] == k)) vccs_accu_point(&A, &cen[3 * (int64_t)u]); }
   A1[t] = A;
 }
 
 __global__ void k_pcl_normals(int64_t V, const int32_t* __restrict__ nbr, const float* __restrict__ cen, const VccsAccu* __restrict__ A1,
-                              float* __restrict__ nrm) {
+                              float* __restrict__ nrm, const int32_t* __restrict__ owner) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
+  const int k = owner ? owner[v] : 0;
+  if (k < 0) return;
   VccsAccu A;
   vccs_accu_zero(&A);
-  vccs_accu_point(&A, &cen[3 * v]);
+  if (!owner) vccs_accu_point(&A, &cen[3 * v]);
   for (int o = 0; o < 27; ++o) {
     const int t = vccs_nbr27(nbr, V, v, o);
-    if (t < 0) continue;
+    if (t < 0 || (owner && owner[t] != k)) continue;
     vccs_accu_point(&A, &cen[3 * (int64_t)t]);
     const VccsAccu B = A1[t];
     vccs_accu_add(&A, &B);
@@ -712,11 +719,28 @@ __global__ void k_pcl_plant_first(const uint32_t* __restrict__ seeds, int K, con
   for (int a = 0; a < 3; ++a) { st[k].c[a] = cen[3 * (int64_t)s + a]; st[k].n[a] = nrm[3 * (int64_t)s + a]; }
 }
 
-// re-seeding: the supervoxel keeps its centroid; its new only leaf is the member voxel that was nearest to it
+// reseedSupervoxels (round 5): the voxel nearest to the supervoxel's centroid among ALL voxels -- PCL asks its kd-tree; here the lattice
+// cells around the centroid's own cell, shell by shell, through the brick table (vccs_common.h: vccs_nearest_voxel).  One thread per
+// supervoxel: three or four shells, a couple of hundred probes.
+__global__ void k_pcl_reseed_nearest(int K, const uint8_t* __restrict__ alive, const VccsState* __restrict__ st, const float* __restrict__ cen,
+                                     const Brick* __restrict__ bricks, uint32_t hbits, int depth, double min_x, double min_y, double min_z, double res_d,
+                                     float res, unsigned long long* __restrict__ seed_key) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  seed_key[k] = ~0ull;
+  if (!alive[k]) return;
+  const float c[3] = {st[k].c[0], st[k].c[1], st[k].c[2]};
+  const uint32_t kx = vm_axis_key(c[0], min_x, res_d), ky = vm_axis_key(c[1], min_y, res_d), kz = vm_axis_key(c[2], min_z, res_d);
+  seed_key[k] = vccs_nearest_voxel(c, kx, ky, kz, 1u << depth, res,
+                                   [&](uint32_t x, uint32_t y, uint32_t z) { bool unused_flag; return brick_find(bricks, hbits, x, y, z, &unused_flag); },
+                                   [&](int v) { return cen + 3 * (int64_t)v; });
+}
+// the supervoxel keeps its centroid; its new only leaf is that voxel.  Supervoxels take their seeds in label order: a voxel that two of them
+// name goes to the later one (atomicMax = the sequential overwrite), the earlier one starts the pass without a voxel
 __global__ void k_pcl_plant_again(const unsigned long long* __restrict__ seed_key, int K, const uint8_t* __restrict__ alive, int32_t* __restrict__ owner) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K || !alive[k] || seed_key[k] == ~0ull) return;
-  owner[(uint32_t)seed_key[k]] = k;
+  atomicMax(&owner[(uint32_t)seed_key[k]], k);
 }
 
 // The offers a voxel gets in one round, folded in label order: the supervoxels < limit that touch it through a live leaf of
@@ -1010,7 +1034,8 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
 }
 // the sums at the start of a pass: every living supervoxel owns exactly its seed voxel
 __global__ void k_pclt_seed_sums(int K, const int32_t* __restrict__ seed_of, const unsigned long long* __restrict__ seed_key, const uint8_t* __restrict__ alive,
-                                 const float* __restrict__ cen, const float* __restrict__ nrm, long long* __restrict__ sums, unsigned int* __restrict__ count) {
+                                 const float* __restrict__ cen, const float* __restrict__ nrm, long long* __restrict__ sums, unsigned int* __restrict__ count,
+                                 const int32_t* __restrict__ owner) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   for (int a = 0; a < 6; ++a) sums[6 * k + a] = 0;
@@ -1018,7 +1043,7 @@ __global__ void k_pclt_seed_sums(int K, const int32_t* __restrict__ seed_of, con
   int64_t v = -1;
   if (seed_of) v = (int64_t)seed_of[k];                                                     // the first pass: the seeds themselves
   else if (alive[k] && seed_key[k] != ~0ull) v = (int64_t)(uint32_t)seed_key[k];            // re-seeding (k_pcl_plant_again)
-  if (v < 0) return;
+  if (v < 0 || (owner && owner[v] != k)) return;                                            // (... lost to a later supervoxel that named the same voxel)
   for (int a = 0; a < 3; ++a) { sums[6 * k + a] = vccs_fix_pos(cen[3 * v + a]); sums[6 * k + 3 + a] = vccs_fix_nrm(nrm[3 * v + a]); }
   count[k] = 1;
 }
@@ -1063,8 +1088,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
                        c->vc_tile_start.p, c->vc_cell.p, (float*)nullptr, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p,
                        (uint2*)c->vc_tile_meta.p, (const uint32_t*)c->vc_tile_of.p, c->vc_nbr_tiles.p);
   }
-  hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p);
-  hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p);
+  hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, (const int32_t*)nullptr);
   // ---- seeds ----
   const float seed = c->P.seed_size, res = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
@@ -1128,15 +1153,18 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
   hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
   if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)seeds, (const unsigned long long*)nullptr, (const uint8_t*)nullptr,
-                                cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+                                cen.p, nrm.p, c->vc_sums.p, c->vc_count.p, (const int32_t*)nullptr);
   for (int pass = 0; pass < 6; ++pass) {
     if (pass > 0) {
-      hipLaunchKernelGGL(k_vccs_fill_u64, dim3(nbK), dim3(TB), 0, c->stream, seed_key, (int64_t)K, ~0ull);
-      hipLaunchKernelGGL(k_vccs_reseed, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], cen.p, state, seed_key);
+      // refineSupervoxels: refineNormals of every supervoxel (from its own leaves), reseedSupervoxels (nearest of all voxels), expansion
+      hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, (const int32_t*)own[cur]);
+      hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, (const int32_t*)own[cur]);
+      hipLaunchKernelGGL(k_pcl_reseed_nearest, dim3(nbK), dim3(TB), 0, c->stream, K, (const uint8_t*)c->vc_alive.p, (const VccsState*)state, cen.p,
+                         (const Brick*)c->hkey.p, c->hbits, c->box.depth, c->box.min[0], c->box.min[1], c->box.min[2], c->box.res, res, seed_key);
       hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
       hipLaunchKernelGGL(k_pcl_plant_again, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, c->vc_alive.p, own[cur]);
       if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)nullptr, (const unsigned long long*)seed_key,
-                                    (const uint8_t*)c->vc_alive.p, cen.p, nrm.p, c->vc_sums.p, c->vc_count.p);
+                                    (const uint8_t*)c->vc_alive.p, cen.p, nrm.p, c->vc_sums.p, c->vc_count.p, (const int32_t*)own[cur]);
     }
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
@@ -1201,6 +1229,37 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
 // ---------------------------------------------------------------- driver
 vgs_status vgs_stage_vccs(vgs_ctx* c) {
   // the class's own octree at voxel_resolution_ (SS:85, test:138-142) provides the VCCS voxels
+  // vccs_mode 1 (round 5): pcl::SupervoxelClustering bins into an octree of its OWN (OctreePointCloudAdjacency), whose box is defined from
+  // the cloud's bounding box before the first point goes in -- defineBoundingBox + getKeyBitSize on the empty tree pad it symmetrically to
+  // the cube of 2^depth voxels -- instead of growing from the first point as the class's octree does.  The box is put together on the host
+  // from the device's bounding box, the growth scan runs over it once (a point on the padded box's upper face still grows it), and the
+  // voxelize stage takes it as a grid that covers the cloud.  Whatever the context had pinned (nothing, outside tiles) comes back after.
+  const bool own_lattice = c->P.vccs_mode == 1;
+  struct Restore {   // (at every way out of the stage: its kernels read c->box until the end)
+    vgs_ctx* c; bool on, pinned, covers; OctreeBox box;
+    ~Restore() { if (on) { c->grid_pinned = pinned; c->grid_covers = covers; if (pinned) c->box = box; } }
+  } restore{c, own_lattice, c->grid_pinned, c->grid_covers, c->box};
+  if (own_lattice) {
+    float bb[6]; int64_t nf = 0;
+    vgs_status sb = vgs_points_bbox(c, bb, &nf);
+    if (sb != VGS_OK) return sb;
+    if (nf > 0) {
+      const double eps = 1.1920928955078125e-07, res = (double)c->P.voxel_size;
+      double mn[3], mx[3];
+      for (int a = 0; a < 3; ++a) { mn[a] = (double)bb[a]; mx[a] = (double)bb[3 + a]; }
+      unsigned mk[3];
+      for (int a = 0; a < 3; ++a) mk[a] = (unsigned)((mx[a] - mn[a]) / res);
+      const unsigned max_voxels = std::max(std::max(std::max(mk[0], mk[1]), mk[2]), 2u);
+      vgs_grid_state g;
+      vgs_grid_state_init(&g);
+      g.depth = (int32_t)std::max(std::min(32u, (unsigned)std::ceil(std::log2((double)max_voxels) - eps)), 0u);
+      const double side = (double)(1u << g.depth) * res - eps;
+      for (int a = 0; a < 3; ++a) g.min[a] = mn[a] - (side - (mx[a] - mn[a])) / 2.0;
+      g.defined = 1;
+      if ((sb = vgs_grid_advance(c, &g)) != VGS_OK) return sb;
+      if ((sb = vgs_set_grid_covering(c, &g)) != VGS_OK) return sb;
+    }
+  }
   vgs_status st0 = vgs_stage_voxelize(c);
   if (st0 != VGS_OK) return st0;
   const int64_t V = c->V, N = c->N;

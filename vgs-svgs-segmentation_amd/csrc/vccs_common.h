@@ -146,4 +146,39 @@ VGS_HD float vccs_seed_min_points(float seed, float res) {
   return 0.05f * (r * r) * 3.1415926536f / (res * res);
 }
 
+// reseedSupervoxels (SupervoxelClustering::reseedSupervoxels, PCL 1.8.1 recalled): the new seed of a supervoxel is the voxel whose
+// centroid is nearest to the supervoxel's centroid among ALL voxels (PCL asks voxel_kdtree_ for one neighbour; FLANN's tie order is
+// replaced by (distance, voxel id)).  Here: the lattice cells around the centroid's own cell, shell by shell (Chebyshev radius r).  A
+// voxel's centroid lies in its cell, the supervoxel's centroid in its own, so everything beyond shell r is at least r * res away: the
+// search ends once the best squared distance is below that bound (less a thousandth of a voxel for the rounding of the means).  Oracle
+// and device run this same procedure, so they agree whatever the coordinates; it IS the nearest of all wherever float means stay within
+// a thousandth of a voxel of their cells.  find(x, y, z) -> voxel id or -1; cen(v) -> pointer to the voxel's centroid.
+VGS_HD bool vccs_shell_settles(float best_d2, int r, float res) {
+  const float bound = (float)r * res - 1.0e-3f * res;
+  return bound > 0.f && best_d2 < bound * bound;
+}
+template <class Find, class Cen>
+VGS_HD unsigned long long vccs_nearest_voxel(const float* c, uint32_t kx, uint32_t ky, uint32_t kz, uint32_t lim, float res, Find find, Cen cen) {
+  unsigned long long best = ~0ull;
+  for (int r = 0; ; ++r) {
+    for (int dz = -r; dz <= r; ++dz)
+      for (int dy = -r; dy <= r; ++dy) {
+        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+        for (int dx = -r; dx <= r; dx += (face || r == 0) ? 1 : 2 * r) {   // inside a slab row only the two end cells belong to the shell
+          const uint32_t x = kx + (uint32_t)dx, y = ky + (uint32_t)dy, z = kz + (uint32_t)dz;   // (below zero wraps above lim)
+          if (!(x < lim && y < lim && z < lim)) continue;
+          const int v = find(x, y, z);
+          if (v < 0) continue;
+          const float* p = cen(v);
+          const float ex = p[0] - c[0], ey = p[1] - c[1], ez = p[2] - c[2];
+          const unsigned long long key = ((unsigned long long)vm_bits((ex * ex + ey * ey) + ez * ez) << 32) | (unsigned long long)(uint32_t)v;
+          best = key < best ? key : best;
+        }
+      }
+    if (best != ~0ull && vccs_shell_settles(vm_from_bits((uint32_t)(best >> 32)), r, res)) break;
+    if ((uint32_t)r >= lim) break;
+  }
+  return best;
+}
+
 #endif
