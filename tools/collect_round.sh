@@ -31,6 +31,8 @@ if has bench; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b -o kt -- $bench > $out/${tag}_bench_stdout.txt 2>&1
   cp /tmp/kt_b/kt_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
   python3 $R/bench.py --steps 20 --warmup 3 > $out/${tag}_bench_line.json 2> $out/${tag}_bench_stderr.txt
+  # the native tiled driver with the world one GPU can form (multi-GPU pre-flight: what the driver costs beside the plain engine)
+  python3 $R/bench.py --gpus 1 --native --steps 10 --warmup 3 --no-cpu-baseline --no-host-to-host > $out/${tag}_bench_native_line.json 2> $out/${tag}_bench_native_stderr.txt
 fi
 if has pmc; then
   i=0
