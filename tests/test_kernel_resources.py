@@ -34,7 +34,9 @@ def _usage(src, tmp_path):
 def test_one_wavefront_local_cut_keeps_its_registers_without_scratch(tmp_path):
     k = _usage("localcut.hip", tmp_path)
     hot = {n: v for n, v in k.items() if "k_localcut_waveILi96ELi448ELi1E" in n or "k_localcut_waveILi128ELi312ELi1E" in n}
-    assert len(hot) == 2, sorted(k)
+    # <96,448,1,false> (bulk), <128,312,1,false> (class B) and <128,312,1,true> (round 5: the one-in-sixteen sample that books how the
+    # lazy schedule fares on the scene -- its bookkeeping must not cost the others a register, which is why it is an instantiation of its own)
+    assert len(hot) == 3, sorted(k)
     for name, u in hot.items():
         assert u["ScratchSize"] == 0, (name, u)
         assert u["VGPRs Spill"] == 0, (name, u)

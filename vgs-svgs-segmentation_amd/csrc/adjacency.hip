@@ -186,13 +186,22 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
                                                         uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
   constexpr int NB3 = NB * NB * NB, Bh = NB / 2, CAPC = 64 * ADJM_TRIPS;
   constexpr int BTRIPS = (NB3 + 63) / 64, ADJM_BRICKS = 64 * BTRIPS;   // bricks per lane, table size
+  constexpr int ADJM_BRICKS_P2 = ADJM_BRICKS <= 64 ? 64 : (ADJM_BRICKS <= 128 ? 128 : (ADJM_BRICKS <= 256 ? 256 : 512));   // the search's first stride is half of this
   static_assert(NB3 <= 512, "brick slot: nine bits of a candidate");
   __shared__ uint64_t s_occ[ADJM_BRICKS];
   __shared__ uint32_t s_first[ADJM_BRICKS];
-  __shared__ uint16_t s_cand[CAPC];     // used << 15 | brick slot << 6 | bit
-  __shared__ uint64_t lst[CAP];
-  __shared__ uint8_t gl[CAP];
-  __shared__ uint16_t loff[CAP];   // packed lattice offset of every survivor (see k_adjacency)
+  // (round 5) the candidates are not written out as a list any more: a lane of the evaluation finds ITS candidate -- the slot whose run
+  // of candidates holds number q (binary search over the slots' prefix sums), then the (q - prefix)-th set bit of that slot's mask
+  __shared__ uint16_t s_pref[ADJM_BRICKS];   // exclusive prefix of the slots' candidate counts, slot order j = lane * BTRIPS + trip
+  // per slot (index sidx = trip * 64 + lane) the candidate mask and the used mask -- read by the evaluation only, whose survivors stay in
+  // registers until two barriers later: the row's list, groups and lattice offsets take the same bytes
+  constexpr int ROW_BYTES = CAP * 8 + CAP * 2 + CAP, SLOT_BYTES = ADJM_BRICKS * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char s_buf[ROW_BYTES > SLOT_BYTES ? ROW_BYTES : SLOT_BYTES];
+  uint64_t* const s_cm = (uint64_t*)s_buf;
+  uint64_t* const s_cu = s_cm + ADJM_BRICKS;
+  uint64_t* const lst = (uint64_t*)s_buf;
+  uint16_t* const loff = (uint16_t*)(s_buf + CAP * 8);   // packed lattice offset of every survivor (see k_adjacency)
+  uint8_t* const gl = s_buf + CAP * 8 + CAP * 2;
   __shared__ uint32_t s_hist[128], s_cur[128];   // two 16-bit counters per word: integer length l lives in word l >> 1
   __shared__ float ctab[3][32];
   const int lane = threadIdx.x;
@@ -242,7 +251,11 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
       s_occ[sidx] = occ; s_first[sidx] = first;
     }
   }
-  // ---- expand the set bits of all lanes into one candidate list ----
+#if defined(ADJM_STOP) && ADJM_STOP == 1
+  if (lane == 0) adj_cnt[u] = (uint32_t)(cand[0] != 0ull); return;
+#endif
+  // ---- the slots' prefix sums (round 5: was a serial per-lane loop over each lane's set bits, 0.43 of the stage's 0.92 ms -- a wavefront
+  // walked it as often as its fullest brick has cells in the ball, sixteen to thirty times for two or three useful lanes) ----
   int mine = 0;
 #pragma unroll
   for (int trip = 0; trip < BTRIPS; ++trip) mine += __popcll(cand[trip]);
@@ -255,16 +268,16 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
     int pos = incl - mine;
 #pragma unroll
     for (int trip = 0; trip < BTRIPS; ++trip) {
-      uint64_t mm = cand[trip];
-      const int sidx = trip * 64 + lane;
-      while (mm) {
-        const int bit = __ffsll((long long)mm) - 1;
-        mm &= mm - 1ull;
-        s_cand[pos++] = (uint16_t)(((int)((cusd[trip] >> bit) & 1ull) << 15) | (sidx << 6) | bit);
-      }
+      s_pref[lane * BTRIPS + trip] = (uint16_t)pos;
+      pos += __popcll(cand[trip]);
+      s_cm[trip * 64 + lane] = cand[trip];
+      s_cu[trip * 64 + lane] = cusd[trip];
     }
   }
   __syncthreads();
+#if defined(ADJM_STOP) && ADJM_STOP == 2
+  if (lane == 0) adj_cnt[u] = (uint32_t)s_pref[1]; return;
+#endif
   // ---- per candidate: float predicate, key, integer length; survivors stay in registers until their slots are known ----
   const float res2 = res_f * res_f;
   int nstore = 0, mused = 0;
@@ -278,9 +291,26 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
     if (tr * 64 < ntot) {   // wave-uniform
       bool keep = false, is_used = false;
       if (q < ntot) {
-        const int cb = s_cand[q];
-        const int sidx = (cb >> 6) & 511, bit = cb & 63;
-        is_used = (cb >> 15) != 0;
+        // slot: the LAST j with prefix <= q (an empty slot shares its prefix with the next one that is not)
+        int j = 0;
+#pragma unroll
+        for (int step = ADJM_BRICKS_P2 / 2; step >= 1; step >>= 1) {
+          const int mid = j + step;
+          if (mid < ADJM_BRICKS && (int)s_pref[mid] <= q) j = mid;
+        }
+        const int sidx = (j % BTRIPS) * 64 + j / BTRIPS;
+        int kth = q - (int)s_pref[j];
+        const uint64_t cmask = s_cm[sidx];
+        // the kth set bit of the slot's mask: halves by population count
+        uint32_t w = (uint32_t)cmask;
+        int bit = 0;
+        { const int c = __popc(w); if (kth >= c) { kth -= c; w = (uint32_t)(cmask >> 32); bit = 32; } }
+        { const int c = __popc(w & 0xffffu); if (kth >= c) { kth -= c; w >>= 16; bit += 16; } }
+        { const int c = __popc(w & 0xffu); if (kth >= c) { kth -= c; w >>= 8; bit += 8; } }
+        { const int c = __popc(w & 0xfu); if (kth >= c) { kth -= c; w >>= 4; bit += 4; } }
+        { const int c = __popc(w & 0x3u); if (kth >= c) { kth -= c; w >>= 2; bit += 2; } }
+        { const int c = (int)(w & 1u); if (kth >= c) { bit += 1; } }
+        is_used = ((s_cu[sidx] >> bit) & 1ull) != 0ull;
         const int bi = sidx % NB - Bh, bj = (sidx / NB) % NB - Bh, bk = sidx / (NB * NB) - Bh;
         // bit = z0 y0 x0 z1 y1 x1 (brick_local)
         const int lx = ((bit >> 2) & 1) | (((bit >> 5) & 1) << 1), ly = ((bit >> 1) & 1) | (((bit >> 4) & 1) << 1), lz = (bit & 1) | (((bit >> 3) & 1) << 1);
@@ -309,6 +339,9 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   }
   if (nstore > CAP || __ballot(!in_band) != 0ull) { to_redo(); return; }
   __syncthreads();
+#if defined(ADJM_STOP) && ADJM_STOP == 3
+  if (lane == 0) adj_cnt[u] = (uint32_t)nstore + (uint32_t)rkey[0]; return;
+#endif
   // ---- counting sort by integer length: start of every length's group (four lengths per lane) ----
   {
     const uint32_t w0 = s_hist[2 * lane], w1 = s_hist[2 * lane + 1];
@@ -332,6 +365,9 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
     }
   }
   __syncthreads();
+#if defined(ADJM_STOP) && ADJM_STOP == 4
+  if (lane == 0) adj_cnt[u] = (uint32_t)lst[0]; return;
+#endif
   // ---- final slot inside the group (the order inside a group is open: equal lengths, keys differ in rounding and id) ----
   uint64_t* row = adj_key + (int64_t)u * adj_stride;
   uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
