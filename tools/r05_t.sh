@@ -1,8 +1,11 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout 1500 python3 -m pytest -x -q -m gpu tests/test_gpu_schedules.py 2>&1 | tail -3
-bash tools/ab_env.sh 20 none none
-cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/kt_b; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_b -o kt -- python3 $R/tools/nl_time.py > /dev/null 2>&1
-python3 $R/tools/kstats.py /tmp/kt_b/kt_kernel_stats.csv 4 30 | grep -E "k_near_lists|k_adjacency_masks"
+for k in 1 2; do
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-to-host 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('plain', round(d['ms_per_step'],3), {k: round(v,3) for k,v in d['stage_ms'].items()})"
+python3 bench.py --gpus 1 --native --steps 10 --warmup 3 --no-cpu-baseline --no-host-to-host 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('native', round(d['ms_per_step'],3), {k: round(v,3) for k,v in d['stage_ms'].items()}, d['driver']['per_rank'][0].get('tiles_ms'))"
+done
