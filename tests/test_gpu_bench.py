@@ -63,11 +63,13 @@ def test_native_driver_costs_what_the_plain_engine_costs(gpu):
     protocol of a rank without neighbours -- shared grid, boundary records, one exchange, label hand-back -- must stay a small part of
     a step, or the N > 1 lines would say more about the driver than about the GPUs.  Measured in round 5 at 4 M points: 7.9 % before the
     grid the driver has just replayed stopped being scanned again by the voxelize stage (vgs_set_grid_covering), 5.9 % after.  At the
-    bench's own 10 M points (profiles/r05_bench_native_line.json) the plain step is 6.6 ms, the native one 7.5: 0.95 ms = 14 % -- the grid phase
-    0.25 ms (bounding box + growth replay; the voxelize stage is 0.14 shorter for it), boundary records off the GPU 0.25, the exchange 0.05,
-    labels handed back 0.15, and a merge stage 0.35 ms longer than the plain one's share (a tile's unions wait for ownership instead of running
-    beside the hand-over kernels).  Host-side phases vary box to box, so the bar here is 12 % + 0.1 ms at 4 M points; the 3 % the review
-    asked for is not reached.  Both lines carry the per-rank device memory in use."""
+    bench's own 10 M points the native step was 7.54 ms against the plain 6.59 (14 %) until the end of the round, when three things a tile
+    did for nothing went: its unions waited for ownership behind closestCheck although ownership is known from the lattice (now: first
+    hooks and unions beside the hand-over kernels, as in the plain engine, -0.33 ms), every row was read for boundary records although only
+    rows near a border line can have a neighbour of the other ownership (-0.16 ms), and the per-point labels were scattered twice (local
+    names, then global: the first is now left to whoever asks, -0.14 ms): **6.91 against 6.57 ms, 5 %** -- grid phase 0.25 ms (the voxelize
+    stage is 0.14 shorter for it), records 0.09, the exchange 0.06, labels handed back 0.16.  Host-side phases vary box to box, so the bar
+    here is 12 % + 0.1 ms at 4 M points; the 3 % the review asked for is not reached.  Both lines carry the per-rank device memory in use."""
     plain = _run(["--points", "4000000", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-host-to-host", "--no-clusters"])
     native = _run(["--gpus", "1", "--native", "--points", "4000000", "--steps", "8", "--warmup", "3"])
     a, b = plain["ms_per_step_median"], native["ms_per_step_median"]

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
                                               const uint8_t* __restrict__ pending, uint32_t* __restrict__ defer_list,
                                               unsigned int* __restrict__ n_defer, const uint32_t* __restrict__ work, int n_work,
                                               const uint16_t* __restrict__ adj_off, int cb_R,
-                                              const uint32_t* __restrict__ cbits, int cb_words, uint8_t* __restrict__ defer_flag, LcGate gate) {
+                                              const uint32_t* __restrict__ cbits, int cb_words, uint8_t* __restrict__ defer_flag, LcGate gate,
+                                              const uint8_t* __restrict__ owned = nullptr) {
   if (!lc_gate_open_early(gate)) return;
   // First pass (pending != null): all rows, while the hand-over kernels of the local cut still run -- a row whose voxel, or
   // one of whose connected neighbours, is handed over is put off (its flags or theirs are not final).  Second pass
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void k_cross(const uint32_t* __restrict__ used_
           if (found >= 0 && conn[(int64_t)ut * adj_stride + found]) mflag = 1;
         }
       }
-      if (mflag && t < best) best = t;
+      if (mflag && t < best && (!owned || owned[i] || owned[t])) best = t;   // (tiled runs: a connection is trusted only if one endpoint is owned)
     }
     mrow[k] = mflag;
     kept += mflag;
@@ -324,12 +325,12 @@ __global__ __launch_bounds__(64) void k_union_mutual(const uint32_t* __restrict_
 // the re-attachment edges on their own (closestCheck's candidates only): used when the mutual edges were united while the host
 // was still fetching closestCheck's fixed-point flag
 __global__ void k_union_attach(const uint32_t* __restrict__ cand, int n_cand, const uint32_t* __restrict__ used_ids, const int32_t* __restrict__ attach,
-                               uint32_t* __restrict__ parent) {
+                               uint32_t* __restrict__ parent, const uint8_t* __restrict__ owned) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_cand) return;
   const uint32_t i = used_ids[cand[j]];
   const int32_t t = attach[i];
-  if (t >= 0) uf_union(parent, i, (uint32_t)t);
+  if (t >= 0 && (!owned || owned[i])) uf_union(parent, i, (uint32_t)t);   // (tiled runs: the owner of the isolated voxel decides its re-attachment)
 }
 
 // pointer jumping between the first hook and the union pass: every later find starts one hop from a root
@@ -409,6 +410,21 @@ __global__ void k_point_labels(const uint32_t* __restrict__ perm, const uint32_t
   if (j >= N) return;
   const uint32_t v = pt_vox[j];
   label[perm[j]] = (v == 0xffffffffu) ? -1 : vox_label[v];
+}
+
+// the per-point labels of a context whose merge stage left them to be asked for (a tile between vgs_segment and the label hand-back)
+vgs_status vgs_ensure_point_labels(vgs_ctx* c) {
+  if (!c->pt_labels_pending) return VGS_OK;
+  c->pt_labels_pending = false;
+  VGS_HIP_TRY(c, hipSetDevice(c->device));
+  if (c->d2h_open && c->d2h_src == c->pt_label.p) { VGS_HIP_TRY(c, hipEventSynchronize(c->ev_d2h)); c->d2h_open = false; }
+  const int TB = 256;
+  hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((c->N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
+                     c->N, c->pt_label.p);
+  VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));
+  c->labels_event_valid = true;
+  VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VGS_OK;
 }
 
 static VgsWeightParams make_weight_params_m(const vgs_params& p) {
@@ -492,10 +508,16 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     mutual = c->conn.p + (size_t)U * c->adj_stride;  // second half holds the mutual flags
     const uint16_t* gt = (c->P.method == 2 && c->adj_have_gtab) ? c->adj_gtab.p : nullptr;
     const float inv_res2 = 1.0f / (c->P.voxel_size * c->P.voxel_size);
-    uint32_t* cross_parent = c->have_region ? nullptr : c->parent.p;
+    // Tiled runs (round 5): which voxels this rank owns depends on the voxel lattice, the region and the points' sources only, so it is
+    // known NOW, not behind closestCheck -- the first hook is taken in k_cross under the ownership test and the unions of the final rows run
+    // beside the hand-over kernels as in a single-context run (the native driver's merge stage was 0.35 ms longer than the plain one's).
+    const bool tile_early = c->have_region && !c->K.no_tile_early;
+    if (tile_early) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
+    const uint8_t* owned_early = tile_early ? c->owned.p : (const uint8_t*)nullptr;
+    uint32_t* cross_parent = (c->have_region && !tile_early) ? nullptr : c->parent.p;
     unsigned int* d_ndefer = (unsigned int*)(c->counters.p + 13);   // zeroed with the local cut's counters
-    // single-context runs whose hand-over kernels are still running: the unions of the final rows go beside them (see below)
-    const bool early_union = !c->have_region && c->lc_tail.open && !c->K.no_overlap && !c->K.no_early_union;
+    // runs whose hand-over kernels are still running: the unions of the final rows go beside them (see below)
+    const bool early_union = (!c->have_region || tile_early) && c->lc_tail.open && !c->K.no_overlap && !c->K.no_early_union;
     if (early_union) VGS_HIP_TRY(c, c->lc_defer_flag.ensure((size_t)U));
     // connect bits of the cuts (method 2, rows with lattice offsets): the lattice lookup of k_cross
     const bool use_bits = c->cb_enabled && c->P.method == 2 && c->adj_have_off;
@@ -512,7 +534,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), first_lds, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                        c->lc_tail.open ? c->lc_pending.p : (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0,
-                       cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr, g_first);
+                       cb_off, cb_lut, cb_bits, c->cb_words, early_union ? c->lc_defer_flag.p : (uint8_t*)nullptr, g_first, owned_early);
     if (early_union) {
       // The unions of the rows that are final go here, beside the hand-over kernels of the local cut (which leave most of the GPU
       // idle and end the critical path of the stage): pointer jumping over the first hooks, then every mutual edge of a row that
@@ -520,7 +542,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       // may have moved by then).
       hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
       hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), first_lds, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0, g_first);
+                         c->adj_stride, mutual, c->attach.p, owned_early, c->parent.p, 0, c->lc_defer_flag.p, (const uint32_t*)nullptr, 0, g_first);
       compressed = true; united = true;
     }
     // ... then the local cut is completed (its flags and list lengths read back) and the rows put off follow
@@ -536,7 +558,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
       hipLaunchKernelGGL(k_cross, dim3(vgs_xcd_grid((U + CX_ROWS - 1) / CX_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, c->used_rank.p, U, c->adj_key.p, c->adj_cnt.p,
                          c->adj_stride, c->conn.p, mutual, c->csize.p, cross_parent, gt, c->adj_gstride, c->adj_nrank.p, inv_res2,
                          (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, (const uint32_t*)nullptr, 0, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr,
-                         LcGate{nullptr, 0u});
+                         LcGate{nullptr, 0u}, owned_early);
       compressed = false; united = false;
       n_defer = 0;
     }
@@ -546,7 +568,7 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
                          (const uint8_t*)nullptr, c->lc_defer.p, d_ndefer, c->lc_defer.p, (int)n_defer, cb_off, cb_lut, cb_bits, c->cb_words, (uint8_t*)nullptr, LcGate{nullptr, 0u});
       if (early_union)
         hipLaunchKernelGGL(k_union_mutual, dim3((n_defer + UM_ROWS - 1) / UM_ROWS), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
-                           c->adj_stride, mutual, c->attach.p, (const uint8_t*)nullptr, c->parent.p, 0, (const uint8_t*)nullptr, c->lc_defer.p, (int)n_defer, LcGate{nullptr, 0u});
+                           c->adj_stride, mutual, c->attach.p, owned_early, c->parent.p, 0, (const uint8_t*)nullptr, c->lc_defer.p, (int)n_defer, LcGate{nullptr, 0u});
     }
     // closestCheck
     VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16));
@@ -599,8 +621,9 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     VGS_HIP_TRY(c, c->conn.ensure(16));
   }
   // connected components
-  if (c->have_region) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
-  if (U > 0 && c->have_region)
+  const bool owned_known = c->have_region && U > 0 && !c->K.no_tile_early;   // (computed at the head of the stage, first hooks taken by k_cross)
+  if (c->have_region && !owned_known) { vgs_status so = vgs_compute_owned(c); if (so != VGS_OK) return so; }
+  if (U > 0 && c->have_region && !owned_known)
     hipLaunchKernelGGL(k_cc_init, dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p, c->adj_stride, mutual,
                        c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p);
   if (U > 0 && !compressed) hipLaunchKernelGGL(k_compress, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V);
@@ -608,7 +631,8 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
     hipLaunchKernelGGL(k_union_mutual, dim3((unsigned)((U + UM_ROWS - 1) / UM_ROWS)), dim3(64), 0, c->stream, c->used_ids.p, U, c->adj_key.p, c->adj_cnt.p,
                        c->adj_stride, mutual, c->attach.p, c->have_region ? c->owned.p : nullptr, c->parent.p, 1, (const uint8_t*)nullptr, (const uint32_t*)nullptr, 0, LcGate{nullptr, 0u});
   else if (U > 0 && n_cand > 0)
-    hipLaunchKernelGGL(k_union_attach, dim3((n_cand + TB - 1) / TB), dim3(TB), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->attach.p, c->parent.p);
+    hipLaunchKernelGGL(k_union_attach, dim3((n_cand + TB - 1) / TB), dim3(TB), 0, c->stream, c->work_ids.p, (int)n_cand, c->used_ids.p, c->attach.p, c->parent.p,
+                       c->have_region ? c->owned.p : (const uint8_t*)nullptr);
   hipLaunchKernelGGL(k_flatten, dim3(nbV), dim3(TB), 0, c->stream, c->parent.p, V, c->have_region ? c->owned.p : nullptr, c->csz.p);
   // cluster filter + labels (VGS_T_LABELS: this tail of the stage, measured on its own; it is part of VGS_T_MERGE)
   VGS_HIP_TRY(c, hipEventRecord(c->ev[14], c->stream));   // ev[14], ev[15]: this tail's own pair
@@ -627,8 +651,12 @@ vgs_status vgs_stage_merge(vgs_ctx* c) {
   // (Round 4 measured the scatter-free alternative -- the point's octree key formed again from its coordinates, its voxel from the
   // brick table, label[p] written in input order: 0.26 ms against this kernel's 0.14 ms at 10 M points.  PCL's key arithmetic is
   // double precision -- three fp64 divisions per point -- and that costs more than the 4-byte scatter saves.)
-  hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
-                     N, c->pt_label.p);
+  // A tile's labels are local names: the driver hands the global ones back (vgs_apply_tile_labels / vgs_apply_global_labels rewrite every
+  // point's label), so the 40 MB scatter is left to whoever asks for point labels BEFORE that happens (vgs_ensure_point_labels; round 5)
+  c->pt_labels_pending = c->have_region && N > 0;
+  if (!c->pt_labels_pending)
+    hipLaunchKernelGGL(k_point_labels, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p,
+                       N, c->pt_label.p);
   VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));
   c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());

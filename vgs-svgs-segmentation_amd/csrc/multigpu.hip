@@ -22,8 +22,11 @@ __global__ void k_point_sources(const uint32_t* __restrict__ perm, const uint32_
   if (v != 0xffffffffu) mix[((i >= own_first && i < own_first + n_own) ? 0 : V) + v] = 1;   // every writer stores the same value
 }
 
+// straddle[v]: bit 0 = the voxel's cube reaches over a border (or holds points of both sides); bit 1 (round 5) = its centre lies within
+// `near` of a border line -- only such a voxel can have a neighbour of the other ownership in its search ball, so only its row is read
+// when the boundary records are made (k_boundary read every row: 0.15 ms for a handful of records)
 __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float res_f, float min_x, float min_y, double lo_x, double lo_y,
-                        double hi_x, double hi_y, uint8_t* __restrict__ owned, uint8_t* __restrict__ straddle, const uint8_t* __restrict__ mix) {
+                        double hi_x, double hi_y, uint8_t* __restrict__ owned, uint8_t* __restrict__ straddle, const uint8_t* __restrict__ mix, double near) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t code = vox_code[v];
@@ -38,7 +41,8 @@ __global__ void k_owned(const uint64_t* __restrict__ vox_code, int64_t V, float 
   // another rank loaded, a halo voxel with points this rank loaded.  Both ranks see that (the holder sends such points in its
   // strip) and both publish the voxel, so the holder learns the label of its points from the owner's record.
   if (mix) st = st || (owned[v] ? mix[V + v] != 0 : mix[v] != 0);
-  straddle[v] = st ? 1 : 0;
+  const bool nr = fabs(cx - lo_x) < near || fabs(cx - hi_x) < near || fabs(cy - lo_y) < near || fabs(cy - hi_y) < near;
+  straddle[v] = (uint8_t)((st ? 1 : 0) | (nr ? 2 : 0));
 }
 
 vgs_status vgs_compute_owned(vgs_ctx* c) {
@@ -53,7 +57,8 @@ vgs_status vgs_compute_owned(vgs_ctx* c) {
     mix = c->mixsrc.p;
   }
   hipLaunchKernelGGL(k_owned, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->vox_code.p, c->V, c->P.voxel_size,
-                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p, c->straddle.p, mix);
+                     (float)c->box.min[0], (float)c->box.min[1], c->own_lo[0], c->own_lo[1], c->own_hi[0], c->own_hi[1], c->owned.p, c->straddle.p, mix,
+                     (double)c->P.graph_size + 2.0 * (double)c->P.voxel_size);   // neighbours' centres are closer than graph_size; two voxels of margin
   VGS_HIP_TRY(c, hipGetLastError());
   return VGS_OK;
 }
@@ -69,35 +74,47 @@ vgs_status vgs_compute_owned(vgs_ctx* c) {
 //   * every voxel, used or not, whose cube reaches over the border (k_boundary_straddle): the ranks on both sides hold
 //     points of it, and the rank that does not own it learns its label through the record of the rank that does.
 // At most two records per voxel (duplicates are removed by the sort that follows).
+// (round 5) a wavefront takes 64 used voxels: every lane checks ITS voxel's re-attachment and whether it lies near a border line; the
+// rows of the near ones (a few per cent of a tile) are then read by the whole wavefront, one after the other
 __global__ __launch_bounds__(64) void k_boundary(const uint32_t* __restrict__ used_ids, int64_t U, const uint64_t* __restrict__ adj_key,
                                                  const uint32_t* __restrict__ adj_cnt, int adj_stride, const uint8_t* __restrict__ mutual,
                                                  const int32_t* __restrict__ attach, const uint8_t* __restrict__ owned,
                                                  const uint32_t* __restrict__ parent, const uint64_t* __restrict__ vox_code,
                                                  unsigned long long cap, unsigned long long* __restrict__ n_out,
-                                                 uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root) {
-  const int64_t u = vgs_xcd_item(blockIdx.x, U);
-  if (u >= U) return;
+                                                 uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root, const uint8_t* __restrict__ straddle) {
   const int lane = threadIdx.x;
-  const uint32_t i = used_ids[u];
-  const int n = (int)adj_cnt[u];
-  const uint64_t* row = adj_key + u * adj_stride;
-  const uint8_t* mrow = mutual + u * adj_stride;
-  const bool oi = owned[i] != 0;
-  bool pub = false;
-  for (int k = lane; k < n; k += 64) {
-    const uint32_t t = (uint32_t)row[k];
-    const bool ot = owned[t] != 0;
-    pub = pub || (oi ? !ot : (ot && mrow[k] != 0));
+  const int64_t u_mine = (int64_t)blockIdx.x * 64 + lane;
+  uint32_t i_mine = 0;
+  bool near_mine = false, oi_mine = false;
+  if (u_mine < U) { i_mine = used_ids[u_mine]; near_mine = (straddle[i_mine] & 2) != 0; oi_mine = owned[i_mine] != 0; }
+  // far from every border line all of the row's voxels share the voxel's ownership: nothing to publish but a re-attachment
+  unsigned long long pub_mask = 0ull;
+  unsigned long long todo = __ballot(near_mine);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const int64_t u = (int64_t)blockIdx.x * 64 + src;
+    const bool oi = __shfl((int)oi_mine, src, 64) != 0;
+    const int n = (int)adj_cnt[u];
+    const uint64_t* row = adj_key + u * adj_stride;
+    const uint8_t* mrow = mutual + u * adj_stride;
+    bool pub = false;
+    for (int k = lane; k < n; k += 64) {
+      const uint32_t t = (uint32_t)row[k];
+      const bool ot = owned[t] != 0;
+      pub = pub || (oi ? !ot : (ot && mrow[k] != 0));
+    }
+    if (__ballot(pub) != 0ull) pub_mask |= 1ull << src;
   }
-  pub = __ballot(pub) != 0ull;
-  if (lane != 0) return;
-  const int32_t a = attach[i];
-  const bool att = a >= 0 && oi && !owned[a];   // the count-as-index target (Q7) need not be a neighbour
+  if (u_mine >= U) return;
+  const bool pub = ((pub_mask >> lane) & 1ull) != 0ull;
+  const int32_t a = attach[i_mine];
+  const bool att = a >= 0 && oi_mine && !owned[a];   // the count-as-index target (Q7) need not be a neighbour
   const unsigned int cnt = (pub || att ? 1u : 0u) + (att ? 1u : 0u);
   if (cnt == 0) return;
   const unsigned long long p = atomicAdd(n_out, (unsigned long long)cnt);
   if (p + cnt > cap) return;
-  out_code[p] = vox_code[i]; out_root[p] = (int32_t)parent[i];
+  out_code[p] = vox_code[i_mine]; out_root[p] = (int32_t)parent[i_mine];
   if (att) { out_code[p + 1] = vox_code[a]; out_root[p + 1] = (int32_t)parent[a]; }
 }
 
@@ -105,7 +122,7 @@ __global__ void k_boundary_straddle(const uint8_t* __restrict__ straddle, int64_
                                     const uint64_t* __restrict__ vox_code, unsigned long long cap, unsigned long long* __restrict__ n_out,
                                     uint64_t* __restrict__ out_code, int32_t* __restrict__ out_root) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V || !straddle[v]) return;
+  if (v >= V || !(straddle[v] & 1)) return;
   const unsigned long long p = atomicAdd(n_out, 1ull);
   if (p < cap) { out_code[p] = vox_code[v]; out_root[p] = (int32_t)parent[v]; }
 }
@@ -348,8 +365,8 @@ vgs_status vgs_get_boundary(vgs_ctx* c, int64_t* n_records, uint64_t* code, int3
     VGS_HIP_TRY(c, hipMemsetAsync(d_n, 0, 8, c->stream));
     const uint8_t* mutual = c->conn.p + (size_t)c->U * c->adj_stride;
     if (c->U > 0)
-      hipLaunchKernelGGL(k_boundary, dim3(vgs_xcd_grid(c->U)), dim3(64), 0, c->stream, c->used_ids.p, c->U, c->adj_key.p, c->adj_cnt.p,
-                       c->adj_stride, mutual, c->attach.p, c->owned.p, c->parent.p, c->vox_code.p, cap, d_n, c->bnd_code.p, c->bnd_root.p);
+      hipLaunchKernelGGL(k_boundary, dim3((unsigned)((c->U + 63) / 64)), dim3(64), 0, c->stream, c->used_ids.p, c->U, c->adj_key.p, c->adj_cnt.p,
+                       c->adj_stride, mutual, c->attach.p, c->owned.p, c->parent.p, c->vox_code.p, cap, d_n, c->bnd_code.p, c->bnd_root.p, c->straddle.p);
     hipLaunchKernelGGL(k_boundary_straddle, dim3((unsigned)((c->V + 255) / 256)), dim3(256), 0, c->stream, c->straddle.p, c->V, c->parent.p,
                        c->vox_code.p, cap, d_n, c->bnd_code.p, c->bnd_root.p);
     unsigned long long n = 0;
@@ -463,6 +480,7 @@ vgs_status vgs_apply_tile_labels(vgs_ctx* c, int32_t local_base, const int32_t* 
                      c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
+  c->pt_labels_pending = false;   // every point's label has just been written
   VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));   // label downloads order themselves behind this (vgs_get_point_labels_async)
   c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());
@@ -512,6 +530,7 @@ vgs_status vgs_apply_root_labels(vgs_ctx* c, const int32_t* root, const int32_t*
                      c->vox_label.p);
   hipLaunchKernelGGL(k_point_labels2, dim3((unsigned)((N + TB - 1) / TB)), dim3(TB), 0, c->stream, c->perm_b.p, c->pt_vox.p, c->vox_label.p, N,
                      c->pt_label.p);
+  c->pt_labels_pending = false;   // every point's label has just been written
   VGS_HIP_TRY(c, hipEventRecord(c->ev[15], c->stream));   // label downloads order themselves behind this (vgs_get_point_labels_async)
   c->labels_event_valid = true;
   VGS_HIP_TRY(c, hipGetLastError());

@@ -93,6 +93,7 @@ struct VgsKnobs {
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
+  bool no_tile_early = false;    // VGS_NO_TILE_EARLY: a tile's first hooks and unions wait behind closestCheck (rounds 3-4)
   int cross_lds_kb = 0;          // VGS_CROSS_LDS: KB of (unused) LDS per wavefront of crossValidation's FIRST pass and its unions -- caps how many
                                  // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
@@ -135,6 +136,7 @@ struct vgs_ctx {
   bool staged = false;         // a cloud is on its way into xyz_buf[1 - xyz_cur]
   int64_t staged_n = 0;
   int staged_stride = 12;
+  bool pt_labels_pending = false;    // a tile's merge stage did not scatter the per-point labels (vgs_ensure_point_labels does, on request)
   bool labels_event_valid = false;   // ev[15] has been recorded behind the last kernel that wrote pt_label
   bool d2h_open = false;       // vgs_get_point_labels_async has a copy in flight ...
   const int32_t* d2h_src = nullptr;   // ... out of this buffer
@@ -360,6 +362,7 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
                                int n_lists, bool all_rows, const float* ctab, float ctab_scale, float d2_stop, int slot, const LcGate& gate,
                                bool big_rows_too);
 vgs_status vgs_stage_localcut(vgs_ctx* c);   // launches everything; its hand-over kernels may still run when it returns
+vgs_status vgs_ensure_point_labels(vgs_ctx* c);   // merge.hip
 vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred);  // waits for them, checks the stage's flags (called by the merge stage)
 vgs_status vgs_stage_merge(vgs_ctx* c);
 vgs_status vgs_clusters_on_device(vgs_ctx* c);   // clusters.hip
