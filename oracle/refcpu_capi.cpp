@@ -250,6 +250,20 @@ void ref_weight_and_bounds(const float* a16, const float* b16, const RefParamsC*
   }
   out3[2] = vm_weight_bound_d(d2, W);
 }
+// vm_pair_weight_both against two plain evaluations, over n pairs of records (a16[k], b16[k]): returns the number of pairs where either
+// orientation differs in any bit (tests/test_oracle_kat.py: must be 0)
+int ref_weight_both_mismatches(const float* a16, const float* b16, int n, const RefParamsC* p, int svgs) {
+  const VgsWeightParams W = dev_params(p, svgs);
+  int bad = 0;
+  for (int k = 0; k < n; ++k) {
+    const VgsNode A = dev_node(a16 + 16 * (size_t)k), B = dev_node(b16 + 16 * (size_t)k);
+    float w12, w21;
+    vm_pair_weight_both(A, B, W, &w12, &w21);
+    const float r12 = vm_pair_weight(A, B, W), r21 = vm_pair_weight(B, A, W);
+    if (vm_bits(w12) != vm_bits(r12) || vm_bits(w21) != vm_bits(r21)) ++bad;
+  }
+  return bad;
+}
 void ref_compute_node(const float* xyz, int stride_floats, const int* idx, int count, int math, int svgs, float* out16) {
   Node nd;
   compute_node(xyz, stride_floats, idx, count, math, svgs != 0, nd);

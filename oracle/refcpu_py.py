@@ -250,6 +250,15 @@ def weight_and_bounds(a16, b16, params, svgs=False):
     return out
 
 
+def weight_both_mismatches(a16, b16, params, svgs=False):
+    """Pairs (rows of a16 / b16) for which vm_pair_weight_both differs from two plain evaluations in any bit (csrc/vgs_math.h)."""
+    a16 = np.ascontiguousarray(a16, dtype=np.float32); b16 = np.ascontiguousarray(b16, dtype=np.float32)
+    L = lib()
+    L.ref_weight_both_mismatches.restype = C.c_int
+    L.ref_weight_both_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(type(params)), C.c_int]
+    return int(L.ref_weight_both_mismatches(_p(a16), _p(b16), a16.shape[0], C.byref(params), int(svgs)))
+
+
 def cut_graph(W, cut, flavour=0):
     W = np.ascontiguousarray(W, dtype=np.float32)
     n = W.shape[0]

@@ -197,12 +197,14 @@ __global__ __launch_bounds__(64, NL_WAVES) void k_near_lists(const uint32_t* __r
     if (lane == 0) out_cnt[s_vid[g_first]] = (uint8_t)nq; continue;
 #endif
     // ---- 2. weights, on full wavefronts: both orientations of every queued pair ----
-    for (int e = lane; e < 2 * nq; e += 64) {
-      const int q = e >> 1;
+    // (round 5: one lane per pair computes both -- only the convexity distance depends on the order of the two voxels, vgs_math.h:
+    // vm_pair_weight_both -- where two lanes each evaluated the whole weight)
+    for (int q = lane; q < nq; q += 64) {
       const NodeRec& A = node[s_vid[q_g[q]]];
       const NodeRec& B = node[q_t[q]];
-      const float w = (e & 1) ? vm_pair_weight(B, A, W) : vm_pair_weight(A, B, W);
-      if (e & 1) q_w2[q] = w; else q_w[q] = w;
+      float w12, w21;
+      vm_pair_weight_both(A, B, W, &w12, &w21);
+      q_w[q] = w12; q_w2[q] = w21;
     }
     __syncthreads();
     for (int q = lane; q < nq; q += 64) {

@@ -147,11 +147,13 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
     pl_barrier<NWV>();
     const int ns = s_ns;
     // ---- 3. both orientations of the survivors' weights ----
-    for (int e = tid; e < 2 * ns; e += TB) {
-      const int q = s_cand[e >> 1];
+    // (one lane per pair: only the convexity distance depends on the order of the two voxels -- vgs_math.h: vm_pair_weight_both)
+    for (int e = tid; e < ns; e += TB) {
+      const int q = s_cand[e];
       const NodeRec& B = node[c_tid[q]];
-      const float w = (e & 1) ? vm_pair_weight(B, A, P.W) : vm_pair_weight(A, B, P.W);
-      if (e & 1) wba[q] = w; else wab[q] = w;
+      float w12, w21;
+      vm_pair_weight_both(A, B, P.W, &w12, &w21);
+      wab[q] = w12; wba[q] = w21;
     }
     pl_barrier<NWV>();
     // ---- 4. the heavy ones, sorted by their heavier orientation ----
