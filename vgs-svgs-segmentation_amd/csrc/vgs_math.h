@@ -400,9 +400,12 @@ VGS_HD float vm_dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1
 // (p and q change places under a commutative sum), the eigen term and the angle of the cross product come out bit for bit the same, while
 // the two angles between a normal and u become acos(-cos2) and acos(-cos1) -- which differ from pi - acos(cos2), pi - acos(cos1) in the last
 // bit.  A builder that stores both orientations of a pair (near-pair lists, pair lists) pays two more acos instead of a second evaluation.
-template <bool SPLIT>
+// (BOTH is a template parameter, not a run-time null check: the plain instantiation must compile to exactly what it was -- the
+// one-wavefront local cut sits at its register limit and a dead store more costs it three spilled registers)
+template <bool SPLIT, bool BOTH = false>
 VGS_HD void vm_pair_distances_t(const VgsNode& v1, const VgsNode& v2, int svgs, float* out, float* convx_swapped = nullptr) {
-  float dist_space = 100.0f, dist_angle = 100.0f, dist_stair = 100.0f, dist_eigen = 100.0f, dist_convx = 100.0f, dist_convx_sw = 100.0f;
+  float dist_space = 100.0f, dist_angle = 100.0f, dist_stair = 100.0f, dist_eigen = 100.0f, dist_convx = 100.0f;
+  [[maybe_unused]] float dist_convx_sw = 100.0f;
   float d12 = 0.0f;
   float u[3] = {0.0f, 0.0f, 0.0f};
   float prod[3] = {0.0f, 0.0f, 0.0f};
@@ -419,7 +422,8 @@ VGS_HD void vm_pair_distances_t(const VgsNode& v1, const VgsNode& v2, int svgs, 
     }
   }
   if (nv) {
-    float a_1 = 0.0f, a_2 = 0.0f, a_1_2 = 0.0f, a_d_s1 = 0.0f, a_d_s2 = 0.0f, a_1s = 0.0f, a_2s = 0.0f;
+    float a_1 = 0.0f, a_2 = 0.0f, a_1_2 = 0.0f, a_d_s1 = 0.0f, a_d_s2 = 0.0f;
+    [[maybe_unused]] float a_1s = 0.0f, a_2s = 0.0f;
     // VS guards on dist_space (100 when positions are invalid -> the reference then reads empty
     // vectors, UB; here u = prod = 0).  SS guards on dist_v1_v2 and sets dist_stair = 0 otherwise.
     const bool guard = svgs ? (d12 != 0.0f) : (dist_space != 0.0f);
@@ -430,7 +434,7 @@ VGS_HD void vm_pair_distances_t(const VgsNode& v1, const VgsNode& v2, int svgs, 
       float cosds = vm_dot3(prod, u);
       a_1 = vm_acos(cos1);
       a_2 = vm_acos(cos2);
-      if (convx_swapped) { a_1s = vm_acos(-cos2); a_2s = vm_acos(-cos1); }   // dot(v2.n, -u), dot(v1.n, -u)
+      if constexpr (BOTH) { a_1s = vm_acos(-cos2); a_2s = vm_acos(-cos1); }   // dot(v2.n, -u), dot(v1.n, -u)
       a_1_2 = vm_acos(cos12);
       a_d_s1 = vm_acos(cosds);
       a_d_s2 = VM_PI_F - a_d_s1;
@@ -451,10 +455,12 @@ VGS_HD void vm_pair_distances_t(const VgsNode& v1, const VgsNode& v2, int svgs, 
     if (a_d_s1 > a_d_s2) a_d_s = a_d_s2;
     if (a_d_s > thr) dist_convx = vm_abs(a_1 - a_2);
     else dist_convx = VM_PI_F;
-    if (a_d_s > thr) dist_convx_sw = vm_abs(a_1s - a_2s);
-    else dist_convx_sw = VM_PI_F;
+    if constexpr (BOTH) {
+      if (a_d_s > thr) dist_convx_sw = vm_abs(a_1s - a_2s);
+      else dist_convx_sw = VM_PI_F;
+    }
   }
-  if (convx_swapped) *convx_swapped = dist_convx_sw;
+  if constexpr (BOTH) *convx_swapped = dist_convx_sw;
   if (ev) {
     float ec = 0.0f, e1 = 0.0f, e2 = 0.0f;
     // entries 4..7 (VS) or 0..7 (SS), summed in index order
@@ -505,7 +511,7 @@ VGS_HD float vm_pair_weight(const VgsNode& v1, const VgsNode& v2, const VgsWeigh
 // vm_pair_weight(v1, v2) and vm_pair_weight(v2, v1), bit for bit, for a little more than the price of one (see vm_pair_distances_t)
 VGS_HD void vm_pair_weight_both(const VgsNode& v1, const VgsNode& v2, const VgsWeightParams& P, float* w12, float* w21) {
   float d[5], sw;
-  vm_pair_distances_t<false>(v1, v2, P.svgs, d, &sw);
+  vm_pair_distances_t<false, true>(v1, v2, P.svgs, d, &sw);
   *w12 = vm_distance_weight(d, P);
   d[4] = sw;
   *w21 = vm_distance_weight(d, P);
