@@ -131,17 +131,22 @@ def test_limits_are_reported_not_silently_wrong(gpu):
 
 
 def test_tables_that_cannot_fit_are_refused_with_an_estimate(gpu):
-    """The adjacency / connect tables are dense (used voxels x lattice offsets of the ball x 12 B): more than six million used voxels seen through a
-    ball of ten voxels would need over 300 GB.  The adjacency stage says so -- VGS_E_NOMEM with the numbers and what to change -- before
+    """The adjacency / connect tables are dense (used voxels x lattice offsets of the ball x 12 B): a sheet of ten million used voxels seen through a
+    ball of ten voxels would need half a terabyte.  The adjacency stage says so -- VGS_E_NOMEM with the numbers and what to change -- before
     it allocates anything, and the context stays usable."""
-    side = 3200
+    # (ADVICE r4) sized from the device that is there, not from the 288 GB the round was developed on: a sheet whose tables at a ball of ten
+    # voxels (4189 lattice offsets x 12 B per used voxel) need 1.5 x the device's memory
+    import torch
+    total_b = torch.cuda.mem_get_info()[1]
+    side = int(np.ceil(np.sqrt(1.5 * total_b / (4189.0 * 12.0) / 0.65)))   # (about 0.7 of the sheet's cells come out as used voxels: float cell edges)
+    assert 500 < side < 6000, side
     ij = np.stack(np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32), indexing="ij"), -1).reshape(-1, 2)
     cell = np.concatenate([ij * 0.05 + 0.0125, ij * 0.05 + 0.0375])                  # two points in every voxel of a 160 m sheet
     xyz = np.concatenate([cell, np.full((cell.shape[0], 1), 1.02, np.float32)], axis=1).astype(np.float32)
     eng = gpu.Engine(gpu.default_params(2, voxel_size=0.05, graph_size=0.5, points_min=1))
     eng.set_points(xyz)
     eng.voxelize(); eng.features()
-    assert eng.counts()["used"] > 6_000_000
+    assert eng.counts()["used"] * 4189.0 * 12.0 > 1.2 * total_b
     with pytest.raises(gpu.VgsError) as e:
         eng.adjacency()
     assert "VGS_E_NOMEM" in str(e.value) and "tables need" in str(e.value) and "GB" in str(e.value), str(e.value)
