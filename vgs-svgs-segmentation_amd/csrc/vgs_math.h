@@ -262,12 +262,14 @@ VGS_HD float vm_best_cross(const float* sm, float lambda, float* out) {
   vm_cross(&t[0], &t[6], v2);
   vm_cross(&t[3], &t[6], v3);
   float l1 = vm_sqnorm(v1), l2 = vm_sqnorm(v2), l3 = vm_sqnorm(v3);
-  const float* v; float l;
-  if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
-  else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
-  else { v = v3; l = l3; }
+  // (values, not a pointer to one of the three: a selected POINTER keeps all three arrays in scratch memory on the GPU -- 40 bytes per
+  // lane in k_features and in the supervoxel stage's tile set-up, a gigabyte of scratch traffic per launch of the latter; round 5)
+  float vx, vy, vz, l;
+  if (l1 >= l2 && l1 >= l3) { vx = v1[0]; vy = v1[1]; vz = v1[2]; l = l1; }
+  else if (l2 >= l1 && l2 >= l3) { vx = v2[0]; vy = v2[1]; vz = v2[2]; l = l2; }
+  else { vx = v3[0]; vy = v3[1]; vz = v3[2]; l = l3; }
   float s = vm_sqrt(l);
-  out[0] = v[0] / s; out[1] = v[1] / s; out[2] = v[2] / s;
+  out[0] = vx / s; out[1] = vy / s; out[2] = vz / s;
   return l;
 }
 
@@ -311,24 +313,27 @@ VGS_HD void vm_eigen33(const float* mat, float* evecs /*[r*3+k]*/, float* evals)
     vm_unit_orthogonal(c0, c1);
     vm_cross(c0, c1, c2);
   } else {
-    float mmax[3];
+    // (the same selections as an array of column pointers indexed by min_el / mid_el would make)
     unsigned min_el = 2, max_el = 2;
-    mmax[2] = vm_best_cross(sm, evals[2], c2);
-    mmax[1] = vm_best_cross(sm, evals[1], c1);
-    min_el = mmax[1] <= mmax[min_el] ? 1u : min_el;
-    max_el = mmax[1] > mmax[max_el] ? 1u : max_el;
-    mmax[0] = vm_best_cross(sm, evals[0], c0);
-    min_el = mmax[0] <= mmax[min_el] ? 0u : min_el;
-    max_el = mmax[0] > mmax[max_el] ? 0u : max_el;
+    const float m2 = vm_best_cross(sm, evals[2], c2);
+    const float m1 = vm_best_cross(sm, evals[1], c1);
+    float mmin = m2, mmaxv = m2;
+    if (m1 <= mmin) { min_el = 1u; mmin = m1; }
+    if (m1 > mmaxv) { max_el = 1u; mmaxv = m1; }
+    const float m0 = vm_best_cross(sm, evals[0], c0);
+    if (m0 <= mmin) { min_el = 0u; mmin = m0; }
+    if (m0 > mmaxv) { max_el = 0u; mmaxv = m0; }
     unsigned mid_el = 3u - min_el - max_el;
-    float* col[3] = {c0, c1, c2};
+    // column k := normalised cross product of columns k + 1 and k + 2 (mod 3), k = min_el first, then mid_el -- spelled out per k: any
+    // run-time choice among c0 / c1 / c2, pointer OR value (the compiler folds a select of loads back into a load through a selected
+    // pointer), keeps all three columns in scratch memory
     float tmp[3];
-    vm_cross(col[(min_el + 1) % 3], col[(min_el + 2) % 3], tmp);
-    vm_normalize3(tmp);
-    col[min_el][0] = tmp[0]; col[min_el][1] = tmp[1]; col[min_el][2] = tmp[2];
-    vm_cross(col[(mid_el + 1) % 3], col[(mid_el + 2) % 3], tmp);
-    vm_normalize3(tmp);
-    col[mid_el][0] = tmp[0]; col[mid_el][1] = tmp[1]; col[mid_el][2] = tmp[2];
+    if (min_el == 0u) { vm_cross(c1, c2, tmp); vm_normalize3(tmp); c0[0] = tmp[0]; c0[1] = tmp[1]; c0[2] = tmp[2]; }
+    else if (min_el == 1u) { vm_cross(c2, c0, tmp); vm_normalize3(tmp); c1[0] = tmp[0]; c1[1] = tmp[1]; c1[2] = tmp[2]; }
+    else { vm_cross(c0, c1, tmp); vm_normalize3(tmp); c2[0] = tmp[0]; c2[1] = tmp[1]; c2[2] = tmp[2]; }
+    if (mid_el == 0u) { vm_cross(c1, c2, tmp); vm_normalize3(tmp); c0[0] = tmp[0]; c0[1] = tmp[1]; c0[2] = tmp[2]; }
+    else if (mid_el == 1u) { vm_cross(c2, c0, tmp); vm_normalize3(tmp); c1[0] = tmp[0]; c1[1] = tmp[1]; c1[2] = tmp[2]; }
+    else { vm_cross(c0, c1, tmp); vm_normalize3(tmp); c2[0] = tmp[0]; c2[1] = tmp[1]; c2[2] = tmp[2]; }
   }
   for (int r = 0; r < 3; ++r) { evecs[r * 3 + 0] = c0[r]; evecs[r * 3 + 1] = c1[r]; evecs[r * 3 + 2] = c2[r]; }
   evals[0] *= scale; evals[1] *= scale; evals[2] *= scale;
