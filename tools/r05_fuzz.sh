@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out/fuzz
-timeout 400 python3 tools/fuzz_parity.py 300 5101 2 2>&1 | tail -2 | tee gpurun_out/fuzz/vgs.txt
-timeout 400 python3 tools/fuzz_parity.py 300 5102 2 wide 2>&1 | tail -2 | tee gpurun_out/fuzz/vgs_wide.txt
-timeout 300 python3 tools/fuzz_parity.py 200 5103 3 2>&1 | tail -2 | tee gpurun_out/fuzz/svgs.txt
-timeout 300 python3 tools/fuzz_tiles.py 200 5104 2>&1 | tail -2 | tee gpurun_out/fuzz/tiles.txt
+timeout 400 python3 tools/fuzz_parity.py 300 5301 2 2>&1 | tail -2 | tee gpurun_out/fuzz/vgs.txt
+timeout 400 python3 tools/fuzz_parity.py 300 5302 2 wide 2>&1 | tail -2 | tee gpurun_out/fuzz/vgs_wide.txt
+timeout 300 python3 tools/fuzz_parity.py 200 5303 3 2>&1 | tail -2 | tee gpurun_out/fuzz/svgs.txt
+timeout 300 python3 tools/fuzz_tiles.py 200 5304 2>&1 | tail -2 | tee gpurun_out/fuzz/tiles.txt
