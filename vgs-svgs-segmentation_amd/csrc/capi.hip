@@ -223,7 +223,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_off.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->nl_cnt.release(); c->nl_tot.release(); c->nl_ent.release(); c->lc_ctab.release(); c->pl_state.release(); c->pl_ent.release(); c->pl_work.release();
   c->cl_off.release(); c->cl_idx.release(); c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->lc_defer_flag.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
-  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_tile_start.release(); c->vc_cell.release(); c->vc_plive.release(); c->vc_tile_of.release(); c->vc_tchg.release(); c->vc_nbr_tiles.release(); c->vc_halo.release(); c->vc_tile_meta.release(); c->vc_pool.release(); c->vc_label.release();
+  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_tile_start.release(); c->vc_cell.release(); c->vc_plive.release(); c->vc_tile_of.release(); c->vc_tchg.release(); c->vc_nbr_tiles.release(); c->vc_halo.release(); c->vc_tile_meta.release(); c->vc_pool.release(); c->vc_ring.release(); c->vc_label.release();
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release(); c->vc_accu.release(); c->vc_live.release(); c->vc_alive.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();

@@ -876,9 +876,11 @@ __global__ void k_pcl_max_label(int K, const uint8_t* __restrict__ alive, unsign
 // k_vccs_expand_tiles.  The fold -- distinct owners below the limit that reach the voxel through a live leaf, in ascending label
 // order, an offer strictly below the recorded distance taking the voxel -- enumerates them as successive minima (vccs_enum_next: the
 // keys ARE the labels, so the order is the sequential one) instead of an insertion sort over 27 gathered values.
-__global__ void k_pclt_init(int64_t V, const int32_t* __restrict__ owner, int32_t* __restrict__ P) {
+// (round 5: also marks every tile "changed" for the round's first sweep -- was a memset per round between two dependent kernels)
+__global__ void k_pclt_init(int64_t V, const int32_t* __restrict__ owner, int32_t* __restrict__ P, uint32_t* __restrict__ tchg, int NT) {
   int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v < V) { const int s = owner[v]; P[v] = s < 0 ? -1 : ((s << 1) | 1); }
+  if (tchg && v < NT) tchg[v] = 0x01010101u;
 }
 template <bool CLAIM>
 __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta, const uint2* __restrict__ halo,
@@ -1148,7 +1150,12 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   uint8_t* live[2] = {c->vc_live.p, c->vc_live.p + V};
   int32_t* plive[2] = {tiles ? c->vc_plive.p : nullptr, tiles ? c->vc_plive.p + V : nullptr};
   uint32_t* tchg[2] = {tiles ? c->vc_tchg.p : nullptr, tiles ? c->vc_tchg.p + NT : nullptr};   // per tile: a flag changed in that sweep
-  unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);
+  // the sweeps' change counters: a ring of words zeroed once per pass (was a memset in front of every batch of sweeps: 80 per step)
+  constexpr int RING = 4096;
+  VGS_HIP_TRY(c, c->vc_ring.ensure(RING));
+  unsigned int* const d_ring = c->vc_ring.p;
+  int ring_at = RING;   // (forces the first fill)
+  unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);   // (the final read-back of the largest label in use)
   int cur = 0;
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
   hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
@@ -1168,10 +1175,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
     }
     for (int it = 1; it < depth; ++it) {
       int lc = 0;
-      if (tiles) {
-        hipLaunchKernelGGL(k_pclt_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], plive[lc]);
-        VGS_HIP_TRY(c, hipMemsetAsync(tchg[lc], 0x01, (size_t)NT * 4, c->stream));   // the first sweep of a round works every tile
-      }
+      if (tiles) hipLaunchKernelGGL(k_pclt_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], plive[lc], tchg[lc], NT);   // (NT <= V) the first sweep of a round works every tile
       else hipLaunchKernelGGL(k_pcl_live_init, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], live[lc]);
       // fixed point of the live flags: the recursion is on smaller labels, so it ends -- a sweep that changes nothing is the proof.
       // Sweeps go out in pairs with one read-back per pair (a sweep at the fixed point changes nothing, so a spare one is harmless):
@@ -1182,19 +1186,21 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       bool settled = false;
       for (int sweep = 0, nb = tiles ? 4 : 2; sweep < 4096 && !settled; sweep += nb, nb = 2) {
         unsigned int ch[6] = {1u, 1u, 1u, 1u, 1u, 1u};
-        VGS_HIP_TRY(c, hipMemsetAsync(d_changed, 0, 4 * (size_t)nb, c->stream));
+        if (ring_at + nb > RING) { VGS_HIP_TRY(c, hipMemsetAsync(d_ring, 0, (size_t)RING * 4, c->stream)); ring_at = 0; }
+        unsigned int* const d_chg = d_ring + ring_at;
+        ring_at += nb;
         for (int k = 0; k < nb; ++k) {
           if (tiles)
             hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                                (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
-                               d_changed + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr,
+                               d_chg + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr,
                                (const int32_t*)c->vc_nbr_tiles.p, (const uint32_t*)tchg[lc], tchg[lc ^ 1]);
           else
             hipLaunchKernelGGL(k_pcl_live, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
-                               live[lc ^ 1], d_changed + k);
+                               live[lc ^ 1], d_chg + k);
           lc ^= 1;
         }
-        VGS_READBACK(c, ch, d_changed, 4 * (size_t)nb);
+        VGS_READBACK(c, ch, d_chg, 4 * (size_t)nb);
         for (int k = 0; k < nb; ++k) settled = settled || !ch[k];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
       }
       if (!settled) { c->err = "svgs_supervoxels (vccs_mode 1): the live flags did not reach their fixed point in 4096 sweeps"; return VGS_E_STATE; }

@@ -269,6 +269,7 @@ struct vgs_ctx {
   DevBuf<int32_t> vc_nbr_tiles;                // vccs_mode 1: the tiles on the 26 sides of a tile ([NT][27], -1: none)
   DevBuf<int32_t> vc_plive;                    // vccs_mode 1 over tiles: owner << 1 | live, two sweeps' worth
   DevBuf<uint16_t> vc_cell;                    // a voxel's cell in its tile's 10^3 label array
+  DevBuf<unsigned int> vc_ring;   // (vccs_mode 1) the sweeps' change counters of a pass
   DevBuf<uint64_t> vc_halo, vc_tile_meta, vc_pool;   // (voxel, cell) of the voxels in the tiles' shells; (offset, length) per tile; entries handed out
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
