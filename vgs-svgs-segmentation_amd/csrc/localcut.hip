@@ -628,7 +628,7 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
   if (u < U) {
     const int m = (int)(prune ? adj_mused[u] : adj_cnt[u]);
     cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 5 : (m <= max_c ? 2 : 3)));
-    if (sample && cls <= 1 && (u & 15) == 0) cls = 6;   // every sixteenth voxel of the one-wavefront classes (k_count_classes counts alike)
+    if (sample && cls <= 1 && (u & (int64_t)(sample - 1)) == 0) cls = 6;   // every sample-th voxel of the one-wavefront classes (k_count_classes counts alike)
     if (cls == 0 && nl_cnt && nl_cnt[used_ids[u]] != NL_NONE && (int)nl_tot[used_ids[u]] <= a1_max) cls = 4;   // a voxel without a list stays in A   // every sixteenth voxel of the one-wavefront classes (before the A1 split: k_count_classes counts alike)
   }
   unsigned long long mk[LC_NCLASS];
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restri
   __syncthreads();
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cls = -1;
-  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); if (sample && cls <= 1 && (u & 15) == 0) cls = 5; }
+  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); if (sample && cls <= 1 && (u & (int64_t)(sample - 1)) == 0) cls = 5; }
   for (int k = 0; k < 6; ++k) {
     const unsigned long long mk = __ballot(cls == k);
     if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_cnt[k], (unsigned int)__popcll(mk));
@@ -816,7 +816,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   unsigned int* d_ncls = (unsigned int*)(c->counters.p + 44);   // words 44-46: A + A1, B, C, D, C0
   const int max_c0 = c->K.no_c0 ? WAVE_B : WAVE_C0;   // VGS_NO_C0: class C takes them all
   const bool dense_ = !c->K.no_dense;
-  const int sample = (c->pl_enabled && dense_ && !c->K.no_vote) ? 1 : 0;
+  const int sample = (c->pl_enabled && dense_ && !c->K.no_vote) ? c->K.vote_period : 0;   // a power of two: one voxel in so many is a sample
   if (early_sizes) {
     hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls, sample);
     vgs_status sb = vgs_readback_begin(c, d_ncls, 24);

@@ -85,6 +85,10 @@
 #define LW_PENDING_LISTED 0xff   // pending[u] of a voxel that is already in a hand-over list (k_ho_lists leaves it alone)
 #define LW_HO_VOTE 0x100
 #define LW_VOTE_BASE 64    // counter words 64 .. 127
+#ifndef LW_VOTE_WORDS
+#define LW_VOTE_WORDS 64u  // words in use (a power of two <= 64).  NOT fewer: every wavefront of the bulk launch reads one of them past the scalar
+                           // cache, and with 16 words (two cache lines) those reads pile up on two L2 channels -- the bulk kernel took 5.9 instead of 2.7 ms
+#endif
 enum { LW_WHY_GAVE_UP = 0, LW_WHY_VOTED, LW_WHY_SIZE, LW_N_WHY };   // (one reason for every way the lazy schedule gives a voxel up: the kernel has no register to spare for more)
 struct LwParams {
   LcParams lc;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       // the scene's samples (see LwParams::ho_bins): a scalar load that bypasses the scalar cache, which does not see the samples'
       // atomics -- no vector register is held for it, and the wavefront that hands over leaves here
       unsigned long long vote_word;
-      const unsigned long long* vp = counters + LW_VOTE_BASE + (blockIdx.x & 63u);
+      const unsigned long long* vp = counters + LW_VOTE_BASE + (blockIdx.x & (LW_VOTE_WORDS - 1u));
       asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(vote_word) : "s"(vp) : "memory");
       const uint32_t fin = (uint32_t)vote_word, gave = (uint32_t)(vote_word >> 32);
       if ((fin + gave >= 8u) && (gave * 8u >= (fin + gave) * 7u)) {
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       // the launch cannot end before they have -- 4 ms, whatever the wavefronts do.)
       if (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) P.pending[u] = (uint8_t)(1 + bin);
       else { fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u; P.pending[u] = LW_PENDING_LISTED; }
-      if constexpr (SAMPLED) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & 63u)], 1ull << 32);   // a sample that gave up
+      if constexpr (SAMPLED) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & (LW_VOTE_WORDS - 1u))], 1ull << 32);   // a sample that gave up
     }
     return;
   }
@@ -1190,7 +1194,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
     }
   }
   if (lane == 0) evals_out[u] = n_evals;  // summed on the host on request: no same-address atomics on the hot path
-  if constexpr (SAMPLED) { if (lane == 0 && m >= 2) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & 63u)], 1ull); }   // a sample that finished
+  if constexpr (SAMPLED) { if (lane == 0 && m >= 2) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & (LW_VOTE_WORDS - 1u))], 1ull); }   // a sample that finished
 #ifdef VGS_PROF
   if (lane == 0 && dbg_out) { long long tnow = clock64(); dbg_out[4 * (size_t)u + 0] = (uint32_t)m; dbg_out[4 * (size_t)u + 1] = (uint32_t)prof[8]; dbg_out[4 * (size_t)u + 2] = (uint32_t)((tnow - t_start) >> 4); dbg_out[4 * (size_t)u + 3] = (uint32_t)n_evals; }
   if (lane == 0) { prof[11] = 1; prof[12] = (unsigned long long)merges; prof[13] = (unsigned long long)m; for (int k = 0; k < 16; ++k) if (prof[k]) atomicAdd(&counters[16 + k], prof[k]); }

@@ -93,6 +93,7 @@ struct VgsKnobs {
   bool no_adjmasks = false;  // VGS_NO_ADJMASKS
   bool no_packed_sort = false;   // VGS_NO_PACKED_SORT: (code, index) pairs through the voxelize sort instead of one packed key
   bool no_early_union = false;   // VGS_NO_EARLY_UNION: the union-find runs behind closestCheck as in rounds 1-3
+  int vote_period = 64;          // VGS_VOTE_PERIOD (power of two): one voxel in so many of the one-wavefront classes runs as a sample
   bool no_tile_early = false;    // VGS_NO_TILE_EARLY: a tile's first hooks and unions wait behind closestCheck (rounds 3-4)
   int cross_lds_kb = 0;          // VGS_CROSS_LDS: KB of (unused) LDS per wavefront of crossValidation's FIRST pass and its unions -- caps how many
                                  // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
