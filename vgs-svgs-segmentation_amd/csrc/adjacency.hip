@@ -176,14 +176,17 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
 // (round 4: balls up to 12 voxels -- 7 x 7 x 7 bricks, six per lane -- take this path too: config 2's ball of ten voxels went through
 // the general kernel's 2048-slot pass, which tests all 4189 offsets of the ball where a planar neighbourhood occupies 305.)
 // ADJM_TRIPS candidates per lane are kept in registers (CAPC = 64 * ADJM_TRIPS)
-template <int CAP, int NB, int ADJM_TRIPS>
+// LISTED (round 5): the rows of a device-side list (the ones the first instantiation passed on: more survivors than its list holds), a fixed
+// grid striding over it -- with a 512-entry list they stay on this path instead of the general kernel's nine dependent probe trips per row
+template <int CAP, int NB, int ADJM_TRIPS, bool LISTED = false>
 __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids, int64_t U,
                                                         const Brick* __restrict__ bricks, uint32_t hbits, const uint64_t* __restrict__ masks,
                                                         int R, float res_f, float min_x, float min_y, float min_z, float r2,
                                                         int adj_stride, uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt,
                                                         uint32_t* __restrict__ adj_mused, uint16_t* __restrict__ gtab, int gstride, int ngroups,
                                                         const int32_t* __restrict__ nvals, unsigned int* __restrict__ n_redo,
-                                                        uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off) {
+                                                        uint32_t* __restrict__ redo_out, uint16_t* __restrict__ adj_off,
+                                                        const uint32_t* __restrict__ rows_in = nullptr, const unsigned int* __restrict__ n_rows_in = nullptr) {
   constexpr int NB3 = NB * NB * NB, Bh = NB / 2, CAPC = 64 * ADJM_TRIPS;
   constexpr int BTRIPS = (NB3 + 63) / 64, ADJM_BRICKS = 64 * BTRIPS;   // bricks per lane, table size
   constexpr int ADJM_BRICKS_P2 = ADJM_BRICKS <= 64 ? 64 : (ADJM_BRICKS <= 128 ? 128 : (ADJM_BRICKS <= 256 ? 256 : 512));   // the search's first stride is half of this
@@ -205,8 +208,7 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
   __shared__ uint32_t s_hist[128], s_cur[128];   // two 16-bit counters per word: integer length l lives in word l >> 1
   __shared__ float ctab[3][32];
   const int lane = threadIdx.x;
-  const int64_t u = vgs_xcd_item(blockIdx.x, U);
-  if (u >= U) return;
+  auto do_row = [&](const int64_t u) {
   const uint32_t i = used_ids[u];
   const uint64_t code = vox_code[i];
   const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
@@ -390,6 +392,16 @@ __global__ __launch_bounds__(64) void k_adjacency_masks(const uint64_t* __restri
       gt[r] = (uint16_t)(r < ngroups ? ((s_hist[g >> 1] >> (16 * (g & 1))) & 0xffffu) : (uint32_t)cnt);
     }
   }
+  };   // do_row
+  if constexpr (LISTED) {
+    for (unsigned int w = blockIdx.x; w < *n_rows_in; w += gridDim.x) {
+      do_row((int64_t)rows_in[w]);
+      __syncthreads();   // the next row reuses the tables
+    }
+  } else {
+    const int64_t u = vgs_xcd_item(blockIdx.x, U);
+    if (u < U) do_row(u);
+  }
 }
 
 // an edge that touches an unused voxel carries the constant weight of five distances of 100 (VS:1602-1606);
@@ -522,17 +534,29 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
   if (2 * c->adj_R + 1 > 32) { c->err = "neighbour ball wider than 31 voxels (graph_size / voxel_size > ~12)"; return VGS_E_UNSUPPORTED; }
   if (c->n_off <= 1024 && !full && c->adj_mask_nb > 0 && gt && !c->K.no_adjmasks) {
     // hot path: candidates from the brick occupancy masks; rows it cannot take go through the general kernel
-    VGS_HIP_TRY(c, c->work_ids.ensure((size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
+    VGS_HIP_TRY(c, c->work_ids.ensure(2 * (size_t)U + 16)); VGS_HIP_TRY(c, c->counters.ensure(64));
     unsigned int* d_nredo = (unsigned int*)(c->counters.p + 40);
-    VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 4, c->stream));
+    VGS_HIP_TRY(c, hipMemsetAsync(d_nredo, 0, 8, c->stream));
 #define LAUNCH_ADJM(NBV)                                                                                                          \
     hipLaunchKernelGGL((k_adjacency_masks<240, NBV, 5>), dim3(vgs_xcd_grid(U)), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,  \
                        (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
                        out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo, c->work_ids.p, off)
     if (c->adj_mask_nb == 3) LAUNCH_ADJM(3); else LAUNCH_ADJM(5);
 #undef LAUNCH_ADJM
-    // rows it passed on (more candidates than its list): the general kernel, a fixed grid striding over the device-side list
-    LAUNCH_ADJ(1024, false, (unsigned int)(U < 2048 ? U : 2048), c->work_ids.p, d_nredo, nullptr);
+    // rows it passed on (more than 240 survivors: clutter): the same kernel with a 512-entry list over the device-side list of them (round 5:
+    // they used to take the general kernel's nine dependent probe trips per row -- 55 us for the launch however few they were); what even
+    // that cannot hold (more than 512 survivors, 576 candidates, a row out of band) goes on to the general kernel through a second list
+    unsigned int* d_nredo2 = d_nredo + 1;
+    uint32_t* list2 = c->work_ids.p + U;
+    const unsigned int g2 = (unsigned int)(U < 2048 ? U : 2048);
+#define LAUNCH_ADJM2(NBV)                                                                                                         \
+    hipLaunchKernelGGL((k_adjacency_masks<512, NBV, 9, true>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U,          \
+                       (const Brick*)c->hkey.p, c->hbits, c->adj_masks.p, c->adj_R, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key,     \
+                       out_cnt, out_nall, gt, c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, d_nredo2, list2, off,                      \
+                       (const uint32_t*)c->work_ids.p, (const unsigned int*)d_nredo)
+    if (c->adj_mask_nb == 3) LAUNCH_ADJM2(3); else LAUNCH_ADJM2(5);
+#undef LAUNCH_ADJM2
+    LAUNCH_ADJ(1024, false, g2, list2, d_nredo2, nullptr);
   } else if (c->n_off <= 8192 && !full && c->adj_mask_nb == 7 && gt && !c->K.no_adjmasks) {
     // balls of up to 12 voxels (config 2: ten): candidates from the occupancy masks of 7 x 7 x 7 bricks -- a planar neighbourhood
     // occupies 305 of the 4189 ball cells (up to 832 occupied cells are taken as candidates: the unused voxels count too); rows with more candidates, or more than 512 survivors, go down the general kernel's two passes
