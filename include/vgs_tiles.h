@@ -77,6 +77,9 @@ vgs_status vgs_tiles_get_times(vgs_tiles* t, double* ms, int32_t n /* <= VGS_TIL
 vgs_status vgs_tiles_get_point_labels(vgs_tiles* t, int32_t* labels /* n */, int64_t* kept_global);
 /* points this rank holds outside its own region (they may come back unlabelled: load by region) */
 vgs_status vgs_tiles_get_info(vgs_tiles* t, int64_t* n_outside, int64_t* n_local /* tile + halo */, int64_t* n_boundary_records);
+/* the last run's boundary exchange as this rank saw it: payload bytes sent and received, and how many collectives carried them (1: every
+ * rank's records fit the fixed-size all-gather of 8192 records; 3: a size word and one padded all-gather behind it) */
+vgs_status vgs_tiles_get_exchange(vgs_tiles* t, int64_t* bytes_sent, int64_t* bytes_received, int32_t* collectives);
 /* The boundary merge on its own (host arithmetic, no context, no GPU; for tests): rank r's records are entries rec_off[r] ..
  * rec_off[r+1] of code / root / cnt (vgs_get_boundary_roots), kept_local[r] its purely local segments.  Outputs: base[r] (labels of
  * rank r's local segments start there), per rank the unique local roots named by records (uroot, entries uoff[r] .. uoff[r+1]) and

@@ -196,6 +196,49 @@ def test_neighbourhoods_above_2048_voxels(gpu, oracle, monkeypatch, wide):
     assert eng.counts()["kept"] == ref.kept_clusters
 
 
+_BALL10_REF = {}
+
+
+@pytest.mark.parametrize("wide", ["pair_lists", "no_extra_large_pair_lists", "general_kernel"])
+def test_ball_of_ten_voxels_solid_block(gpu, oracle, monkeypatch, wide):
+    """BASELINE config 2's own ratio (graph 0.5 / voxel 0.05) on a solid block: the ball's offsets reach ten voxels per axis while the loop
+    that enumerates them runs to eleven.  Round 5 gated the extra-large pair-list instantiation on the loop bound, so it was never launched at
+    this ratio and the voxels class D's instantiation had queued for it (every neighbourhood above 1024 voxels) were never cut.
+    Three ways through the wide classes, each identical to the oracle: the extra-large pair-list kernel; without it (VGS_NO_PG_XL: class D's
+    instantiation hands on to the dense kernel and the general kernels behind it, as for a wider ball); no pair lists for the wide classes."""
+    import os
+    if wide == "general_kernel":
+        monkeypatch.setenv("VGS_PG_WIDE", "0")
+    if wide == "no_extra_large_pair_lists":
+        monkeypatch.setenv("VGS_NO_PG_XL", "1")
+    rng = np.random.default_rng(13)
+    xyz = (rng.uniform(0, 1, (100_000, 3)) * 0.8 + np.array([1.0, -2.0, 0.2])).astype(np.float32)
+    p = gpu.default_params(2, voxel_size=0.05, graph_size=0.5)
+    eng = gpu.Engine(p)
+    eng.set_points(xyz)
+    eng.run()
+    n = eng.adjacency_counts()
+    sc = eng.schedule_counters()
+    n_d = int((n > 1024).sum())
+    assert n.max() > 2048 and n_d > 1000 and sc["outside_limits"] == 0, (n.max(), n_d, sc)
+    if wide == "pair_lists":
+        assert sc["extra_large"] == 0 and sc["pair_list_cut"] >= n_d, sc      # (rows cut, not work items visited)
+    elif wide == "no_extra_large_pair_lists":
+        assert sc["handed_over_large"] > 0.9 * n_d and sc["pair_list_cut"] < sc["handed_over_large"], sc   # (n counts unused neighbours too)
+    else:
+        assert sc["pair_list_cut"] == 0, sc
+    if "ref" not in _BALL10_REF:
+        _BALL10_REF["ref"] = oracle.run_vgs(xyz, oracle_params(oracle, p, threads=os.cpu_count() or 1))
+    ref = _BALL10_REF["ref"]
+    for which in ("connect_cut", "connect_cross", "connect_final"):
+        off, idx = eng.lists(which)
+        roff, ridx = ref.lists(which)
+        assert np.array_equal(off, roff)
+        assert ragged_sets(off, idx) == ragged_sets(roff, ridx)
+    np.testing.assert_array_equal(eng.point_labels(), ref.labels()[0])
+    assert eng.counts()["kept"] == ref.kept_clusters
+
+
 def test_dense_volume_adjacency_second_pass(gpu, oracle):
     """A solid block of points: the search ball (radius 8 voxels, 2109 lattice cells) is full, more neighbours than the
     first adjacency pass holds (2048), so the rows go through the second pass; the lists must equal the oracle's."""

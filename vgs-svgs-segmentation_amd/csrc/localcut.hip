@@ -941,7 +941,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // workgroup waits for a contiguous hole for milliseconds (measured: 291 class-C voxels took 8.8 ms behind class A).
   // from here on the side streams carry work of this run: a failure below must make the next run wait for them
   c->pl_enabled_at_launch = false;
-  c->lc_tail.gated = false;
+  c->lc_tail.gated = false; c->lc_tail.pg_xl_queued = false;
   c->lc_tail.open = true; c->lc_tail.dense = dense; c->lc_tail.grid_f = 0; c->lc_tail.grid_g = GRID_G; c->lc_tail.tail_ms = 0.f;
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
@@ -969,14 +969,20 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // 4189 offsets), in a list of its own behind the samples' 
     uint32_t* const ids_xl_pg = c->work_ids.p + (10 + LW_HO_BINS) * U;
     unsigned int* const d_nxl = (unsigned int*)(c->counters.p + 56);
+    // The extra-large instantiation finds a vertex through a cube of 21^3 slots around the voxel: every offset of the ball must lie within
+    // ten voxels per axis.  cb_R is the ball's largest |offset| per axis (adj_R is the bound of the loop that enumerates the ball, one or
+    // two more: at graph 0.5 / voxel 0.05 it is 11 and the ball's reach is 10).  A wider ball: nobody is queued for it -- what class D's
+    // instantiation cannot hold goes to the hand-over list, the dense kernel and the general kernels behind it, as before round 5.
+    const bool pg_xl = c->cb_R <= 10 && !c->K.no_pg_xl;
+    c->lc_tail.pg_xl_queued = pg_xl && nabc[3] > 0;
     VGS_HIP_TRY(c, hipEventRecord(c->ev_ho2, c->stream2));   // the rows are built
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho2, 0));
     // the largest neighbourhoods first on the builder's stream, the bulk of them (up to 320 voxels) beside them on the other
     if (nabc[3] > 0)
       hipLaunchKernelGGL((k_localcut_pg<PG_D>), dim3(vgs_xcd_grid(nabc[3])), dim3(512), 0, c->stream2, ids_d, 0, 1, (const unsigned int*)nullptr, nabc[3], 1, c->adj_key.p,
                          c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
-                         c->cb_words, LcGate{nullptr, 0u}, ids_xl_pg, d_nxl);
-    if (nabc[3] > 0 && c->adj_R <= 10)   // what was too big for it: whole balls of up to ten voxels (the length of the list is on the device)
+                         c->cb_words, LcGate{nullptr, 0u}, pg_xl ? ids_xl_pg : (uint32_t*)nullptr, pg_xl ? d_nxl : (unsigned int*)nullptr);
+    if (nabc[3] > 0 && pg_xl)   // what was too big for it: whole balls of up to ten voxels (the length of the list is on the device)
       hipLaunchKernelGGL((k_localcut_pg<PG_XL>), dim3(256), dim3(256), 0, c->stream2, ids_xl_pg, 0, 1, d_nxl, 0u, 0, c->adj_key.p,
                          c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
                          c->cb_words, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
@@ -1209,6 +1215,8 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   unsigned long long hc[64] = {0};   // (words 58-63: the pair lists' pool and the pair-list kernel's counts)
   VGS_READBACK(c, hc, cnt, sizeof(hc));
   const unsigned long long lc_why[4] = {hc[3], hc[4], hc[5], hc[6]};   // (the first words of hc are read again behind the kernels launched below)
+  // neighbourhoods queued for the extra-large pair-list instantiation although it was not launched: their rows would never be written
+  if (!c->lc_tail.pg_xl_queued && (unsigned int)(hc[56] & 0xffffffffull) != 0u) { c->err = "local cut: voxels queued for a kernel that was not launched"; return VGS_E_STATE; }
   c->lc_tail.many = c->lc_tail.gated && (unsigned int)(hc[57] & 0xffffffffull) == LC_MANY;
   c->lc_diag[9] = (int64_t)hc[63]; c->lc_diag[10] = (int64_t)(hc[58] & 0xffffffffull); c->lc_diag[11] = (int64_t)hc[62]; c->lc_diag[12] = (int64_t)hc[60];
   const unsigned long long* h = hc;

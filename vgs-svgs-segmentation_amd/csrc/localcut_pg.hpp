@@ -119,7 +119,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     }
   };
 
-  auto process = [&](const uint32_t u) {
+  // returns whether this kernel cut the voxel (wrote its row); a voxel passed on (too_big, fallback) is somebody else's
+  auto process = [&](const uint32_t u) -> bool {
     const int m = __builtin_amdgcn_readfirstlane((int)adj_cnt[u]);
     const uint64_t* row = adj_key + (int64_t)u * adj_stride;
     const uint16_t* orow = adj_off + (int64_t)u * adj_stride;
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     };
     if (m > MAXM && too_big != nullptr && orow[0] != 0xffffu) {   // the next larger instantiation takes it
       if (tid == 0) too_big[atomicAdd(n_too_big, 1u)] = u;
-      return;
+      return false;
     }
-    if (m > MAXM || orow[0] == 0xffffu || (P.dbg_max_m > 0 && m > P.dbg_max_m)) { hand_on(); return; }
+    if (m > MAXM || orow[0] == 0xffffu || (P.dbg_max_m > 0 && m > P.dbg_max_m)) { hand_on(); return false; }
     static_assert(sizeof(uint64_t) * LCAP >= 4 * 1024, "the bit row (<= 31^3 offsets) fits the edge list");
     // ---- the neighbourhood: lists, offsets, hash, segment state ----
     if constexpr (DMAP != 0) { for (int k = tid; k < (DCELLS + 1) / 2; k += TB) ((uint32_t*)dmap)[k] = 0xffffffffu; }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
       ctab3[a][k] = vm_voxel_center(key, G.res_f, a == 0 ? G.min_x : (a == 1 ? G.min_y : G.min_z));
     }
     pg_barrier();
-    if (s_i[S_BAD]) { hand_on(); return; }
+    if (s_i[S_BAD]) { hand_on(); return false; }
     unsigned int my_pairs = 0;
     bool done = m < 2 || PL.any[(uint32_t)row[0]] != 1;   // no heavy pair holds the voxel: it stays alone (uniform)
     bool handed = false;
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
       }
       PGP_CNT(12, bands); (void)bands;
     }
-    if (handed) { hand_on(); return; }
+    if (handed) { hand_on(); return false; }
 
     // =========================== phase B: edges at or below a singleton's threshold ===========================
     if (phase_a_complete && s_i[S_MERGES] < m - 1) {
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           }
           pg_barrier();
           const int nlB = s_i[S_CNT];
-          if (nlB > LCAP) { hand_on(); return; }   // the banded phase B of the dense kernel is behind the fallback list
+          if (nlB > LCAP) { hand_on(); return false; }   // the banded phase B of the dense kernel is behind the fallback list
           sort_list(nlB);
           merge_list(nlB, -1.0f);
           PGP_CNT(13, 1);
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
     if (tid == 0) evals_out[u] = (uint32_t)s_i[S_PAIRS];
     PGP_CNT(14, 1);
     PGP_ACC(7);
+    return true;
   };   // process
 
   // Either hand-over lists (largest neighbourhoods first, work_stride apart, their lengths on the device: a fixed grid strides over
@@ -659,8 +661,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
       if (it >= n_work_host || (xcd_order && (wi >> 3) >= per_xcd)) continue;
       u = work[it];
     }
-    process((uint32_t)__builtin_amdgcn_readfirstlane((int)u));
-    ++n_cut;
+    if (process((uint32_t)__builtin_amdgcn_readfirstlane((int)u))) ++n_cut;
     pg_barrier();   // the next voxel reuses every array
   }
   if (tid == 0 && n_cut) atomicAdd(&counters[63], (unsigned long long)n_cut);

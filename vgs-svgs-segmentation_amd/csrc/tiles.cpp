@@ -207,6 +207,7 @@ struct vgs_tiles {
   double lo[2] = {0, 0}, hi[2] = {0, 0};
   std::vector<float> local;   // tile + halo, packed xyz
   int64_t own_first = 0, n_own = 0, n_outside = 0, n_records = 0, kept = 0;
+  int64_t exch_sent = 0, exch_recv = 0; int exch_calls = 0;   // the last run's boundary exchange: bytes this rank sent / received, collectives it took
   double times[VGS_TILES_T_COUNT] = {0};   // last run, milliseconds of host wall time per phase (vgs_tiles_get_times)
   int strict_region = 0;      // VGS_TILES_OPT_STRICT_REGION
   int fail_phase = 0;         // tests (VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT): 1 grid, 2 stages, 3 points, 4 upload (behind the last collective of set_points)
@@ -326,8 +327,10 @@ vgs_status vgs_tiles_set_points(vgs_tiles* t, const float* xyz, int64_t n, int32
     std::fprintf(stderr, "[vgs_tiles] rank %d: %lld of %lld points lie outside this rank's region; they may come back unlabelled (-1). "
                          "Load points by region, or set VGS_TILES_OPT_STRICT_REGION to make this an error.\n", c.rank, (long long)t->n_outside, (long long)n);
   }
-  vgs_status carry = VGS_OK;
-  if (t->fail_phase == 3) { carry = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=points"; }
+  // a failure behind the last collective of the previous call (the label write-back at the end of vgs_tiles_run) has reached nobody
+  // yet: it travels in this call's status word (it used to be cleared below and never arrived)
+  vgs_status carry = t->pending;
+  if (t->fail_phase == 3 && carry == VGS_OK) { carry = VGS_E_STATE; t->err = "failure requested by VGS_TILES_FAIL_RANK / VGS_TILES_FAIL_AT=points"; }
   if (t->strict_region && t->n_outside > 0 && carry == VGS_OK) {
     carry = VGS_E_ARG;
     t->err = std::to_string(t->n_outside) + " points lie outside this rank's region (VGS_TILES_OPT_STRICT_REGION)";
@@ -470,8 +473,16 @@ vgs_status vgs_tiles_run(vgs_tiles* t) {
     }
     bool fits = true;
     for (int r = 0; r < c.world; ++r) fits = fits && (HDR + 3 * (size_t)all[cap * (size_t)r]) <= cap;
+    t->exch_sent = (int64_t)(cap * sizeof(int64_t)); t->exch_recv = t->exch_sent * c.world; t->exch_calls = 1;
     if (fits) for (int r = 0; r < c.world; ++r) gathered[(size_t)r].assign(all.begin() + (ptrdiff_t)(cap * (size_t)r), all.begin() + (ptrdiff_t)(cap * (size_t)r + HDR + 3 * (size_t)all[cap * (size_t)r]));
-    else TCOMM(all_gather_varlen(c, payload, gathered));
+    else {
+      // (a rank with more than 8192 boundary voxels -- a 10 M-point tile has 10^4 to 10^5: the sizes are known from the headers, but the
+      // helper's own size word keeps the code path one; the payload is padded to the largest rank's)
+      int64_t mx = 0;
+      for (int r = 0; r < c.world; ++r) mx = std::max<int64_t>(mx, (int64_t)(HDR + 3 * (size_t)all[cap * (size_t)r]));
+      TCOMM(all_gather_varlen(c, payload, gathered));
+      t->exch_sent += (int64_t)sizeof(int64_t) * (1 + mx); t->exch_recv += (int64_t)sizeof(int64_t) * (1 + mx) * c.world; t->exch_calls += 2;
+    }
   }
   double t4 = now_ms();
   t->times[VGS_TILES_T_EXCHANGE] = t4 - t3;
@@ -536,6 +547,14 @@ vgs_status vgs_tiles_merge_boundary(int world, const int64_t* rec_off, const uin
     if (uroot) std::copy(ur[(size_t)r].begin(), ur[(size_t)r].end(), uroot + uoff[r]);
     if (ulabel) std::copy(ul[(size_t)r].begin(), ul[(size_t)r].end(), ulabel + uoff[r]);
   }
+  return VGS_OK;
+}
+
+vgs_status vgs_tiles_get_exchange(vgs_tiles* t, int64_t* bytes_sent, int64_t* bytes_received, int32_t* collectives) {
+  if (!t) return VGS_E_ARG;
+  if (bytes_sent) *bytes_sent = t->exch_sent;
+  if (bytes_received) *bytes_received = t->exch_recv;
+  if (collectives) *collectives = t->exch_calls;
   return VGS_OK;
 }
 

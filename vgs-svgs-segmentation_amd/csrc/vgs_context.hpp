@@ -99,6 +99,7 @@ struct VgsKnobs {
                                  // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
+  bool no_pg_xl = false;         // VGS_NO_PG_XL: no extra-large pair-list instantiation (neighbourhoods above 1024 voxels take the hand-over path)
   bool no_connbits = false;  // VGS_NO_CONNBITS: crossValidation searches the neighbour's row (the path of rounds 1-3)
   bool no_pairlists = false; // VGS_NO_PAIRLISTS: no pair lists (pairlist.hpp); hand-overs and wide classes take the kernels of round 4
   bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
@@ -226,7 +227,7 @@ struct vgs_ctx {
   DevBuf<uint8_t> lc_pending;
   DevBuf<uint8_t> lc_defer_flag;   // per row: the first pass of crossValidation put it off (written by every row of that pass)
   DevBuf<uint32_t> lc_defer;
-  struct { bool open = false; bool dense = true; bool gated = false; /* merge's first pass looks at LcGate's word */ bool many = false; /* ... and found LC_MANY */ unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; } lc_tail;
+  struct { bool open = false; bool dense = true; bool gated = false; /* merge's first pass looks at LcGate's word */ bool many = false; /* ... and found LC_MANY */ unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; bool pg_xl_queued = false; /* class D's pair-list kernel queued for the extra-large one, which was launched */ } lc_tail;
   int64_t lc_diag[16] = {0};   // vgs_get_schedule_counters[_ex]
   DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
   float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;

@@ -62,6 +62,8 @@ def lib():
         L.vgs_tiles_get_point_labels.argtypes = [P, P, P]
         L.vgs_tiles_get_info.restype = C.c_int
         L.vgs_tiles_get_info.argtypes = [P, P, P, P]
+        L.vgs_tiles_get_exchange.restype = C.c_int
+        L.vgs_tiles_get_exchange.argtypes = [P, P, P, P]
         L.vgs_tiles_local_group_create.restype = C.c_int
         L.vgs_tiles_local_group_create.argtypes = [C.c_int, P]
         L.vgs_tiles_local_group_destroy.restype = None
@@ -245,6 +247,16 @@ class NativeTiles:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._ck(self._L.vgs_tiles_get_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_outside=a.value, n_local=b.value, n_boundary_records=c.value)
+
+    def exchange(self):
+        """the last run's boundary exchange: bytes this rank sent / received, collectives taken"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._ck(self._L.vgs_tiles_get_exchange(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(bytes_sent=a.value, bytes_received=b.value, collectives=c.value)
+
+    def bbox(self):
+        from .api import Engine
+        return Engine.bbox(_CtxView(self._ctx()))
 
     # read-only views of the rank's engine context (counts, stage times)
     def _ctx(self):
