@@ -81,7 +81,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
   k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
   k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m); k.dbg_xl_from = geti("VGS_DBG_XL_FROM", k.dbg_xl_from);
   k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
-  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_pg_xl = has("VGS_NO_PG_XL"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.dense_to_pg = has("VGS_DENSE_TO_PG"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.cross_lds_kb = geti("VGS_CROSS_LDS", k.cross_lds_kb); k.no_tile_early = has("VGS_NO_TILE_EARLY"); { int vp = geti("VGS_VOTE_PERIOD", k.vote_period); if (vp >= 2 && vp <= 4096 && (vp & (vp - 1)) == 0) k.vote_period = vp; } k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac);
+  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_pg_xl = has("VGS_NO_PG_XL"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.cross_lds_kb = geti("VGS_CROSS_LDS", k.cross_lds_kb); k.no_tile_early = has("VGS_NO_TILE_EARLY"); { int vp = geti("VGS_VOTE_PERIOD", k.vote_period); if (vp >= 2 && vp <= 4096 && (vp & (vp - 1)) == 0) k.vote_period = vp; } k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac);
   k.debug = has("VGS_DEBUG");
 }
 
@@ -223,7 +223,7 @@ void vgs_destroy(vgs_ctx* c) {
   c->hkey.release(); c->hval.release(); c->offsets.release(); c->adj_masks.release(); c->adj_gtab.release(); c->adj_nvals.release(); c->adj_nrank.release(); c->adj_key.release(); c->adj_off.release(); c->adj_cnt.release(); c->adj_mused.release();
   c->nl_cnt.release(); c->nl_tot.release(); c->nl_ent.release(); c->lc_ctab.release(); c->pl_state.release(); c->pl_ent.release(); c->pl_work.release();
   c->cl_off.release(); c->cl_idx.release(); c->conn.release(); c->evals.release(); c->lc_pending.release(); c->lc_defer.release(); c->lc_defer_flag.release(); c->csize.release(); c->attach.release(); c->cc_flags.release(); c->parent.release(); c->csz.release();
-  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_tile_start.release(); c->vc_cell.release(); c->vc_plive.release(); c->vc_tile_of.release(); c->vc_tchg.release(); c->vc_nbr_tiles.release(); c->vc_halo.release(); c->vc_tile_meta.release(); c->vc_pool.release(); c->vc_ring.release(); c->vc_label.release();
+  c->vc_cen.release(); c->vc_nrm.release(); c->vc_dist.release(); c->vc_state.release(); c->vc_nbr.release(); c->vc_nbr4.release(); c->vc_tile_start.release(); c->vc_cell.release(); c->vc_plive.release(); c->vc_tile_of.release(); c->vc_tchg.release(); c->vc_nbr_tiles.release(); c->vc_halo.release(); c->vc_tile_meta.release(); c->vc_pool.release(); c->vc_ring.release(); c->vc_dbg.release(); c->vc_label.release();
   c->vc_seedkey.release(); c->vc_sums.release(); c->vc_count.release(); c->vc_accu.release(); c->vc_live.release(); c->vc_alive.release();
   c->sv_label.release(); c->sv_key_a.release(); c->sv_key_b.release(); c->cell_code_a.release(); c->cell_code_b.release();
   c->cell_id_a.release(); c->cell_id_b.release(); c->cell_start.release();

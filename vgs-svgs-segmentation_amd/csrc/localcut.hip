@@ -1087,29 +1087,18 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       const LcGate g_few = {d_gate, LC_FEW}, g_many = {d_gate, LC_MANY};
       const uint32_t* ids4[LW_HO_BINS]; const unsigned int* nd4[LW_HO_BINS];
       for (int k = 0; k < LW_HO_BINS; ++k) { ids4[k] = ids_f + (size_t)k * U; nd4[k] = d_nf + k; }
-      // (the pool may be allocated by the first build of a context: its pointer is read behind the builds)
+      // (the pool is sized by vgs_pairlists_begin, once per run)
       auto pair_lists = [&]() { return PairLists{(const uint2*)c->pl_state.p, c->pl_ent.p, c->pl_state.p + (size_t)c->V * 9, c->pl_w_ring}; };
       const PgGeom G = {c->vox_code.p, c->P.voxel_size, (float)c->box.min[0], (float)c->box.min[1], (float)c->box.min[2], c->adj_r2};
       // (Few hand-overs through the pair lists as well -- mark the rows their neighbourhoods touch, build, read -- was measured in round 5:
       // 8.0 against 6.9 ms on URB10M.  Its 5 k hand-overs sit in tree crowns whose 100 k voxels are all somebody's neighbour: twenty rows
       // built per voxel cut.)
       {
-      // the dense kernel queues the neighbourhoods with more heavy edges than its list holds (a handful: 179 of 5 k on URB10M, and the
-      // slowest of its launch by far -- every band of theirs is one more sweep over all pairs) for the pair-list kernel: their rows are
-      // marked and built behind it (a few thousand), and k_localcut_pg reads them
-      uint32_t* const ids_tp = c->work_ids.p + (11 + LW_HO_BINS) * U;
-      unsigned int* const d_ntp = (unsigned int*)(c->counters.p + 47);
-      const bool to_pg = c->K.dense_to_pg;   // (measured on URB10M: no gain from it, and its chain of launches sits behind the dense kernel)
+      // (Round 5 let the dense kernel queue the neighbourhoods with more heavy edges than its list holds for the pair-list kernel, their rows
+      // marked and built behind it -- VGS_DENSE_TO_PG: measured on URB10M, no gain, and its build was not ordered behind the all-rows build on
+      // the other stream: ADVICE r5.  Removed; those neighbourhoods take the dense kernel's own bands.)
       hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(grid_f), dim3(256), 0, c->stream3, ids_f, (int)U, LW_HO_BINS, d_nf, c->adj_key.p, c->adj_cnt.p,
-                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few, to_pg ? ids_tp : (uint32_t*)nullptr, d_ntp);
-      if (to_pg) {
-        const uint32_t* tp_ids[1] = {ids_tp}; const unsigned int* tp_n[1] = {d_ntp};
-        st = vgs_pairlists_build(c, c->stream3, tp_ids, tp_n, nullptr, 1, false, LP.ctab, LP.ctab_scale, LP.d2_stop, 2, g_few, false);
-        if (st == VGS_OK && c->pl_enabled)
-          hipLaunchKernelGGL((k_localcut_pg<PG_SMALL>), dim3(std::min<unsigned int>(grid_f, 2048u)), dim3(256), 0, c->stream3, ids_tp, 0, 1, d_ntp, 0u, 0, c->adj_key.p, c->adj_cnt.p,
-                             c->adj_stride, c->adj_off.p, c->node.p, LP, pair_lists(), G, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, (uint8_t*)nullptr,
-                             (uint32_t*)nullptr, 0, 0, g_few, (uint32_t*)nullptr, (unsigned int*)nullptr);
-      }
+                         c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p, g_few, (uint32_t*)nullptr, (unsigned int*)nullptr);
       // (the pair-list chain on a stream of its own: when it is not wanted its four empty launches end beside the dense kernel, not behind it)
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho, 0));
       // (many hand-overs: their neighbourhoods cover practically every row, so every row is built -- marking the wanted ones is 15 M

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
   if (tid < PL_TBINS) s_ctab[tid] = P.ctab[tid];
   const unsigned int n_items = n_work_dev ? *n_work_dev : (unsigned int)n_work;
   unsigned int chunk_pos = 0u, chunk_end = 0u;   // this workgroup's piece of the pool (uniform)
+  bool pool_done = false;                        // ... it lies behind the pool's end: no further chunk is taken (uniform)
   for (unsigned int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t u = work ? (int64_t)work[item] : (int64_t)item;
     const uint32_t vid = used_ids[u];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
     // ROW was 133 k returning atomics on one address on the noisy surface -- they serialise at ~15 ns each and took two of the
     // kernel's 2.0 ms.
     constexpr unsigned int PL_CHUNK = PL_CHUNK_OF(CAP);
-    if (nk > 0 && chunk_pos + (unsigned int)nk > chunk_end) {   // uniform
+    if (nk > 0 && !pool_done && chunk_pos + (unsigned int)nk > chunk_end) {   // uniform
       if (tid == 0) s_base = atomicAdd(cursor, PL_CHUNK);
       pl_barrier<NWV>();
       chunk_pos = s_base;
@@ -206,7 +207,10 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_lists(const uint32_t* __restr
     }
     const unsigned int base_e = chunk_pos;
     chunk_pos += (unsigned int)nk;
-    if (nk > 0 && (unsigned long long)chunk_end > (unsigned long long)pool_cap) {   // uniform: the chunk lies (partly) behind the pool's end
+    // (a workgroup that has found the pool exhausted takes no further chunk: the 32-bit cursor ends at most one chunk per workgroup behind
+    // the pool's end -- the pool is capped at 4.0e9 entries -- instead of advancing with every row of the run and wrapping: ADVICE r5)
+    if (nk > 0 && (pool_done || (unsigned long long)chunk_end > (unsigned long long)pool_cap)) {   // uniform: the chunk lies (partly) behind the pool's end
+      pool_done = true;
       if (tid == 0) { idx[vid] = make_uint2(0u, PL_UNUSABLE); atomicAdd(n_full, 1ull); }
       continue;
     }
@@ -279,6 +283,29 @@ vgs_status vgs_pairlists_begin(vgs_ctx* c, hipStream_t strm) {
     W.inv_sig_c = 1.0f / c->P.sig_c; W.inv_sig_w2 = 1.0f / (c->P.sig_w * c->P.sig_w); W.svgs = 0;
     c->pl_w_ring = d > 0.0f ? vm_weight_bound_d(d * d * (1.0f - 2.0e-6f), W) : __builtin_huge_valf();
   }
+  // The pool, sized ONCE per run (up to three builds of a run, on different streams, each used to look at the free memory again,
+  // and a build that found more of it re-allocated the pool under the index entries and the launches of the earlier ones): at most half of a
+  // row's entries are at positive offsets; never more than the 32-bit index of an entry can name.
+  {
+    const int64_t U = c->U;
+    // (every builder workgroup may leave one chunk partly used)
+    const double want = (double)U * (double)((c->adj_stride - 1) / 2 + 1) + (double)PL_GRID_SMALL * PL_CHUNK_OF(512) + (double)PL_GRID_BIG * PL_CHUNK_OF(4096);
+    const size_t cap = (size_t)(want < 4.0e9 ? want : 4.0e9);
+    if (c->pl_ent.cap < cap) {
+      size_t freeb = 0, totb = 0;
+      (void)hipMemGetInfo(&freeb, &totb);
+      size_t take = cap;
+      // the lists are a cache of weights: when the device cannot hold one for every ball offset the pool is what fits, and rows that
+      // find it exhausted keep the paths of round 4 (counted in PL_W_FULL)
+      if (take * sizeof(float4) > freeb / 2) take = freeb / 2 / sizeof(float4);
+      if (take < (size_t)U + (size_t)PL_GRID_SMALL * PL_CHUNK_OF(512) + (size_t)PL_GRID_BIG * PL_CHUNK_OF(4096)) return VGS_OK;   // (not enabled)
+      if (c->pl_ent.cap < take) {
+        // the previous run's launches may still read the old pool on the side streams
+        VGS_HIP_TRY(c, hipDeviceSynchronize());
+        VGS_HIP_TRY(c, c->pl_ent.ensure(take));
+      }
+    }
+  }
   c->pl_enabled = true;
   return VGS_OK;
 }
@@ -298,22 +325,8 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
   unsigned int* n_work = (unsigned int*)(c->counters.p + (slot == 2 ? PL_W_WORK3 : (slot ? PL_W_WORK2 : PL_W_WORK)));
   unsigned int* n_redo = n_work + 1;
   uint32_t* const wl = c->pl_work.p + (size_t)slot * 2 * (size_t)U;
-  // the pool: at most half of a row's entries are at positive offsets; never more than the 32-bit index of an entry can name
-  {
-    // (every builder workgroup may leave one chunk partly used)
-    const double want = (double)U * (double)((c->adj_stride - 1) / 2 + 1) + (double)PL_GRID_SMALL * PL_CHUNK_OF(512) + (double)PL_GRID_BIG * PL_CHUNK_OF(4096);
-    const size_t cap = (size_t)(want < 4.0e9 ? want : 4.0e9);
-    if (c->pl_ent.cap < cap) {
-      size_t freeb = 0, totb = 0;
-      (void)hipMemGetInfo(&freeb, &totb);
-      size_t take = cap;
-      // the lists are a cache of weights: when the device cannot hold one for every ball offset the pool is what fits, and rows that
-      // find it exhausted keep the paths of round 4 (counted in PL_W_FULL)
-      if (take * sizeof(float4) > freeb / 2) take = freeb / 2 / sizeof(float4);
-      if (take < (size_t)U + (size_t)PL_GRID_SMALL * PL_CHUNK_OF(512) + (size_t)PL_GRID_BIG * PL_CHUNK_OF(4096)) { c->pl_enabled = false; return VGS_OK; }
-      if (c->pl_ent.cap < take) VGS_HIP_TRY(c, c->pl_ent.ensure(take));
-    }
-  }
+  // (the pool was sized by vgs_pairlists_begin: it is never re-allocated between two builds of one run -- index entries and launches in
+  // flight hold its address)
   const unsigned int pool_cap = (unsigned int)(c->pl_ent.cap < 0xfffffff0ull ? c->pl_ent.cap : 0xfffffff0ull);
   VGS_HIP_TRY(c, hipMemsetAsync(n_work, 0, 8, strm));
   if (!all_rows) {

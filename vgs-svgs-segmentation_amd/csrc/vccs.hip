@@ -889,7 +889,8 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
                                                    float w_s_over_seed, float w_n, int32_t* __restrict__ P_out, unsigned int* __restrict__ changed,
                                                    int32_t* __restrict__ owner1, float* __restrict__ dist1, long long* __restrict__ sums,
                                                    unsigned int* __restrict__ count, const int32_t* __restrict__ nbr_tiles,
-                                                   const uint32_t* __restrict__ tchg_in, uint32_t* __restrict__ tchg_out) {
+                                                   const uint32_t* __restrict__ tchg_in, uint32_t* __restrict__ tchg_out,
+                                                   unsigned int* __restrict__ dbg_moved = nullptr) {
   // A sweep's output for a tile is a function of the flags in its window -- its own voxels and the shell, which lie in the tile and in
   // the tiles on its 26 sides.  If none of these changed a flag in the previous sweep, the window is what it was then and so is the
   // output: the tile copies its flags and is done.  From the second sweep of a round on most tiles are that quiet.
@@ -1019,6 +1020,7 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
     const bool chg = __ballot(any_change) != 0ull;
     if (lane == 0) { if (chg) atomicOr(changed, 1u); if (tchg_out) tchg_out[t] = chg ? 1u : 0u; }
   }
+  if (CLAIM && dbg_moved) { const int nm = __popcll(__ballot(touched)); if (lane == 0 && nm) atomicAdd(dbg_moved, (unsigned int)nm); }   // (lanes, not voxels: a lower bound)
   if (CLAIM && __ballot(touched) != 0ull) {
     vt_sync();
     for (int k = lane; k < VT_SLOTS; k += 64) {
@@ -1157,6 +1159,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   int ring_at = RING;   // (forces the first fill)
   unsigned int* d_changed = (unsigned int*)(c->counters.p + 56);   // (the final read-back of the largest label in use)
   int cur = 0;
+  unsigned int* dbg_moved = nullptr;   // VGS_DEBUG: lanes that moved a voxel, per pass and round
+  if (c->K.debug) { VGS_HIP_TRY(c, c->vc_dbg.ensure(128)); VGS_HIP_TRY(c, hipMemsetAsync(c->vc_dbg.p, 0, 512, c->stream)); dbg_moved = c->vc_dbg.p; }
   hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
   hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
   if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)seeds, (const unsigned long long*)nullptr, (const uint8_t*)nullptr,
@@ -1208,7 +1212,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
         hipLaunchKernelGGL(k_pclt_sweep<true>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
                            (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
                            (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p, (const int32_t*)nullptr,
-                           (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, dbg_moved ? dbg_moved + pass * 16 + it : (unsigned int*)nullptr);
       else
         hipLaunchKernelGGL(k_pcl_claim, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, own[cur], dst[cur], live[lc], cen.p, nrm.p, state, w_s_over_seed, w_n,
                            own[cur ^ 1], dst[cur ^ 1]);
@@ -1227,6 +1231,15 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   unsigned int mx = 0;
   VGS_READBACK(c, &mx, d_changed, 4);
   VGS_HIP_TRY(c, hipGetLastError());
+  if (dbg_moved) {
+    unsigned int h[128];
+    VGS_HIP_TRY(c, hipMemcpy(h, dbg_moved, sizeof(h), hipMemcpyDeviceToHost));
+    for (int pass = 0; pass < 6; ++pass) {
+      fprintf(stderr, "[vgs] vccs_mode 1 pass %d: lanes that moved a voxel per round:", pass);
+      for (int it = 1; it < depth && it < 16; ++it) fprintf(stderr, " %u", h[pass * 16 + it]);
+      fprintf(stderr, "\n");
+    }
+  }
   c->sv_max_label = (int32_t)mx;   // getMaxLabel(): the largest label still in use
   c->sv_have_labels = true;
   return VGS_OK;

@@ -105,8 +105,6 @@ struct VgsKnobs {
   bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
   int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
   int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
-  bool dense_to_pg = false;      // VGS_DENSE_TO_PG: the dense hand-over kernel queues its overflowing neighbourhoods for the pair-list kernel (off: five
-                                 // launches on the step's critical path for a handful of voxels; it takes them in bands itself)
   int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
   int pg_wide_frac = 8;      // VGS_PG_WIDEFRAC: ... when they are more than 1/N of the used voxels
   bool debug = false;        // VGS_DEBUG
@@ -272,6 +270,7 @@ struct vgs_ctx {
   DevBuf<int32_t> vc_plive;                    // vccs_mode 1 over tiles: owner << 1 | live, two sweeps' worth
   DevBuf<uint16_t> vc_cell;                    // a voxel's cell in its tile's 10^3 label array
   DevBuf<unsigned int> vc_ring;   // (vccs_mode 1) the sweeps' change counters of a pass
+  DevBuf<unsigned int> vc_dbg;    // (vccs_mode 1, VGS_DEBUG) lanes that moved a voxel, per pass and round
   DevBuf<uint64_t> vc_halo, vc_tile_meta, vc_pool;   // (voxel, cell) of the voxels in the tiles' shells; (offset, length) per tile; entries handed out
   DevBuf<uint64_t> vc_seedkey;
   DevBuf<long long> vc_sums;
