@@ -44,9 +44,11 @@ typedef struct {
   float color_impt, spatial_impt, normal_impt; /* SVGS sig_a, sig_b, sig_c(2nd) lines 46,48,50 */
   int32_t q7_count_as_index; /* 1 = reproduce closestCheck reading the neighbour count as a voxel id (VS:2243) */
   int32_t device;        /* HIP device ordinal */
-  int32_t vccs_mode;     /* svgs_supervoxels: 0 = synchronous rounds (every voxel decides from the state at the start of a round),
-                          * 1 = pcl::SupervoxelClustering's own order: supervoxels take their turns one after the other in label
-                          * order, 2-ring normals, seed rejection (csrc/vccs.hip; unpinned against PCL either way) */
+  int32_t vccs_mode;     /* svgs_supervoxels: 1 (the default of vgs_params_default_svgs since round 6) = pcl::SupervoxelClustering's own
+                          * order: supervoxels take their turns one after the other in label order, 2-ring normals, seed rejection, the
+                          * adjacency octree's own lattice, refineNormals, re-seeding by the nearest of all voxels;
+                          * 0 = a faster synchronous variant (every voxel decides from the state at the start of a round): a DIFFERENT
+                          * algorithm whose final segments are not within P2 of mode 1's (csrc/vccs.hip; unpinned against PCL either way) */
 } vgs_params;
 
 typedef struct vgs_ctx vgs_ctx;
@@ -146,6 +148,8 @@ vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
 /* round 5: 9 voxels cut by the pair-list kernel (csrc/localcut_pg.hpp), 10 entries of the pair lists built for them (csrc/pairlist.hpp),
  * 11 one-wavefront voxels handed over without a try on the strength of the scene's samples (LwParams::vote), 12 rows that found the
  * pair lists' pool exhausted */
+/* round 6: 13 voxels the early hand-over's readers left in their queue (finished behind the stage; 0 unless they ran out of patience),
+ * 14 voxels handed over through that queue while the bulk class was still running (VGS_EARLY_HO; csrc/localcut_dense.hpp, queue mode) */
 vgs_status vgs_get_schedule_counters_ex(vgs_ctx* ctx, int64_t* out, int32_t n);
 /* Screening table of the dense hand-over kernels for a parameter set (host arithmetic, no context, no GPU; for tests): a
  * pair of valid positions and normals whose squared centroid distance d2 is >= *d2_stop, or whose dot(n1, n2) lies in

@@ -17,4 +17,4 @@ def test_register_network_sorts_like_std_sort(mean):
         pytest.skip("tools/regsort_test is not built (make -C vgs-svgs-segmentation_amd/csrc regsort_test)")
     out = subprocess.run([EXE, "20000", str(mean)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("(wrong keys 0)") == 4, out.stdout   # block form, LDS network, eight keys per lane, two halves
+    assert out.stdout.count("(wrong keys 0)") == 5, out.stdout   # block form, one-word keys (round 6: ties, dropped entries, out-of-window lists), LDS network, eight keys per lane, two halves

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def run(gpu, oracle):
     xyz = gpu.scenes.urban_scene(250_000)
-    p = gpu.default_params(3)
+    p = gpu.default_params(3, vccs_mode=0)    # the synchronous variant (the default is PCL's order since round 6: run_pcl below)
     eng = gpu.Engine(p)
     eng.set_points(xyz)
     eng.run()                      # svgs_supervoxels + svgs_segment (segmentationSVGS, test:138-160)
@@ -105,12 +105,28 @@ def test_end_to_end_matches_oracle_pipeline(run, oracle):
 def run_pcl(request, gpu, oracle):
     name, n = request.param
     xyz = {"urban": gpu.scenes.urban_scene, "pc": gpu.scenes.pc_scene, "town": gpu.scenes.town_scene}[name](n)
-    p = gpu.default_params(3, vccs_mode=1)
+    p = gpu.default_params(3)
+    assert p.vccs_mode == 1                   # PCL's order is what SVGS means (vgs_params_default_svgs)
     eng = gpu.Engine(p)
     eng.set_points(xyz)
     eng.run()
     labels, max_label = eng.supervoxel_labels()
     return dict(eng=eng, xyz=xyz, labels=labels, max_label=max_label, p=p)
+
+
+def test_synchronous_variant_is_not_within_p2_of_pcl_order(run_pcl, gpu):
+    """how far are the FINAL segments with mode 0's supervoxels from those with mode 1's?  P2 of SURVEY 8c on points
+    (>= 99.5 % in matching segments, IoU >= 0.98 for every large segment, kept count within 1 %).  Measured in round 6 (tools/sv_modes_p2.py):
+    agreement 0.92 / 0.96 / 0.93, smallest IoU 0.76 / 0.28 / 0.67 on these three scenes -- the synchronous variant is an approximation, not
+    a faster route to the same result, which is why PCL's order is the default.  The test pins that finding: should mode 0 ever come within
+    P2, the default and config 4's quoted mode are to be reconsidered."""
+    from helpers import p2_protocol
+    e0 = gpu.Engine(gpu.default_params(3, vccs_mode=0))
+    e0.set_points(run_pcl["xyz"])
+    e0.run()
+    r = p2_protocol(e0.point_labels(), run_pcl["eng"].point_labels(), np.arange(run_pcl["xyz"].shape[0]), min_voxels=2000)
+    assert 0.85 <= r["agreement"] < 0.995, r            # the same scene structure, not the same segments
+    assert r["min_iou"] < 0.98, r
 
 
 def test_pcl_order_labels_match_the_sequential_restatement(run_pcl, oracle):

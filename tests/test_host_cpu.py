@@ -30,6 +30,7 @@ def test_defaults_match_task_files(vgs):
     assert s.method == 3 and np.float32(s.voxel_size) == np.float32(0.05) and np.float32(s.seed_size) == np.float32(0.25)
     assert np.float32(s.sig_w) == np.float32(1.0) and np.float32(s.cut_thred) == np.float32(0.5)
     assert (np.float32(s.color_impt), np.float32(s.spatial_impt), np.float32(s.normal_impt)) == (np.float32(0), np.float32(0.25), np.float32(0.75))
+    assert s.vccs_mode == 1      # createSupervoxels calls pcl::SupervoxelClustering (SS:265-284): PCL's own order is the default
 
 
 def _write_task(path, method, lines):

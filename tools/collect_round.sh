@@ -3,13 +3,13 @@
 #   bench (config 3):  kernel stats, PMC per launch (traffic + instruction + cycle passes), traffic.json, step timeline, stage bandwidths,
 #                      instruction counts of the bulk kernel phase by phase -> valu_mix.json
 #   c2, c3n:           line, kernel stats, PMC per launch            xl: line (the solid block at r = 10)
-#   c4, c4p:           line, kernel stats
+#   c4, c4s:           line, kernel stats (c4 = PCL order, the default; c4s = the synchronous variant)
 # The box holds no .git: the commit comes in as an argument (the caller's `git rev-parse --short HEAD`, clean tree) and the script
 # REFUSES a tag directory that already holds files of another commit (profiles/<tag>_MANIFEST.json lists file -> commit).
 # usage (from the container):  gpurun --timeout 2400 -- 'tools/collect_round.sh r05 <commit> [parts]'     parts default: all
-#        parts: bench pmc timeline phases c2 c3n xl c4 c4p
+#        parts: bench pmc timeline phases c2 c3n xl c4 c4s
 tag=${1:?tag}; commit=${2:?commit}; shift 2
-parts=${*:-bench pmc timeline phases c2 c3n xl c4 c4p}
+parts=${*:-bench pmc timeline phases c2 c3n xl c4 c4s}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profiles
 mkdir -p $out
@@ -19,7 +19,7 @@ import json, sys
 m, commit, parts = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3].split()
 # a part may be re-collected at a new commit only together with everything that shares its kernels: all or nothing
 other = sorted({c for f, c in m.items() if c != commit})
-if other and set(parts) != set("bench pmc timeline phases c2 c3n xl c4 c4p".split()):
+if other and set(parts) != set("bench pmc timeline phases c2 c3n xl c4 c4s".split()):
     print(f"profiles of {other} are in the manifest: collect ALL parts at {commit}, not a subset", file=sys.stderr); sys.exit(1)
 PY
 then exit 2; fi
@@ -83,7 +83,7 @@ if has xl; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_xl -o kt -- python3 $R/tools/run_config.py xl 0 3 > /dev/null 2>&1
   cp /tmp/kt_xl/kt_kernel_stats.csv $out/${tag}_xl_kernel_stats.csv
 fi
-for cfg in c4 c4p; do
+for cfg in c4 c4s; do
   if has $cfg; then
     python3 $R/tools/run_config.py $cfg 0 5 > $out/${tag}_${cfg}_line.json 2> $out/${tag}_${cfg}_stderr.txt
     rm -rf /tmp/kt_$cfg

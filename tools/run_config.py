@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one BASELINE.json configuration on the GPU and print ONE bench-style JSON line (counts, ms per step, stage times).
-usage: tools/run_config.py c1|c2|c3|c3n|c4|c4p|xl [points] [steps]      (not the bench contract: bench.py times configs[2])"""
+usage: tools/run_config.py c1|c2|c3|c3n|c4|c4s|xl [points] [steps]      (not the bench contract: bench.py times configs[2])"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vgs_svgs_segmentation_amd as v
@@ -12,10 +12,10 @@ if cfg == "c2":
     xyz, p, name = v.scenes.pc_scene(n or 1_000_000), v.default_params(2, voxel_size=0.05), "PC1M: planar+cylinder scene, VGS, voxel 0.05 m, graph 0.5 m"
 elif cfg == "c3":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(2, voxel_size=0.1), "URB10M: urban scene, VGS, voxel 0.1 m, graph 0.5 m"
-elif cfg == "c4":
-    xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3), "URB10M: urban scene, SVGS (Task_File_SVGS.txt: voxel 0.05 m, seed 0.25 m, graph 0.5 m)"
-elif cfg == "c4p":
-    xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3, vccs_mode=1), "URB10M: urban scene, SVGS, supervoxels in PCL's own order (vccs_mode 1)"
+elif cfg in ("c4", "c4p", "c4s"):   # BASELINE config 4; supervoxels in PCL's own order are the default since round 6 (c4p: the name rounds 3-5 used for it)
+    xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3), "URB10M: urban scene, SVGS (Task_File_SVGS.txt: voxel 0.05 m, seed 0.25 m, graph 0.5 m), supervoxels in PCL's own order (vccs_mode 1, the default)"
+elif cfg == "c4s":
+    xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3, vccs_mode=0), "URB10M: urban scene, SVGS with the synchronous supervoxel variant (vccs_mode 0: an approximation, not within P2 of the default)"
 elif cfg == "c3n":
     xyz, p, name = v.scenes.noisy_surface_scene(n or 5_000_000), v.default_params(2, voxel_size=0.1), "C3N: undulating surface, 3 cm range noise, VGS, voxel 0.1 m, graph 0.5 m"
 elif cfg == "xl":
@@ -29,7 +29,7 @@ eng.set_points(xyz)
 ms, acc = [], {}
 for it in range(steps + 1):
     t = time.perf_counter()
-    if cfg in ("c4", "c4p"):
+    if cfg in ("c4", "c4p", "c4s"):
         eng.supervoxels()   # run() keeps supervoxel labels once they exist: createSupervoxels is part of every step
     eng.run()
     dt = (time.perf_counter() - t) * 1e3

@@ -151,6 +151,156 @@ __device__ __forceinline__ void sort_desc(uint64_t* lk, int cnt, int lane) {
   for (int r = 0; r < K; ++r) { const int e = lane * K + r; if (e < cnt) lk[e] = k[r]; }
 }
 
+// ---- the same sort on 32-bit keys (round 6) -------------------------------------------------------------------------------------------
+// A comparator of the network above is v_cmp_gt_u64 and four v_cndmask_b32 -- five instructions of the half-rate class (tools/valu_rate.hip:
+// 4.1 cycles each against 2.2 for full-rate ones), two DPP moves more across lanes; 87 % of the sort's instructions.  The lists of phase A
+// hold weights in (thr0, 1] with thr0 >= 0.5: 2^23 float values at most, so  key32 = (weight bits - wbase) << 9 | (511 - slot)  orders 512
+// slots by weight in ONE word -- and a comparator on one word is v_max_u32 + v_min_u32, full rate, with the DPP move folded into either.
+// Directions: instead of selecting "keep the larger / the smaller" per block (a select per key and stage), the lanes of an ascending block
+// hold their keys COMPLEMENTED while it is one -- sorting ~k descending is sorting k ascending -- so every lane-dependent comparator runs
+// one way; the complement moves once per merge level (one v_xor per key).  What is left of the half-rate class is one select per key and
+// cross-lane stage (the lower lane of a pair keeps the maximum, the upper one the minimum).
+// The 64-bit keys come back through the slots: position i takes lk[slot of the i-th key32].  Keys of equal weight are then in slot order,
+// not in the order of their low words: runs of equal high words (rare: two weights of one neighbourhood with the same 23 bits) are put
+// right by adjacent exchanges in registers until none is left -- the result is the descending order of the full 64-bit keys, exactly what
+// sort_desc gives.  A key outside the window (never in phase A; the check is one compare per key) sends the list to sort_desc.
+template <int J>
+__device__ __forceinline__ uint32_t other_lane32(uint32_t x) {
+  if constexpr (J == 0) return dpp_all<0xB1>(x);                                       // quad_perm [1,0,3,2]
+  else if constexpr (J == 1) return dpp_all<0x4E>(x);                                  // quad_perm [2,3,0,1]
+  else if constexpr (J == 2) { uint32_t o = dpp_all<0x104>(x); return dpp<0x114, 0xa>(o, x); }
+  else return dpp_all<0x128>(x);                                                       // row_ror:8
+}
+// lane stride 1 << J, every block descending in what the lanes hold: the lower lane of a pair keeps the larger key
+template <int K, int J>
+__device__ __forceinline__ void lane_stage32(uint32_t (&k)[K], bool lower) {
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    uint32_t a, b;
+    if constexpr (J <= 3) { a = k[r]; b = other_lane32<J>(k[r]); }
+    else if constexpr (J == 4) { auto s = __builtin_amdgcn_permlane16_swap(k[r], k[r], false, false); a = s[0]; b = s[1]; }
+    else { auto s = __builtin_amdgcn_permlane32_swap(k[r], k[r], false, false); a = s[0]; b = s[1]; }
+    const uint32_t mx = a > b ? a : b, mn = a > b ? b : a;   // v_max_u32 / v_min_u32
+    k[r] = lower ? mx : mn;
+  }
+}
+template <int K, int LOGK, int LOGN, int S, int J>
+__device__ __forceinline__ void stage32(uint32_t (&k)[K], int lane) {
+  if constexpr (J >= LOGK) {
+    lane_stage32<K, J - LOGK>(k, ((lane >> (J - LOGK)) & 1) == 0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      if ((r >> J) & 1) continue;
+      const int r2 = r + (1 << J);
+      // S < LOGK: the block's direction is a bit of the register index, known here; otherwise descending (complemented where ascending)
+      const bool desc = (S >= LOGK) || (((r >> S) & 1) == 0);
+      const uint32_t x = k[r], y = k[r2];
+      const uint32_t mx = x > y ? x : y, mn = x > y ? y : x;
+      k[r] = desc ? mx : mn;
+      k[r2] = desc ? mn : mx;
+    }
+  }
+}
+template <int K, int LOGK, int LOGN, int S, int J>
+struct Strides32 {
+  static __device__ __forceinline__ void run(uint32_t (&k)[K], int lane) {
+    stage32<K, LOGK, LOGN, S, J>(k, lane);
+    Strides32<K, LOGK, LOGN, S, J - 1>::run(k, lane);
+  }
+};
+template <int K, int LOGK, int LOGN, int S>
+struct Strides32<K, LOGK, LOGN, S, -1> {
+  static __device__ __forceinline__ void run(uint32_t (&)[K], int) {}
+};
+template <int K, int LOGK, int LOGN, int S>
+struct Net32 {
+  static __device__ __forceinline__ void run(uint32_t (&k)[K], int lane) {
+    Net32<K, LOGK, LOGN, S - 1>::run(k, lane);
+    if constexpr (S >= LOGK) {
+      // the lanes whose block changes direction between level S - 1 and level S complement their keys: ascending at level L (LOGK <= L <
+      // LOGN) are the lanes with bit L - LOGK set; below LOGK and at LOGN nobody is
+      int f = 0;
+      if constexpr (S > LOGK && S > 1) f ^= lane >> (S - 1 - LOGK);   // (level 0, single keys, has no direction)
+      if constexpr (S < LOGN) f ^= lane >> (S - LOGK);
+      const uint32_t m = 0u - (uint32_t)(f & 1);
+#pragma unroll
+      for (int r = 0; r < K; ++r) k[r] ^= m;
+    }
+    Strides32<K, LOGK, LOGN, S, S - 1>::run(k, lane);
+  }
+};
+template <int K, int LOGK, int LOGN>
+struct Net32<K, LOGK, LOGN, 0> {
+  static __device__ __forceinline__ void run(uint32_t (&)[K], int) {}
+};
+
+// lk[0, cnt) descending, cnt <= 64 * K <= 512, as sort_desc<K> leaves it.  wbase: every non-zero key's high word is expected in
+// [wbase, wbase + 2^23).  Returns false -- list untouched -- when a key lies outside that window (uniform): the caller takes sort_desc.
+// FIX_TIES false: the low words of equal high words already descend with the slot (pairlist.hip: the low word IS the complemented slot).
+template <int K, bool FIX_TIES = true>
+__device__ __forceinline__ bool sort_desc32(uint64_t* lk, int cnt, int lane, uint32_t wbase) {
+  constexpr int LOGK = ilog2(K), LOGN = LOGK + 6;
+  static_assert(64 * K <= 512, "nine bits of slot");
+  uint32_t k[K];
+#if REGSORT_OPAQUE_LANE
+  asm volatile("" : "+v"(lane));
+#endif
+  bool outside = false;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const int e = lane * K + r;
+    const uint32_t hi = e < cnt ? ((const uint32_t*)lk)[2 * e + 1] : 0u;   // (a dropped entry is 0: its high word is)
+    const uint32_t d = hi - wbase;
+    outside = outside || (hi != 0u && d >= (1u << 23));
+    k[r] = hi != 0u ? ((d << 9) | (uint32_t)(511 - e)) : 0u;
+  }
+  if (__ballot(outside) != 0ull) return false;
+  Net32<K, LOGK, LOGN, LOGN>::run(k, lane);
+  // does any key carry the weight of the next one?  (uniform answer; where they are is found again in LDS by the rare list that has some:
+  // a mark per position kept in a register across the write-back cost the bulk kernel of the local cut four spilled registers)
+  bool tie = false;
+  if constexpr (FIX_TIES) {
+#pragma unroll
+    for (int r = 0; r + 1 < K; ++r) tie = tie || (k[r + 1] != 0u && ((k[r] ^ k[r + 1]) >> 9) == 0u);
+    const uint32_t nxt = (uint32_t)__shfl_down((int)k[0], 1, 64);
+    tie = tie || (lane < 63 && nxt != 0u && ((k[K - 1] ^ nxt) >> 9) == 0u);
+    tie = __ballot(tie) != 0ull;
+  }
+  {
+    // the low words come back through the slots; the high word of a key is in its key32 (no second register per key)
+    uint32_t lo[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) lo[r] = k[r] != 0u ? ((const uint32_t*)lk)[2 * (511 - (int)(k[r] & 511u))] : 0u;
+    lds_fence();   // every slot has been read
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int e = lane * K + r;
+      if (e < cnt) lk[e] = k[r] != 0u ? (((uint64_t)(wbase + (k[r] >> 9)) << 32) | lo[r]) : 0ull;
+    }
+  }
+  if constexpr (FIX_TIES) {
+    if (tie) {
+      // adjacent exchanges inside the runs of equal high words, even pairs then odd pairs, until a pass moves nothing (runs are two or
+      // three keys long)
+      bool moved = true;
+      while (__ballot(moved) != 0ull) {
+        moved = false;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          lds_fence();
+          for (int e = 2 * lane + par; e + 1 < cnt; e += 128) {
+            const uint64_t x = lk[e], y = lk[e + 1];
+            if ((uint32_t)(x >> 32) == (uint32_t)(y >> 32) && x < y) { lk[e] = y; lk[e + 1] = x; moved = true; }
+          }
+        }
+      }
+      lds_fence();
+    }
+  }
+  return true;
+}
+
 // 64*K < cnt <= 128*K keys with the register budget of K per lane: both halves sorted descending one after the other, the first
 // step of their merge as a mirror step through LDS (slot i against slot 128*K - 1 - i; slots at and behind cnt are keys below
 // every real one and never move, so the list need not reach 128*K slots), then the rest of the merge on each half in registers.
