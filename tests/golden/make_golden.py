@@ -42,19 +42,25 @@ def grid_supervoxels(xyz, seed):
 SVGS_CASES = {
     # name: (scene function, n, labelling, oracle params): method 3, Task_File_SVGS.txt values unless overridden
     "svgs_urban_40k_grid": (v.scenes.urban_scene, 40_000, "grid", dict()),
-    "svgs_pc_80k_vccs": (v.scenes.pc_scene, 80_000, "vccs", dict()),
+    "svgs_pc_80k_vccs": (v.scenes.pc_scene, 80_000, "vccs", dict()),      # supervoxels in PCL's order (the engine's default since round 6)
+    "svgs_pc_80k_vccs0": (v.scenes.pc_scene, 80_000, "vccs0", dict()),    # the synchronous variant (vccs_mode 0)
     "svgs_town_30k_grid_cut03": (v.scenes.town_scene, 30_000, "grid", dict(cut_thred=0.3, sig_w=2.0, graph_size=0.6)),
 }
 
 
 def main_svgs(out_dir):
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for name, (fn, n, how, kw) in SVGS_CASES.items():
+        if only and name not in only:
+            continue
         xyz = fn(n)
         p0 = R.svgs_params(**kw)
         if how == "grid":
             labels, max_label = grid_supervoxels(xyz, p0.seed_size)
+        elif how == "vccs0":
+            labels, max_label = R.vccs(xyz, p0)     # the oracle's restatement of this repo's synchronous VCCS-style stage (unpinned against PCL)
         else:
-            labels, max_label = R.vccs(xyz, p0)     # the oracle's restatement of this repo's VCCS-style stage (unpinned against PCL)
+            labels, max_label = R.vccs_pcl(xyz, p0)  # ... of pcl::SupervoxelClustering's own order (unpinned against PCL; the default)
         rec = {"xyz": xyz, "sv_label": labels, "max_label": np.int32(max_label)}
         for math in (0, 1):
             r = R.run_svgs_from_labels(xyz, labels, max_label, R.svgs_params(math=math, flavour=1, **kw))

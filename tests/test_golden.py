@@ -111,8 +111,8 @@ def test_oracle_reproduces_svgs_golden(oracle, path):
     assert partition_agreement(g["point_label_ref"], g["point_label_ref_faithful"]) > 0.995
     for leg in ("point_label_ref", "point_label_ref_faithful"):     # full P2 of the DevMath vectors against both RefMath data flows
         assert_p2(g["point_label_dev"], g[leg], _sv_node(g))
-    if "vccs" in os.path.basename(path):   # the labelling itself is the oracle's VCCS restatement of this repo's stage
-        lab, mx = oracle.vccs(g["xyz"], oracle.svgs_params(**_params(g)))
+    if "vccs" in os.path.basename(path):   # the labelling itself is the oracle's restatement of this repo's supervoxel stage (vccs0: the synchronous variant)
+        lab, mx = (oracle.vccs if "vccs0" in os.path.basename(path) else oracle.vccs_pcl)(g["xyz"], oracle.svgs_params(**_params(g)))
         np.testing.assert_array_equal(lab, g["sv_label"])
         assert mx == int(g["max_label"])
 
@@ -147,7 +147,7 @@ def test_gpu_reproduces_svgs_golden(gpu, path):
     for leg in ("point_label_ref", "point_label_ref_faithful"):
         assert_p2(eng.point_labels(), g[leg], _sv_node(g))
     if "vccs" in os.path.basename(path):             # the engine's own supervoxel stage gives this labelling
-        e2 = gpu.Engine(p)
+        e2 = gpu.Engine(gpu.default_params(3, vccs_mode=0, **_params(g)) if "vccs0" in os.path.basename(path) else p)
         e2.set_points(g["xyz"])
         e2.supervoxels()
         lab, mx = e2.supervoxel_labels()

@@ -138,12 +138,7 @@ __global__ void k_first_violation(const float* __restrict__ xyz, int stride_f, i
 }
 
 // one thread: OctreeBox::adopt for the point the scan found (the same statements in the same order, double arithmetic)
-__global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned) {
-  if (g->done) return;
-  const unsigned long long idx = g->found;
-  g->found = ~0ull;
-  if (idx == ~0ull) { g->done = 1; return; }
-  if (pinned) { g->done = 2; return; }   // a point outside a pinned grid: the host reports it
+__device__ void grow_adopt(const float* __restrict__ xyz, int stride_f, GrowState* g, unsigned long long idx) {
   const float* pp = xyz + (int64_t)idx * stride_f;
   const float p[3] = {pp[0], pp[1], pp[2]};
   const double eps = 1.1920928955078125e-07;   // std::numeric_limits<float>::epsilon()
@@ -183,6 +178,55 @@ __global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* 
     for (int a = 0; a < 3; ++a) { e.min[a] = g->min[a]; e.shift[a] = g->shift[a]; }
   }
   g->start = (long long)idx + 1;
+}
+__global__ void k_adopt(const float* __restrict__ xyz, int stride_f, GrowState* __restrict__ g, int pinned) {
+  if (g->done) return;
+  const unsigned long long idx = g->found;
+  g->found = ~0ull;
+  if (idx == ~0ull) { g->done = 1; return; }
+  if (pinned) { g->done = 2; return; }   // a point outside a pinned grid: the host reports it
+  grow_adopt(xyz, stride_f, g, idx);
+}
+
+// The growth over the first n_prefix points in ONE launch (round 6): a cloud in random order has grown its box for the last time within its
+// first few dozen points -- every growth step doubles the box, and a point outside a box that already covers most of the scene comes soon
+// -- yet every step used to be a scan launch and an adopt launch (sixteen launches and 0.17 ms in front of the first key).  One workgroup
+// keeps the state in LDS, finds the first point of the prefix outside the box, adopts it, and starts again behind it until the prefix
+// holds none; the scans over the whole cloud (k_first_violation) continue from there, and normally find nothing.
+__global__ __launch_bounds__(1024) void k_grow_prefix(const float* __restrict__ xyz, int stride_f, int64_t n_prefix, GrowState* __restrict__ gs, int pinned) {
+  __shared__ GrowState S;
+  __shared__ unsigned long long s_best[16];
+  const int tid = threadIdx.x;
+  static_assert(sizeof(GrowState) % 8 == 0, "copied as 64-bit words");
+  for (int k = tid; k < (int)(sizeof(GrowState) / 8); k += 1024) ((unsigned long long*)&S)[k] = ((const unsigned long long*)gs)[k];
+  __syncthreads();
+  if (S.done) return;
+  while (true) {
+    BoxD box;
+    for (int a = 0; a < 3; ++a) { box.min[a] = S.min[a]; box.max[a] = S.max[a]; }
+    box.defined = S.defined;
+    const int64_t start = S.start;
+    unsigned long long best = ~0ull;
+    for (int64_t i = start + tid; i < n_prefix; i += 1024) {
+      const float* p = xyz + i * stride_f;
+      if (fv_outside(p[0], p[1], p[2], box)) { best = (unsigned long long)i; break; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_down(best, o, 64); best = other < best ? other : best; }
+    __syncthreads();   // (everybody has read the state)
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long b = ~0ull;
+      for (int w = 0; w < 16; ++w) b = s_best[w] < b ? s_best[w] : b;
+      if (b == ~0ull) { if (S.start < n_prefix) S.start = n_prefix; S.found = ~0ull; s_best[0] = 0ull; }
+      else if (pinned) { S.done = 2; s_best[0] = 0ull; }
+      else { grow_adopt(xyz, stride_f, &S, b); s_best[0] = (S.done || S.overflow) ? 0ull : 1ull; }
+    }
+    __syncthreads();
+    if (s_best[0] == 0ull) break;
+    __syncthreads();   // (s_best is rewritten at the top)
+  }
+  for (int k = tid; k < (int)(sizeof(GrowState) / 8); k += 1024) ((unsigned long long*)gs)[k] = ((const unsigned long long*)&S)[k];
 }
 
 // code = valid bit | Morton(key), key generated with the box of the point's insertion epoch
@@ -305,9 +349,13 @@ vgs_status vgs_grow_box_from(vgs_ctx* c, OctreeBox& box, bool record_epochs) {
   // few enough threads that the scan moves through the cloud front to back (a growth step is found within the first
   // trip or two: the points come in random order), enough to keep the HBM pipes full on the one scan that reads everything
   const int blocks = (int)std::max<int64_t>(8, std::min<int64_t>((c->N / 4 + 255) / 256 + 1, (int64_t)c->K.fv_blocks));
+  // the first points in one launch (k_grow_prefix); the first batch of whole-cloud scans behind it is then two pairs, not eight
+  const bool prefix = !c->K.no_grow_prefix;
+  if (prefix)
+    hipLaunchKernelGGL(k_grow_prefix, dim3(1), dim3(1024), 0, c->stream, c->xyz, c->stride_f, std::min<int64_t>(c->N, 8192), d_g, pinned);
   for (int batch = 0; batch < 64; ++batch) {
     // a scene grows its box about log2(extent / voxel) times; pairs queued after the last growth return at once
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < ((prefix && batch == 0) ? 2 : 8); ++k) {
       hipLaunchKernelGGL(k_first_violation, dim3(blocks), dim3(256), 0, c->stream, c->xyz, c->stride_f, c->N, d_g);
       hipLaunchKernelGGL(k_adopt, dim3(1), dim3(1), 0, c->stream, c->xyz, c->stride_f, d_g, pinned);
     }
