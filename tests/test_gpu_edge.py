@@ -283,7 +283,7 @@ def test_early_hand_over_queue_gives_the_same_result(gpu, monkeypatch, scene):
     if scene == "urban":
         xyz = gpu.scenes.urban_scene(400_000)
     else:
-        xyz = gpu.scenes.noisy_surface_scene(300_000)
+        xyz = gpu.scenes.noisy_surface_scene(1_500_000)
         monkeypatch.setenv("VGS_NO_VOTE", "1")
     p = gpu.default_params(2, voxel_size=0.1)
     ref = gpu.Engine(p); ref.set_points(xyz); ref.run()

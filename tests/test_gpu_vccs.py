@@ -168,7 +168,7 @@ def test_pcl_order_end_to_end(run_pcl, oracle):
 def test_pcl_order_switch_rolls_the_labels_back(gpu):
     """vccs_mode is one of the VCCS parameters: changing it invalidates supervoxel labels made by the other mode."""
     xyz = gpu.scenes.urban_scene(60_000)
-    p = gpu.default_params(3)
+    p = gpu.default_params(3, vccs_mode=0)
     eng = gpu.Engine(p)
     eng.set_points(xyz)
     eng.run()

@@ -165,6 +165,168 @@ __global__ __launch_bounds__(64) void k_adjacency(const uint64_t* __restrict__ v
   }
 }
 
+// The rows nobody else could take -- more than 2048 used neighbours: a solid volume seen through a ball of ten voxels holds up to 4159 --
+// with a WORKGROUP per row (round 6).  k_adjacency<8192> gives such a row one wavefront, and its 88 KB of LDS leave ONE wavefront per CU:
+// 66 dependent probe trips and a rank loop over groups of a hundred entries with nothing beside them to hide a single latency (33 ms for
+// the 17 k rows of the r = 10 block, 87 % of its step).  Here TB threads share the row: phase A probes the ball's offsets, every thread
+// parking its key in the row's own slot of the table (slot = offset index; the same thread reads it back); the survivors of every 64
+// offsets are counted, the counts scanned, and phase B moves the keys to their places in the list -- offset order, i.e. grouped by
+// integer length as the general kernel has them; the rank inside a group and the group table are the general kernel's, TB entries at a
+// time.  Used neighbours only (the hot path); the rows' order, offsets and group tables are the general kernel's, bit for bit.
+template <int TB>
+__global__ __launch_bounds__(TB) void k_adjacency_wide(const uint64_t* __restrict__ vox_code, const uint32_t* __restrict__ used_ids, const Brick* __restrict__ bricks,
+                                                       uint32_t hbits, const int32_t* __restrict__ offsets, int n_off, int R, int depth,
+                                                       float res_f, float min_x, float min_y, float min_z, float r2, int adj_stride,
+                                                       uint64_t* __restrict__ adj_key, uint32_t* __restrict__ adj_cnt, uint32_t* __restrict__ adj_mused,
+                                                       uint16_t* __restrict__ gtab, int gstride, int ngroups, const int32_t* __restrict__ nvals,
+                                                       const uint32_t* __restrict__ redo, const unsigned int* __restrict__ n_redo, uint16_t* __restrict__ adj_off) {
+  constexpr int CAP = 8192, NCH = CAP / 64;
+  __shared__ uint64_t lst[CAP];
+  __shared__ uint8_t gl[CAP];
+  __shared__ uint16_t loff[CAP];
+  __shared__ float ctab[3][32];
+  __shared__ int s_ch[NCH + 1];   // survivors of every 64 offsets, then their exclusive prefix sums
+  __shared__ int s_mused, s_outband;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto do_row = [&](const int64_t u) {
+    const uint32_t i = used_ids[u];
+    const uint64_t code = vox_code[i];
+    const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
+    const float cx = vm_voxel_center(kx, res_f, min_x), cy = vm_voxel_center(ky, res_f, min_y), cz = vm_voxel_center(kz, res_f, min_z);
+    const uint32_t lim = 1u << depth;
+    if (tid < 2 * R + 1) {
+      ctab[0][tid] = vm_voxel_center(kx + (uint32_t)(tid - R), res_f, min_x);
+      ctab[1][tid] = vm_voxel_center(ky + (uint32_t)(tid - R), res_f, min_y);
+      ctab[2][tid] = vm_voxel_center(kz + (uint32_t)(tid - R), res_f, min_z);
+    }
+    if (tid == 0) { s_mused = 0; s_outband = 0; }
+    for (int k = tid; k <= NCH; k += TB) s_ch[k] = 0;
+    __syncthreads();
+    uint64_t* row = adj_key + (int64_t)u * adj_stride;
+    uint16_t* orow = adj_off ? adj_off + (int64_t)u * adj_stride : nullptr;
+    const float res2 = res_f * res_f;
+    int mused = 0;
+    bool in_band = true;
+    // ---- phase A: probe, park the key in the row's slot of this offset ----
+    for (int base = wave * 64; base < n_off; base += TB) {
+      const int o = base + lane;
+      bool keep = false, is_used = false;
+      uint64_t key64 = 0;
+      if (o < n_off) {
+        const int32_t pk = offsets[o];
+        const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
+        const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;
+        if (nx < lim && ny < lim && nz < lim) {
+          const int t = brick_find(bricks, hbits, nx, ny, nz, &is_used);
+          if (t >= 0) {
+            const float tx = cx - ctab[0][dx + R];
+            const float ty = cy - ctab[1][dy + R];
+            const float tz = cz - ctab[2][dz + R];
+            const float d2 = (tx * tx + ty * ty) + tz * tz;
+            if (d2 < r2) {
+              keep = true;
+              key64 = ((uint64_t)vm_bits(d2) << 32) | (uint32_t)t;
+              const int norm = dx * dx + dy * dy + dz * dz;
+              in_band = in_band && (fabsf(d2 - (float)norm * res2) < 0.49f * res2) && (norm < 256);
+            }
+          }
+        }
+        row[o] = (keep && is_used) ? key64 : 0ull;   // (a real key is never 0: the voxel itself, d2 = 0, id >= 0 ... id 0 at distance 0 IS 0: see below)
+      }
+      mused += __popcll(__ballot(keep));
+      const unsigned long long m = __ballot(keep && is_used);
+      if (lane == 0) s_ch[base >> 6] = __popcll(m);
+    }
+    if (lane == 0 && mused) atomicAdd(&s_mused, mused);
+    if (!in_band) s_outband = 1;
+    __syncthreads();
+    // ---- the chunks' places (one wavefront; 132 chunks at most) ----
+    if (wave == 0) {
+      int carry = 0;
+      for (int b0 = 0; b0 <= NCH; b0 += 64) {
+        const int k = b0 + lane;
+        const int x = k <= NCH ? s_ch[k] : 0;
+        int incl = x;
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int y = __shfl_up(incl, o2, 64); if (lane >= o2) incl += y; }
+        if (k <= NCH) s_ch[k] = carry + incl - x;
+        carry += __shfl(incl, 63, 64);
+      }
+    }
+    __syncthreads();
+    const int cnt = s_ch[NCH];
+    // ---- phase B: every thread takes its keys back and puts them in place ----
+    for (int base = wave * 64; base < n_off; base += TB) {
+      const int o = base + lane;
+      uint64_t key64 = 0;
+      int norm = 0;
+      uint32_t poff = 0;
+      bool store = false;
+      if (o < n_off) {
+        const int32_t pk = offsets[o];
+        const int dx = (int)(int8_t)(pk & 0xff), dy = (int)(int8_t)((pk >> 8) & 0xff), dz = (int)(int8_t)((pk >> 16) & 0xff);
+        key64 = row[o];
+        // the voxel with id 0 at distance 0 has the key 0: it is the row's own voxel (offset 0, always used here) -- stored by its offset
+        store = key64 != 0ull || (pk & 0xffffff) == 0;
+        norm = dx * dx + dy * dy + dz * dz;
+        poff = (uint32_t)(dx + 16) | ((uint32_t)(dy + 16) << 5) | ((uint32_t)(dz + 16) << 10);
+      }
+      const unsigned long long m = __ballot(store);
+      if (store) { const int pos = s_ch[base >> 6] + __popcll(m & ((1ull << lane) - 1ull)); lst[pos] = key64; gl[pos] = (uint8_t)norm; loff[pos] = (uint16_t)poff; }
+    }
+    __syncthreads();
+    if (s_outband == 0) {
+      for (int p = tid; p < cnt; p += TB) {
+        const uint64_t key = lst[p];
+        const int g = gl[p];
+        int first = p, rank = 0;
+        for (int q = p - 1; q >= 0 && gl[q] == g; --q) { first = q; rank += lst[q] < key ? 1 : 0; }
+        for (int q = p + 1; q < cnt && gl[q] == g; ++q) rank += lst[q] < key ? 1 : 0;
+        row[first + rank] = key;
+        if (orow) orow[first + rank] = loff[p];
+      }
+      if (tid == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)s_mused; }
+      if (gtab) {
+        uint16_t* gt = gtab + (int64_t)u * gstride;
+        for (int r = tid; r <= ngroups; r += TB) {
+          int lo = 0, hi = cnt;
+          if (r < ngroups) {
+            const int want = nvals[r];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)gl[mid] < want) lo = mid + 1; else hi = mid; }
+          } else {
+            lo = cnt;
+          }
+          gt[r] = (uint16_t)lo;
+        }
+      }
+      return;
+    }
+    if (gtab) for (int r = tid; r <= ngroups; r += TB) gtab[(int64_t)u * gstride + r] = 0xffffu;
+    if (orow && tid == 0) orow[0] = 0xffffu;
+    int np = 64;
+    while (np < cnt) np <<= 1;
+    for (int k = cnt + tid; k < np; k += TB) lst[k] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= np; size <<= 1) {
+      for (int strd = size >> 1; strd > 0; strd >>= 1) {
+        for (int t = tid; t < (np >> 1); t += TB) {
+          const int lo = ((t / strd) * (strd << 1)) + (t & (strd - 1));
+          const int hi = lo + strd;
+          const bool up = ((lo & size) == 0);
+          const uint64_t a = lst[lo], b = lst[hi];
+          if ((a > b) == up) { lst[lo] = b; lst[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int k = tid; k < cnt; k += TB) row[k] = lst[k];
+    if (tid == 0) { adj_cnt[u] = (uint32_t)cnt; adj_mused[u] = (uint32_t)s_mused; }
+  };   // do_row
+  for (unsigned int w = blockIdx.x; w < *n_redo; w += gridDim.x) {
+    do_row((int64_t)redo[w]);
+    __syncthreads();   // the next row reuses every array
+  }
+}
+
 // ---- hot path for small balls: candidates from brick occupancy masks --------------------------------------------
 // On a surface about a sixth of the ball's lattice cells are occupied, yet the kernel above probes the brick table for
 // every one of them.  Here a lane fetches one BRICK of the (at most 5 x 5 x 5) bricks the ball touches, ANDs its occupancy
@@ -573,9 +735,14 @@ vgs_status vgs_run_adjacency(vgs_ctx* c, bool full, uint64_t* out_key, uint32_t*
     hipLaunchKernelGGL((k_adjacency<2048, false>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U, (const Brick*)c->hkey.p, c->hbits,
                        c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride, out_key, out_cnt, out_nall, gt,
                        c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, list1, d_n1, list2, off, d_n2);
-    hipLaunchKernelGGL((k_adjacency<8192, false>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U, (const Brick*)c->hkey.p, c->hbits,
-                       c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride, out_key, out_cnt, out_nall, gt,
-                       c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, list2, d_n2, (uint32_t*)nullptr, off, d_n2);
+    if (c->K.no_adj_wide)
+      hipLaunchKernelGGL((k_adjacency<8192, false>), dim3(g2), dim3(64), 0, c->stream, c->vox_code.p, row_ids, U, (const Brick*)c->hkey.p, c->hbits,
+                         c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->node.p, c->adj_stride, out_key, out_cnt, out_nall, gt,
+                         c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, list2, d_n2, (uint32_t*)nullptr, off, d_n2);
+    else   // a workgroup per row (round 6)
+      hipLaunchKernelGGL((k_adjacency_wide<512>), dim3(g2), dim3(512), 0, c->stream, c->vox_code.p, row_ids, (const Brick*)c->hkey.p, c->hbits,
+                         c->offsets.p, c->n_off, c->adj_R, c->box.depth, res_f, mnx, mny, mnz, r2, c->adj_stride, out_key, out_cnt, out_nall, gt,
+                         c->adj_gstride, c->adj_ngroups, c->adj_nvals.p, (const uint32_t*)list2, (const unsigned int*)d_n2, off);
   } else if (c->n_off <= 1024) {
     if (full) LAUNCH_ADJ(1024, true, vgs_xcd_grid(U), nullptr, nullptr, nullptr); else LAUNCH_ADJ(1024, false, vgs_xcd_grid(U), nullptr, nullptr, nullptr);
   } else if (c->n_off <= 8192) {

@@ -608,9 +608,77 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
           }
           pg_barrier();
           const int nlB = s_i[S_CNT];
-          if (nlB > LCAP) { hand_on(); return false; }   // the banded phase B of the dense kernel is behind the fallback list
-          sort_list(nlB);
-          merge_list(nlB, -1.0f);
+          if (nlB <= LCAP) {
+            sort_list(nlB);
+            merge_list(nlB, -1.0f);
+          } else {
+            // More such pairs than the list holds (a solid volume: thousands of vertices whose segments all stay below thr0).  Round 5 handed
+            // the voxel on -- for a neighbourhood above 2048 vertices that ends in the extra-large instantiation of the general kernel, 4 s a
+            // voxel on the r = 10 block.  Round 6: bands of descending weight as in localcut_dense.hpp -- one pass histograms the weights
+            // (PG_NBIN bins over [0, thr0], in the lists' position words: every list is read to its end by now), then every band -- the
+            // heaviest whole bins that fit the list -- is collected by a pass of its own, sorted and merged; pairs merged away meanwhile only
+            // make later bands shorter; the bands end when the voxel's own segment is frozen below the next one (fact F).
+            constexpr int PG_NBIN = MAXM >= 1024 ? 1024 : (MAXM >= 512 ? 512 : (MAXM >= 256 ? 256 : 128));
+            uint32_t* const hist = lpos;
+            const float scale = (float)PG_NBIN / thr0;
+            auto bin_of = [&](float w) -> int { const int bb = (int)(w * scale); return bb < 0 ? 0 : (bb > PG_NBIN - 1 ? PG_NBIN - 1 : bb); };
+            for (int k = tid; k < PG_NBIN; k += TB) hist[k] = 0u;
+            pg_barrier();
+            for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
+              int ia, ib;
+              decode(p, nb, Pb, ia, ib);
+              const int xa = alist[ia], xb = alist[ib];
+              const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;
+              if (seg[a] != seg[b]) {
+                const float w = vm_pair_weight(R(a), R(b), W);
+                ++my_pairs;
+                if (w <= thr0) atomicAdd(&hist[bin_of(w)], 1u);
+              }
+            }
+            pg_barrier();
+            int top = PG_NBIN;   // bins [top, PG_NBIN) are done
+            while (true) {
+              if (tid == 0) {
+                unsigned int acc = 0;
+                int lo = top;
+                while (lo > 0 && acc + hist[lo - 1] <= (unsigned int)LCAP) { --lo; acc += hist[lo]; }
+                s_i[S_NQ] = lo;
+                s_i[S_CNT] = 0;
+              }
+              pg_barrier();
+              const int lo = s_i[S_NQ];
+              if (lo == top) { hand_on(); return false; }   // one bin alone overflows the list: degenerate ties
+              for (uint32_t p = (uint32_t)tid; p < Pb; p += TB) {
+                int ia, ib;
+                decode(p, nb, Pb, ia, ib);
+                const int xa = alist[ia], xb = alist[ib];
+                const int a = xa < xb ? xa : xb, b = xa < xb ? xb : xa;
+                if (seg[a] != seg[b]) {
+                  const float w = vm_pair_weight(R(a), R(b), W);
+                  ++my_pairs;
+                  if (w <= thr0) {
+                    const int bb = bin_of(w);
+                    if (bb >= lo && bb < top) {
+                      const int at = atomicAdd(&s_i[S_CNT], 1);
+                      if (at < LCAP) lk[at] = ((uint64_t)vm_bits(w) << 32) | (uint64_t)(PCOMP - (((uint32_t)a << PSH) | (uint32_t)b));
+                    }
+                  }
+                }
+              }
+              pg_barrier();
+              const int nband = s_i[S_CNT] < LCAP ? s_i[S_CNT] : LCAP;   // <= the histogram's count of these bins
+              sort_list(nband);
+              merge_list(nband, -1.0f);
+              if (lo == 0) break;
+              top = lo;
+              // every pair left has a bin below `top`, so it weighs less than this
+              const float wub = (float)top / scale * 1.0001f;
+              const int r0 = seg[0];   // flattened by merge_list
+              if (!(thr[r0] < wub) || s_i[S_MERGES] >= m - 1) break;
+              pg_barrier();   // (the counters are rewritten at the top)
+            }
+            if (tid == 0) atomicAdd(&counters[0], 1ull);   // "banded"
+          }
           PGP_CNT(13, 1);
         }
         PGP_ACC(6);

@@ -101,6 +101,7 @@ struct VgsKnobs {
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
   int early_ho = 0;              // VGS_EARLY_HO=N: N persistent workgroups of the dense hand-over kernel are dispatched BEFORE the bulk class and take the voxels it
                                  // gives up from a device-side queue while it runs (0: off -- the hand-overs wait for the bulk class to end)
+  bool no_adj_wide = false;      // VGS_NO_ADJ_WIDE: rows above 2048 used neighbours keep the one-wavefront general kernel (A/B twin of round 6's workgroup per row)
   bool no_grow_prefix = false;   // VGS_NO_GROW_PREFIX: the octree box grows by one scan launch and one adopt launch per step from the first point on
   bool no_sort32 = false;        // VGS_NO_SORT32: the one-wavefront classes of the local cut keep the 64-bit sort network (A/B twin of round 6's one-word keys)
   bool no_pg_xl = false;         // VGS_NO_PG_XL: no extra-large pair-list instantiation (neighbourhoods above 1024 voxels take the hand-over path)
