@@ -138,7 +138,7 @@ def profiled_traffic(n_points):
     commit they were taken at, and the kernel's mean issue cycles per VALU instruction (profiles/rNN_valu_mix.json);
     None if a profile is missing or was taken on another workload."""
     prof = os.path.join(ROOT, "profiles")
-    for tag in ("r05", "r04", "r03", "r02", "r01"):   # the newest round's profile that exists
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):   # the newest round's profile that exists
         try:
             with open(os.path.join(prof, f"{tag}_traffic.json")) as f:
                 t = json.load(f)
@@ -517,7 +517,7 @@ def main():
             "config": {"workload": workload, "points_per_gpu": n_per, "voxels": V, "used_voxels": c["used"], "adjacency_entries": E,
                        "segments": c["kept"], "pair_evaluations": c["pairs"],
                        "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles, shared grid, one all-gather of boundary labels ({'RCCL, native driver' if rccl_comm is not None else backend})"},
-            "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,448,1> (local affinity graph + threshold-merge cut, bulk class)",
+            "roofline": {"bound": "hbm", "kernel": "k_localcut_wave<96,448,1,false,true> (local affinity graph + threshold-merge cut, bulk class, one-word sort keys)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_avg_ms,
                          "traffic_commit": prof["commit"] if prof else None,

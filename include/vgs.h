@@ -148,8 +148,6 @@ vgs_status vgs_get_schedule_counters(vgs_ctx* ctx, int64_t* out /* 8 */);
 /* round 5: 9 voxels cut by the pair-list kernel (csrc/localcut_pg.hpp), 10 entries of the pair lists built for them (csrc/pairlist.hpp),
  * 11 one-wavefront voxels handed over without a try on the strength of the scene's samples (LwParams::vote), 12 rows that found the
  * pair lists' pool exhausted */
-/* round 6: 13 voxels the early hand-over's readers left in their queue (finished behind the stage; 0 unless they ran out of patience),
- * 14 voxels handed over through that queue while the bulk class was still running (VGS_EARLY_HO; csrc/localcut_dense.hpp, queue mode) */
 vgs_status vgs_get_schedule_counters_ex(vgs_ctx* ctx, int64_t* out, int32_t n);
 /* Screening table of the dense hand-over kernels for a parameter set (host arithmetic, no context, no GPU; for tests): a
  * pair of valid positions and normals whose squared centroid distance d2 is >= *d2_stop, or whose dot(n1, n2) lies in

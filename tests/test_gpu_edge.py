@@ -273,30 +273,3 @@ def test_dense_volume_adjacency_second_pass(gpu, oracle):
             gd2 = (gd[:, 0] * gd[:, 0] + gd[:, 1] * gd[:, 1]) + gd[:, 2] * gd[:, 2]
             assert (np.diff(gd2) >= 0).all()  # getOneVoxelAdjacency order: ascending distance
 
-
-@pytest.mark.parametrize("scene", ["urban", "noisy_no_vote"])
-def test_early_hand_over_queue_gives_the_same_result(gpu, monkeypatch, scene):
-    """VGS_EARLY_HO (round 6, off by default: measured slower -- profiles/r06_ab_early_handover.txt): persistent workgroups of the dense hand-over
-    kernel, dispatched before the bulk class, take the voxels it gives up from a device-side queue while it runs.  Scheduling only: connect
-    lists, labels and counts equal the default schedule's.  The noisy surface without the samples' vote gives up more voxels than the queue has
-    slots: the rest keeps the marks and the lists of the default path."""
-    if scene == "urban":
-        xyz = gpu.scenes.urban_scene(400_000)
-    else:
-        xyz = gpu.scenes.noisy_surface_scene(1_500_000)
-        monkeypatch.setenv("VGS_NO_VOTE", "1")
-    p = gpu.default_params(2, voxel_size=0.1)
-    ref = gpu.Engine(p); ref.set_points(xyz); ref.run()
-    monkeypatch.setenv("VGS_EARLY_HO", "64")
-    eng = gpu.Engine(p); eng.set_points(xyz); eng.run()
-    sc, sr = eng.schedule_counters(), ref.schedule_counters()
-    assert sr["queued_early"] == 0 and sc["queued_early"] > 0 and sc["queue_left_over"] == 0, (sc, sr)
-    if scene != "urban":
-        assert sc["queued_early"] == 8192 and sc["handed_over"] > 8192, sc          # the queue's slots, and the marks behind them
-    for which in ("connect_cut", "connect_final"):
-        off, idx = eng.lists(which)
-        roff, ridx = ref.lists(which)
-        assert np.array_equal(off, roff) and ragged_sets(off, idx) == ragged_sets(roff, ridx)
-    np.testing.assert_array_equal(eng.point_labels(), ref.point_labels())
-    eng.run()                                                                             # a second run on the same context: the queue is reset
-    np.testing.assert_array_equal(eng.point_labels(), ref.point_labels())

@@ -92,7 +92,9 @@ def test_config4_svgs10m(gpu):
     c = eng.counts()
     assert c["supervoxels"] > 50_000
     sv, mx = eng.supervoxel_labels()
-    assert sv.min() >= 0 and sv.max() <= mx and mx == c["supervoxels"] + 1          # labels 1..max_label, the last one is not a node (SS:313)
+    # labels 1..max_label, the last one is not a node (SS:313).  In PCL's order (the default) a supervoxel left without voxels is removed for
+    # good: the labels in use have gaps, getMaxLabel() is the largest of them and the nodes are fewer (measured: 112 193 against 99 954)
+    assert sv.min() >= 0 and sv.max() <= mx and c["supervoxels"] <= mx <= 1.5 * c["supervoxels"], (mx, c["supervoxels"])
     # every point of one supervoxel carries one segment label (label == max_label is dropped by the reference, SS:313)
     ok = (sv > 0) & (sv < mx)
     first = np.full(mx + 1, -2, dtype=np.int64)

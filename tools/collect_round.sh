@@ -7,9 +7,9 @@
 # The box holds no .git: the commit comes in as an argument (the caller's `git rev-parse --short HEAD`, clean tree) and the script
 # REFUSES a tag directory that already holds files of another commit (profiles/<tag>_MANIFEST.json lists file -> commit).
 # usage (from the container):  gpurun --timeout 2400 -- 'tools/collect_round.sh r05 <commit> [parts]'     parts default: all
-#        parts: bench pmc timeline phases c2 c3n xl c4 c4s
+#        parts: bench pmc timeline phases c2 c3n xl c4 c4s c5
 tag=${1:?tag}; commit=${2:?commit}; shift 2
-parts=${*:-bench pmc timeline phases c2 c3n xl c4 c4s}
+parts=${*:-bench pmc timeline phases c2 c3n xl c4 c4s c5}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/profiles
 mkdir -p $out
@@ -19,7 +19,7 @@ import json, sys
 m, commit, parts = json.load(open(sys.argv[1])), sys.argv[2], sys.argv[3].split()
 # a part may be re-collected at a new commit only together with everything that shares its kernels: all or nothing
 other = sorted({c for f, c in m.items() if c != commit})
-if other and set(parts) != set("bench pmc timeline phases c2 c3n xl c4 c4s".split()):
+if other and set(parts) != set("bench pmc timeline phases c2 c3n xl c4 c4s c5".split()):
     print(f"profiles of {other} are in the manifest: collect ALL parts at {commit}, not a subset", file=sys.stderr); sys.exit(1)
 PY
 then exit 2; fi
@@ -91,6 +91,11 @@ for cfg in c4 c4s; do
     cp /tmp/kt_$cfg/kt_kernel_stats.csv $out/${tag}_${cfg}_kernel_stats.csv
   fi
 done
+if has c5; then
+  # config 5 at its real size on this one GPU: the test writes its evidence itself (tests/test_gpu_config5.py)
+  (cd $R && python3 -m pytest tests/test_gpu_config5.py -x -q -p no:cacheprovider > $out/${tag}_c5_stdout.txt 2>&1)
+  cp $R/gpurun_out/c5_onegpu.json $out/${tag}_c5_onegpu.json
+fi
 # empty stderr files say nothing
 find $out -name "${tag}_*_stderr.txt" -size 0 -delete
 # the manifest: every file of this call -> the commit

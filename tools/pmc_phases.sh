@@ -19,7 +19,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:48]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[(k, r["Counter_Name"])] += 1
 for k in acc:
-    if "k_localcut_wave<96, 448, 1, false>" in k:
+    if "k_localcut_wave<96, 448, 1, false" in k:
         print(sys.argv[2], {c: f"{v / calls[(k, c)]:.4g}" for c, v in sorted(acc[k].items())})
 PY
 }

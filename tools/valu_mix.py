@@ -104,7 +104,7 @@ def main():
                               cwd=CSRC, stderr=subprocess.DEVNULL)
         text = open(asm).read().split("\n")
     files, ranges = {}, source_ranges()
-    start = next(i for i, l in enumerate(text) if re.match(r"_Z15k_localcut_waveILi96ELi448ELi1ELb0EE.*:", l))
+    start = next(i for i, l in enumerate(text) if re.match(r"_Z15k_localcut_waveILi96ELi448ELi1ELb0ELb1EE.*:", l))
     end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))
     for l in text:
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
@@ -145,7 +145,7 @@ def main():
     cycles = sum(d[p] * sum(pm[p][k] * CYC[k] for k in CYC) for p in d)
     total = sum(d.values())
     issue_s = cycles / (CLOCK_GHZ * 1e9) / N_SIMD
-    res = {"kernel": "k_localcut_wave<96,448,1>", "commit": commit, "valu_wave_instructions_per_launch": total, "kernel_ms": kernel_ms,
+    res = {"kernel": "k_localcut_wave<96,448,1,false,true>", "commit": commit, "valu_wave_instructions_per_launch": total, "kernel_ms": kernel_ms,
            "static_instructions": {p: static.get(p) for p in sorted(static)}, "dynamic_per_phase": d, "mix_per_phase": pm,
            "mean_cycles_per_instruction": cycles / total, "valu_issue_frac": issue_s / (kernel_ms * 1e-3),
            "share_half_or_slower_dynamic": sum(d[p] * (pm[p]["half"] + pm[p]["quarter"]) for p in d) / total,

@@ -141,10 +141,10 @@ class Engine:
         return {k: int(c[i]) for i, k in enumerate(names)}
 
     def schedule_counters(self):
-        c = np.zeros(15, dtype=np.int64)
-        self._ck(self._L.vgs_get_schedule_counters_ex(self._h, _ptr(c), 15))
+        c = np.zeros(13, dtype=np.int64)
+        self._ck(self._L.vgs_get_schedule_counters_ex(self._h, _ptr(c), 13))
         names = ("lazy_gave_up", "list_overflow", "handed_over", "dense_sent_on", "handed_over_large", "outside_limits", "cross_put_off", "banded",
-                 "extra_large", "pair_list_cut", "pair_list_entries", "voted_over", "pair_list_pool_full", "queue_left_over", "queued_early")
+                 "extra_large", "pair_list_cut", "pair_list_entries", "voted_over", "pair_list_pool_full")
         return dict(zip(names, (int(x) for x in c)))
 
     def stage_times(self):

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
 // lists != null: workgroup b takes entry b of the concatenation of the (up to 5) hand-over lists; otherwise every pending row of [0, U)
-struct CbLists { const uint32_t* ids[6]; unsigned int end[6]; };   // end[k] = number of entries in lists 0 .. k; list 5: the early hand-over queue (voxel + 1, flag in bit 31)
+struct CbLists { const uint32_t* ids[5]; unsigned int end[5]; };   // end[k] = number of entries in lists 0 .. k
 __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pending, int64_t U, const uint32_t* __restrict__ adj_cnt, int adj_stride,
                                                   const uint8_t* __restrict__ conn, const uint16_t* __restrict__ adj_off,
                                                   int cb_R, int cb_words, uint32_t* __restrict__ cbits, CbLists L, int use_lists) {
@@ -531,10 +531,9 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
   if (use_lists) {
     const unsigned int b = blockIdx.x;
     int k = 0;
-    while (k < 5 && b >= L.end[k]) ++k;
+    while (k < 4 && b >= L.end[k]) ++k;
     if (b >= L.end[k]) return;
     u = (int64_t)L.ids[k][b - (k ? L.end[k - 1] : 0u)];
-    if (k == 5) u = (int64_t)(((uint32_t)u & 0x7fffffffu) - 1u);
   } else if (u >= U || !pending[u]) return;
   const int lane = threadIdx.x;
   for (int k = lane; k < cb_words; k += 64) cb[k] = 0u;
@@ -549,7 +548,6 @@ __global__ __launch_bounds__(64) void k_conn_bits(const uint8_t* __restrict__ pe
   for (int k = lane; k < cb_words; k += 64) cbits[(size_t)u * (size_t)cb_words + k] = cb[k];
 }
 
-__global__ void k_lc_set_word(unsigned int* w, unsigned int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // The hand-over lists of the one-wavefront classes, built from the marks their kernels left (pending[u] = 1 + list + LW_HO_BINS * why,
 // localcut_wave.hpp): voxel order, one atomic per list and 1024 voxels; the reasons are counted into the schedule counters on the way.
 // The marks become plain "pending" flags for the merge stage.
@@ -890,13 +888,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   c->cb_enabled = c->P.method == 2 && c->adj_have_off && c->cb_words > 0 && c->cb_words <= VGS_CB_MAX_WORDS && c->adj_R <= 15 && !c->K.no_connbits;
   WP.cbits = nullptr; WP.cb_R = 0; WP.cb_words = 0;
   WP.n_first_dev = nullptr; WP.n_main_dev = nullptr;
-  // early hand-over (LwParams::q_ctl): the queue behind the work lists, its control words in counter words 38-39 (zeroed with the counters)
-  // (the kernels find both from pointers they have anyway: LW_Q_WORD, LW_Q_LIST)
-  static_assert(8 + LW_Q_LIST == 11 + LW_HO_BINS, "the queue takes the list that round 5's VGS_DENSE_TO_PG used");
-  uint32_t* const q_ids = ids_f + (size_t)LW_Q_LIST * U;
-  unsigned int* const q_ctl = (unsigned int*)(c->counters.p + LW_Q_WORD);
-  const unsigned int q_cap = (unsigned int)std::min<int64_t>(U, (int64_t)LW_Q_CAP);
-  const bool early = c->K.early_ho > 0 && !c->K.no_dense && c->P.method == 2;
   if (c->cb_enabled) {
     VGS_HIP_TRY(c, c->conn_bits.ensure((size_t)U * (size_t)c->cb_words));
     WP.cbits = c->conn_bits.p; WP.cb_R = c->cb_R; WP.cb_words = c->cb_words;
@@ -955,20 +946,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   VGS_HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev[2], 0));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[2], 0));
-  c->lc_tail.early = false;
-  if (early && nabc[0] + nabc[4] > 0) {
-    // Early hand-over (round 6): K.early_ho workgroups of the dense hand-over kernel are dispatched HERE, before any of the one-wavefront
-    // classes' 5 KB workgroups exist, and read the queue the bulk class appends to until a word set behind it says the producers are through.
-    VGS_HIP_TRY(c, hipMemsetAsync(q_ids, 0, (size_t)q_cap * 4, c->stream));
-    VGS_HIP_TRY(c, hipEventRecord(c->ev_q, c->stream));
-    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream5, c->ev_q, 0));
-    hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3((unsigned int)c->K.early_ho), dim3(256), 0, c->stream5, (const uint32_t*)nullptr, (int)q_cap, DN_QUEUE,
-                       (const unsigned int*)nullptr, c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt, ids_f2, d_nf2, c->evals.p,
-                       LcGate{nullptr, 0u}, q_ids, q_ctl);
-    VGS_HIP_TRY(c, hipEventRecord(c->ev_q, c->stream5));
-    WP.ho_bins |= LW_HO_QUEUE;
-    c->lc_tail.early = true;
-  }
   // the bulk class waits on an event that crosses queues once more, so it starts a few microseconds after the others
   VGS_HIP_TRY(c, hipEventRecord(c->ev[9], c->stream3));
   VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[9], 0));
@@ -1090,10 +1067,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
 #undef LW_LAUNCH_1W
   }
   VGS_HIP_TRY(c, hipEventRecord(c->ev[11], c->stream));
-  if (c->lc_tail.early) {   // the queue's producers -- the bulk class here, the samples and class B on their stream -- are through
-    VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev[8], 0));
-    hipLaunchKernelGGL(k_lc_set_word, dim3(1), dim3(1), 0, c->stream, q_ctl + 2, 1u);
-  }
   // Hand-overs of classes A/B go to the workgroup kernel: fixed grid, list length read on the device (no host round
   // trip before the launch); the host checks the length afterwards (vgs_localcut_finish).  The kernel runs on the side
   // stream of class B, behind the bulk, and is NOT waited for here: the merge stage starts crossValidation on the rows that
@@ -1158,7 +1131,6 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
       VGS_HIP_TRY(c, hipEventRecord(c->ev_ho2, c->stream4));
       VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_ho2, 0));
     }
-    if (c->lc_tail.early) VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev_q, 0));   // ... and the queue's readers
     VGS_HIP_TRY(c, hipEventRecord(c->ev[4], c->stream3));
   }
   // the main stream goes on once every class has produced its rows or marked them pending
@@ -1246,15 +1218,10 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
   c->lc_tail.many = c->lc_tail.gated && (unsigned int)(hc[57] & 0xffffffffull) == LC_MANY;
   c->lc_diag[9] = (int64_t)hc[63]; c->lc_diag[10] = (int64_t)(hc[58] & 0xffffffffull); c->lc_diag[11] = (int64_t)hc[62]; c->lc_diag[12] = (int64_t)hc[60];
   const unsigned long long* h = hc;
-  c->lc_diag[13] = 0;
   // hand-overs of the one-wavefront classes (all size lists together), of classes C/D
   const unsigned int nfg[2] = {(unsigned int)((hc[14] & 0xffffffffull) + (hc[14] >> 32) + (hc[15] & 0xffffffffull) + (hc[15] >> 32)),
                                (unsigned int)(hc[11] >> 32)};
-  // the early hand-over queue: voxels queued (never more than its slots), taken and done by its readers
-  const unsigned int n_q = c->lc_tail.early ? std::min<unsigned int>((unsigned int)(hc[LW_Q_WORD] >> 32), (unsigned int)std::min<int64_t>(U, (int64_t)LW_Q_CAP)) : 0u;
-  const unsigned int n_q_done = c->lc_tail.early ? (unsigned int)(hc[LW_Q_WORD + 1] >> 32) : 0u;
-  uint32_t* const q_ids = ids_f + (size_t)LW_Q_LIST * U;
-  const unsigned int nf = nfg[0] + nfg[1] + n_q;
+  const unsigned int nf = nfg[0] + nfg[1];
   if (n_deferred) *n_deferred = (unsigned int)(hc[13] & 0xffffffffull);
   const bool dense = c->lc_tail.dense;   // as the launch half of the stage saw it
   const unsigned int nf2 = (unsigned int)(hc[12] & 0xffffffffull), ng2 = (unsigned int)(hc[12] >> 32);   // sent on by the dense kernels
@@ -1270,21 +1237,6 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
       // diagnostics path: lists longer than the general kernel's fixed grids
       if (nfg[0] > grid_f) { st = launch_rest(ids_f + grid_f, nfg[0] - grid_f, true); more = true; }
       if (st == VGS_OK && nfg[1] > GRID_G) { st = launch_rest(ids_g + GRID_G, nfg[1] - GRID_G, false); more = true; }
-    }
-    if (st == VGS_OK && n_q_done < n_q) {
-      // the queue's readers left before it was empty (they ran out of patience: DN_QUEUE_PATIENCE): the unflagged entries now
-      hipLaunchKernelGGL((k_localcut_dense<DN_SMALL>), dim3(std::min<unsigned int>(n_q - n_q_done, 4096u)), dim3(256), 0, c->stream, (const uint32_t*)q_ids, (int)std::min<int64_t>(U, (int64_t)LW_Q_CAP),
-                         DN_QUEUE_REST, (const unsigned int*)(c->counters.p + LW_Q_WORD), c->adj_key.p, c->adj_cnt.p, c->adj_stride, c->node.p, LP, c->conn.p, cnt,
-                         c->work_ids.p + 7 * U, (unsigned int*)(c->counters.p + 12), c->evals.p, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
-      // (what THAT sends on joins the small general kernel's list behind the entries launched above: taken by the launch below)
-      VGS_HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-      unsigned long long w12 = 0;
-      VGS_HIP_TRY(c, hipMemcpyAsync(&w12, cnt + 12, sizeof(w12), hipMemcpyDeviceToHost, c->stream));
-      VGS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-      const unsigned int nf2b = (unsigned int)(w12 & 0xffffffffull);
-      if (nf2b > nf2) st = launch_rest(c->work_ids.p + 7 * U + nf2, nf2b - nf2, true);
-      more = true;
-      c->lc_diag[13] = (int64_t)(n_q - n_q_done);
     }
     if (st != VGS_OK) return st;
     if (more) {
@@ -1319,14 +1271,12 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     unsigned int at = 0;
     for (int k = 0; k < 4; ++k) { L.ids[k] = ids_f + (size_t)k * U; at += nb4[k]; L.end[k] = at; }
     L.ids[4] = ids_g; at += nfg[1]; L.end[4] = at;
-    L.ids[5] = q_ids; at += n_q; L.end[5] = at;
     hipLaunchKernelGGL(k_conn_bits, dim3(at), dim3(64), 0, c->stream, c->lc_pending.p, U, c->adj_cnt.p, c->adj_stride, c->conn.p, c->adj_off.p,
                        c->cb_R, c->cb_words, c->conn_bits.p, L, 1);
     VGS_HIP_TRY(c, hipGetLastError());
   }
   c->counts[VGS_N_REATTACHED + 2] = nf;  // diagnostics: voxels handed over by the wave kernels
-  c->lc_diag[0] = (int64_t)lc_why[0] + (int64_t)n_q;   // (the queued ones carry no mark for k_ho_lists to count)
-  c->lc_diag[14] = (int64_t)n_q; c->lc_diag[1] = (int64_t)(lc_why[1] + lc_why[2] + lc_why[3]); c->lc_diag[2] = (int64_t)nfg[0] + (int64_t)n_q; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
+  c->lc_diag[0] = (int64_t)lc_why[0]; c->lc_diag[1] = (int64_t)(lc_why[1] + lc_why[2] + lc_why[3]); c->lc_diag[2] = (int64_t)nfg[0]; c->lc_diag[3] = (int64_t)nf2 + (int64_t)ng2;
   c->lc_diag[4] = (int64_t)nfg[1]; c->lc_diag[5] = (int64_t)h[1]; c->lc_diag[6] = (int64_t)(hc[13] & 0xffffffffull); c->lc_diag[7] = (int64_t)h[0];
   VGS_HIP_TRY(c, hipGetLastError());
   float kms = 0.f;

@@ -34,9 +34,6 @@
 #define DN_NBIN 1024    // histogram bins of the banded phase B (they reuse the queue's bytes)
 #define DN_ABIN 256     // histogram bins of the banded phase A, over (thr0, 1]
 #define DN_NF 15        // words of a record kept in LDS: c[3], n[3], f[8], flags
-#define DN_QUEUE (-1)        // n_lists: the launch reads the early hand-over queue instead of lists
-#define DN_QUEUE_REST (-2)   // n_lists: ... finishes what the queue's readers left undone
-#define DN_QUEUE_PATIENCE 2000000ull   // 20 ms of the 100 MHz wall clock: a step is 6 ms
 
 #ifdef VGS_PROF
 __device__ unsigned long long g_dn_prof[16];
@@ -581,59 +578,6 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
 #endif
   };   // process
 
-  if (n_lists == DN_QUEUE) {
-    // ---- the early hand-over (round 6): this launch was dispatched BEFORE the bulk class of the one-wavefront kernels (a 30 KB workgroup
-    // starves once their 5 KB workgroups have filled every CU's LDS) and takes the voxels they give up from their queue while they run
-    // (LwParams::q_ctl; here: to_pg = the queue, n_to_pg = its control words, work_stride = its slots).  A workgroup leaves when the slot it
-    // has drawn is empty AND the producers are through (a word set by a launch behind them) -- or after DN_QUEUE_PATIENCE of waiting for
-    // either, whatever went wrong: the queue's entries are flagged when done, and what is not flagged is finished behind the stage
-    // (DN_QUEUE_REST), so a workgroup that leaves early costs time, never a voxel.  Everything that crosses workgroups here is an agent-scope
-    // atomic: the XCDs' L2s are not coherent with each other.
-    __shared__ unsigned int s_item;
-    unsigned int* const ctl = n_to_pg;
-    unsigned int my_slot = 0;
-    const unsigned long long t_begin = wall_clock64();   // 100 MHz
-    while (true) {
-      if (tid == 0) {
-        unsigned int item = 0u;
-        my_slot = atomicAdd(&ctl[0], 1u);
-        if (my_slot < (unsigned int)work_stride) {
-          while (true) {
-            item = __hip_atomic_load(&to_pg[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (item != 0u) break;
-            if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // no producer is left: the slot is final
-              item = __hip_atomic_load(&to_pg[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-            if (wall_clock64() - t_begin > DN_QUEUE_PATIENCE) break;
-            __builtin_amdgcn_s_sleep(64);
-          }
-        }
-        s_item = item;
-      }
-      __syncthreads();
-      const unsigned int item = s_item;
-      if (item == 0u) break;   // uniform
-      process((uint32_t)__builtin_amdgcn_readfirstlane((int)(item - 1u)));
-      __syncthreads();   // the row is written, the next voxel reuses every array
-      if (tid == 0) {
-        __hip_atomic_store(&to_pg[my_slot], item | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(&ctl[3], 1u);
-      }
-    }
-    return;
-  }
-  if (n_lists == DN_QUEUE_REST) {
-    // what the early hand-over left in the queue (nothing, unless its workgroups ran out of patience): n_work_dev[1] entries, done ones flagged
-    const unsigned int nq = n_work_dev[1] < (unsigned int)work_stride ? n_work_dev[1] : (unsigned int)work_stride;
-    for (unsigned int wi = blockIdx.x; wi < nq; wi += gridDim.x) {
-      const unsigned int item = work[wi];
-      if (item == 0u || (item & 0x80000000u) != 0u) continue;   // uniform
-      process((uint32_t)__builtin_amdgcn_readfirstlane((int)(item - 1u)));
-      __syncthreads();
-    }
-    return;
-  }
   for (unsigned int wi = blockIdx.x; ; wi += gridDim.x) {
     unsigned int wpos = wi;
     int wbin = 0;

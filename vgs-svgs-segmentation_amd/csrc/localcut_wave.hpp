@@ -124,18 +124,7 @@ struct LwParams {
   // bulk launch: lengths of the first and the main work list read on the device (the host launches with a grid for their sum); null: n_first / n_work
   const unsigned int* n_first_dev;
   const unsigned int* n_main_dev;
-  // Early hand-over (round 6; null: off).  A voxel the lazy schedule gives up is appended to a device-side queue that a few persistent workgroups
-  // of the dense hand-over kernel -- dispatched BEFORE this launch, so that their LDS is theirs -- drain while this launch is still running
-  // (localcut_dense.hpp, queue mode).  Control words: {next to take, next free slot, "the producers are through", taken and done}; queue[slot] =
-  // voxel + 1, written once, 0 until then; beyond its slots (a noisy scene: every voxel is given up) the voxel is only marked, as without.
-  // No parameter of its own (the kernel has no scalar register to spare: three more cost the bulk class six spilled vector registers): bit
-  // LW_HO_QUEUE of ho_bins switches it on, the control words are counter words LW_Q_WORD.., the queue sits LW_Q_LIST lists behind the hand-over
-  // lists and holds min(LW_Q_CAP, ho_stride) slots.
 };
-#define LW_HO_QUEUE 0x200
-#define LW_Q_WORD 38      // counter words 38-39: four 32-bit control words
-#define LW_Q_LIST 7       // `fallback` + LW_Q_LIST * ho_stride
-#define LW_Q_CAP 8192u
 
 // The hand-over kernel's cost grows with the square of the neighbourhood size and its launch ends with the slowest voxel:
 // the one-wavefront classes sort their hand-overs into lists by size, and the launch takes the list of the largest first.
@@ -1194,19 +1183,7 @@ __global__ __launch_bounds__(64 * NW, MAXM <= 255 ? LW_WAVES : (NW > 1 ? (MAXM =
       // One-wavefront classes: only the mark; k_ho_lists builds the hand-over lists from the marks afterwards.  (Appending here is one
       // RETURNING atomic on one of four addresses per handed-over voxel: on a noisy scene 130 k of them serialise at ~30 ns each and
       // the launch cannot end before they have -- 4 ms, whatever the wavefronts do.)
-      if (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) {
-        bool queued = false;
-        if ((P.ho_bins & LW_HO_QUEUE) != 0) {
-          unsigned int* const q_ctl = (unsigned int*)(counters + LW_Q_WORD);
-          const unsigned int q_cap = (unsigned int)P.ho_stride < LW_Q_CAP ? (unsigned int)P.ho_stride : LW_Q_CAP;
-          if (__hip_atomic_load(&q_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q_cap) {
-            // (one returning atomic per queued voxel, at most q_cap of them per run: a scene that gives up more than that stops at the load)
-            const unsigned int slot = atomicAdd(&q_ctl[1], 1u);
-            if (slot < q_cap) { __hip_atomic_store(&fallback[(size_t)LW_Q_LIST * P.ho_stride + slot], u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); queued = true; }
-          }
-        }
-        P.pending[u] = queued ? (uint8_t)LW_PENDING_LISTED : (uint8_t)(1 + bin);   // (listed: k_ho_lists leaves it to the queue's readers)
-      }
+      if (SMALL && NW == 1 && (P.ho_bins & 0xff) > 1) P.pending[u] = (uint8_t)(1 + bin);
       else { fallback[(size_t)bin * P.ho_stride + atomicAdd(n_fallback + bin, 1u)] = u; P.pending[u] = LW_PENDING_LISTED; }
       if constexpr (SAMPLED) atomicAdd(&counters[LW_VOTE_BASE + (blockIdx.x & (LW_VOTE_WORDS - 1u))], 1ull << 32);   // a sample that gave up
     }

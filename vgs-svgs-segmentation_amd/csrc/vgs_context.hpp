@@ -99,8 +99,6 @@ struct VgsKnobs {
                                  // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
-  int early_ho = 0;              // VGS_EARLY_HO=N: N persistent workgroups of the dense hand-over kernel are dispatched BEFORE the bulk class and take the voxels it
-                                 // gives up from a device-side queue while it runs (0: off -- the hand-overs wait for the bulk class to end)
   bool no_adj_wide = false;      // VGS_NO_ADJ_WIDE: rows above 2048 used neighbours keep the one-wavefront general kernel (A/B twin of round 6's workgroup per row)
   bool no_grow_prefix = false;   // VGS_NO_GROW_PREFIX: the octree box grows by one scan launch and one adopt launch per step from the first point on
   bool no_sort32 = false;        // VGS_NO_SORT32: the one-wavefront classes of the local cut keep the 64-bit sort network (A/B twin of round 6's one-word keys)
@@ -123,7 +121,6 @@ struct vgs_ctx {
   hipStream_t stream2 = nullptr;  // side streams: the heavy local-cut classes overlap the light one
   hipStream_t stream3 = nullptr;
   hipStream_t stream4 = nullptr;
-  hipStream_t stream5 = nullptr;   // the early hand-over kernel of the local cut (round 6): dispatched before the bulk class, ends after it
   std::string err;
   int stage = ST_NONE;
   void* pin = nullptr;   // 4 KB of pinned host memory: small read-backs land here (a pageable destination makes the copy blocking and slower)
@@ -221,7 +218,6 @@ struct vgs_ctx {
   bool pl_enabled = false;
   bool pl_enabled_at_launch = false;   // this run queued the pair-list chain for its hand-overs (stream4 joins stream3 before the stage's last event)
   hipEvent_t ev_ho = nullptr, ev_ho2 = nullptr;   // hand-over lists built / pair-list chain done
-  hipEvent_t ev_q = nullptr;      // the early hand-over kernel is through
   float pl_w_ring = 0.0f;      // PairLists::w_ring of this run
 
   // local cut / merge
@@ -232,7 +228,7 @@ struct vgs_ctx {
   DevBuf<uint8_t> lc_pending;
   DevBuf<uint8_t> lc_defer_flag;   // per row: the first pass of crossValidation put it off (written by every row of that pass)
   DevBuf<uint32_t> lc_defer;
-  struct { bool open = false; bool dense = true; bool gated = false; /* merge's first pass looks at LcGate's word */ bool many = false; /* ... and found LC_MANY */ unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; bool early = false; /* the early hand-over kernel was launched */ bool pg_xl_queued = false; /* class D's pair-list kernel queued for the extra-large one, which was launched */ } lc_tail;
+  struct { bool open = false; bool dense = true; bool gated = false; /* merge's first pass looks at LcGate's word */ bool many = false; /* ... and found LC_MANY */ unsigned int grid_f = 0, grid_g = 0, nabc[5] = {0, 0, 0, 0, 0}; float tail_ms = 0.f; bool pg_xl_queued = false; /* class D's pair-list kernel queued for the extra-large one, which was launched */ } lc_tail;
   int64_t lc_diag[16] = {0};   // vgs_get_schedule_counters[_ex]
   DevBuf<float> lc_ctab;      // screening table of the dense hand-over kernels (localcut.hip: lc_screen_table)
   float lc_ctab_key[8] = {0}, lc_ctab_scale = 0.0f;
