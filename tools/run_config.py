@@ -12,7 +12,7 @@ if cfg == "c2":
     xyz, p, name = v.scenes.pc_scene(n or 1_000_000), v.default_params(2, voxel_size=0.05), "PC1M: planar+cylinder scene, VGS, voxel 0.05 m, graph 0.5 m"
 elif cfg == "c3":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(2, voxel_size=0.1), "URB10M: urban scene, VGS, voxel 0.1 m, graph 0.5 m"
-elif cfg in ("c4", "c4p", "c4s"):   # BASELINE config 4; supervoxels in PCL's own order are the default since round 6 (c4p: the name rounds 3-5 used for it)
+elif cfg in ("c4", "c4p"):   # BASELINE config 4; supervoxels in PCL's own order are the default since round 6 (c4p: the name rounds 3-5 used for it)
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3), "URB10M: urban scene, SVGS (Task_File_SVGS.txt: voxel 0.05 m, seed 0.25 m, graph 0.5 m), supervoxels in PCL's own order (vccs_mode 1, the default)"
 elif cfg == "c4s":
     xyz, p, name = v.scenes.urban_scene(n or 10_000_000), v.default_params(3, vccs_mode=0), "URB10M: urban scene, SVGS with the synchronous supervoxel variant (vccs_mode 0: an approximation, not within P2 of the default)"
