@@ -517,7 +517,10 @@ __global__ __launch_bounds__(LC_TB) void k_localcut(const uint32_t* __restrict__
 #define PG_C0 320, 2048, 4, 5, false            // ... for neighbourhoods of 129-320 voxels (29 KB of LDS: five workgroups per CU)
 #define PG_C 512, 2048, 4, 4, false             // ... of up to 512 (34 KB: four)
 #define PG_D 1024, 4096, 8, 4, false            // ... of up to 1024 (68 KB: two workgroups of eight wavefronts)
-#define PG_XL 4224, 2048, 4, 1, false, 21        // ... of whole balls of up to ten voxels (4189 offsets; 154 KB: one workgroup per CU)
+#ifndef PG_XL_NW
+#define PG_XL_NW 16   // (round 6: 4 -> 16 wavefronts: the block scene 49.5 -> 36.8 ms, config 2 4.94 -> 4.89)
+#endif
+#define PG_XL 4224, 2048, PG_XL_NW, 1, false, 21        // ... of whole balls of up to ten voxels (4189 offsets; 154 KB: one workgroup of sixteen wavefronts per CU)
 
 // Connect bits of the voxels the hand-over kernels cut (k_localcut_dense, k_localcut: they write the connect row only): one wavefront
 // per pending voxel turns its row into the bit-per-ball-offset form the wave kernels write themselves (localcut_wave.hpp, result).
@@ -983,7 +986,7 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                          c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
                          c->cb_words, LcGate{nullptr, 0u}, pg_xl ? ids_xl_pg : (uint32_t*)nullptr, pg_xl ? d_nxl : (unsigned int*)nullptr);
     if (nabc[3] > 0 && pg_xl)   // what was too big for it: whole balls of up to ten voxels (the length of the list is on the device)
-      hipLaunchKernelGGL((k_localcut_pg<PG_XL>), dim3(256), dim3(256), 0, c->stream2, ids_xl_pg, 0, 1, d_nxl, 0u, 0, c->adj_key.p,
+      hipLaunchKernelGGL((k_localcut_pg<PG_XL>), dim3(256), dim3(64 * PG_XL_NW), 0, c->stream2, ids_xl_pg, 0, 1, d_nxl, 0u, 0, c->adj_key.p,
                          c->adj_cnt.p, c->adj_stride, c->adj_off.p, c->node.p, LP, PLw, G, c->conn.p, cnt, ids_g, d_ng, c->evals.p, c->lc_pending.p, wbits, c->cb_R,
                          c->cb_words, LcGate{nullptr, 0u}, (uint32_t*)nullptr, (unsigned int*)nullptr);
     if (nabc[2] > 0)
