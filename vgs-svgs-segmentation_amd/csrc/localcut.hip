@@ -655,19 +655,21 @@ __global__ __launch_bounds__(1024) void k_classify(const uint32_t* __restrict__ 
 // Class sizes alone (A and A1 together): what the host needs to size the launches does not depend on the near-pair lists, so it is
 // counted BEFORE they are built and fetched while they are (vgs_stage_localcut).
 __global__ __launch_bounds__(1024) void k_count_classes(const uint32_t* __restrict__ adj_cnt, int64_t U, int max_a, int max_b, int max_c, int max_c0,
-                                                        unsigned int* __restrict__ n_cls /* 6: A + A1, B, C, D, C0, S */, int sample) {
-  __shared__ unsigned int s_cnt[6];
-  if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0u;
+                                                        unsigned int* __restrict__ n_cls /* 7: A + A1, B, C, D, C0, S, of D those above max_d */, int sample,
+                                                        int max_d) {
+  __shared__ unsigned int s_cnt[7];
+  if (threadIdx.x < 7) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int cls = -1;
-  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); if (sample && cls <= 1 && (u & (int64_t)(sample - 1)) == 0) cls = 5; }
-  for (int k = 0; k < 6; ++k) {
-    const unsigned long long mk = __ballot(cls == k);
+  bool xl = false;
+  if (u < U) { const int m = (int)adj_cnt[u]; cls = m <= max_a ? 0 : (m <= max_b ? 1 : (m <= max_c0 ? 4 : (m <= max_c ? 2 : 3))); xl = m > max_d; if (sample && cls <= 1 && (u & (int64_t)(sample - 1)) == 0) cls = 5; }
+  for (int k = 0; k < 7; ++k) {
+    const unsigned long long mk = __ballot(k < 6 ? cls == k : xl);
     if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_cnt[k], (unsigned int)__popcll(mk));
   }
   __syncthreads();
-  if (threadIdx.x < 6 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x < 7 && s_cnt[threadIdx.x]) atomicAdd(&n_cls[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // Smallest squared distance (to the bisection's resolution) whose weight bound is at or below a singleton's threshold:
@@ -821,8 +823,8 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   const bool dense_ = !c->K.no_dense;
   const int sample = (c->pl_enabled && dense_ && !c->K.no_vote) ? c->K.vote_period : 0;   // a power of two: one voxel in so many is a sample
   if (early_sizes) {
-    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls, sample);
-    vgs_status sb = vgs_readback_begin(c, d_ncls, 24);
+    hipLaunchKernelGGL(k_count_classes, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, c->stream, c->adj_cnt.p, U, WAVE_A, WAVE_B, WAVE_C, max_c0, d_ncls, sample, 1024);
+    vgs_status sb = vgs_readback_begin(c, d_ncls, 28);
     if (sb != VGS_OK) return sb;
   }
   {
@@ -837,12 +839,14 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
                      ids_d, ids_a1, d_nabc, max_c0, ids_c0, sample, ids_s);
   unsigned int nabc[LC_NCLASS] = {0, 0, 0, 0, 0, 0, 0};
   unsigned int n_bulk = 0;   // A + A1
+  unsigned int n_above_d = ~0u;   // neighbourhoods above 1024 voxels (~0: not counted -- the diagnostics path without the early counts)
   if (early_sizes) {
-    unsigned int ncls[6] = {0, 0, 0, 0, 0, 0};
-    vgs_status se = vgs_readback_end(c, ncls, 24);
+    unsigned int ncls[7] = {0, 0, 0, 0, 0, 0, 0};
+    vgs_status se = vgs_readback_end(c, ncls, 28);
     if (se != VGS_OK) return se;
     n_bulk = ncls[0]; nabc[1] = ncls[1]; nabc[2] = ncls[2]; nabc[3] = ncls[3]; nabc[5] = ncls[4]; nabc[6] = ncls[5];
     nabc[0] = n_bulk; nabc[4] = 0;   // (host-side bookkeeping only: the kernel reads the split from d_nabc)
+    n_above_d = ncls[6];
   } else {
     VGS_READBACK(c, nabc, d_nabc, sizeof(nabc));
     n_bulk = nabc[0] + nabc[4];
@@ -976,7 +980,10 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
     // ten voxels per axis.  cb_R is the ball's largest |offset| per axis (adj_R is the bound of the loop that enumerates the ball, one or
     // two more: at graph 0.5 / voxel 0.05 it is 11 and the ball's reach is 10).  A wider ball: nobody is queued for it -- what class D's
     // instantiation cannot hold goes to the hand-over list, the dense kernel and the general kernels behind it, as before round 5.
-    const bool pg_xl = c->cb_R <= 10 && !c->K.no_pg_xl;
+    // ... and it is launched only when a neighbourhood above class D's 1024 voxels exists (counted with the classes; round 6): its 154 KB
+    // workgroups need a CU's whole LDS, so an EMPTY launch of it waits for class C0's workgroups beside it to drain -- 2.0 ms on config 2,
+    // where nobody is that large -- and holds back what is queued behind it on the builder's stream
+    const bool pg_xl = c->cb_R <= 10 && !c->K.no_pg_xl && n_above_d != 0u;
     c->lc_tail.pg_xl_queued = pg_xl && nabc[3] > 0;
     VGS_HIP_TRY(c, hipEventRecord(c->ev_ho2, c->stream2));   // the rows are built
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream4, c->ev_ho2, 0));
