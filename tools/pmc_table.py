@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-DOMINANT = "void k_localcut_wave<96, 448, 1, false>"   # (the SAMPLED instantiation <.., true> runs one voxel in sixteen)
+DOMINANT = "void k_localcut_wave<96, 448, 1, false"   # (the SAMPLED instantiation <.., true> runs one voxel in sixteen)
 
 
 def main():
