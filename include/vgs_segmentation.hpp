@@ -118,14 +118,13 @@ class VoxelBasedSegmentation {
     adj_off_.clear(); adj_idx_.clear();
   }
   void getBoundingBox(double& min_x, double& min_y, double& min_z, double& max_x, double& max_y, double& max_z) {
-    ensure_voxels();   // (test:56 calls this right behind setVoxelSize)
     double b[6];
     chk(vgs_get_bbox(ctx(), b), "vgs_get_bbox");
     min_x = b[0]; min_y = b[1]; min_z = b[2]; max_x = b[3]; max_y = b[4]; max_z = b[5];
   }
 
   int getCloudPointNum(const PCXYZPtr& input_data) { cloud_ = input_data; return (int)input_data->points.size(); }  // VS:94
-  int getVoxelNum() { ensure_voxels(); return (int)count(VGS_N_VOXELS); }                 // VS:104
+  int getVoxelNum() { return (int)count(VGS_N_VOXELS); }                 // VS:104
   int getClusterNum() { return (int)count(VGS_N_CLUSTERS); }                              // VS:111
   std::vector<std::vector<int>> getClusterIdx() {                                        // VS:117
     std::vector<std::vector<int>> out;
@@ -154,9 +153,8 @@ class VoxelBasedSegmentation {
   float getVoxelResolution() const { return voxel_resolution_ > 0.0f ? voxel_resolution_ : p_.voxel_size; }   // (debug meshes)
   void setBoundingBox(double, double, double, double, double, double) {}                 // VS:133 (the engine keeps the octree's box)
   // VS:146.  The voxel table is built by addPointsFromInputCloud with the constructor's resolution and stays as it is.
-  void setVoxelCenters() { ensure_voxels(); }
+  void setVoxelCenters() {}   // (the table is built by addPointsFromInputCloud)
   std::vector<PointXYZ> getVoxelCenters() {                                              // VS:191
-    ensure_voxels();
     const int64_t v = count(VGS_N_VOXELS);
     std::vector<float> c((size_t)v * 3 + 1);
     chk(vgs_get_voxel_centers(ctx(), c.data()), "vgs_get_voxel_centers");
@@ -164,9 +162,8 @@ class VoxelBasedSegmentation {
     for (int64_t i = 0; i < v; ++i) out[(size_t)i] = PointXYZ(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
     return out;
   }
-  void calcualteVoxelCloudAttributes(const PCXYZPtr&) { ensure_voxels(); chk(vgs_features(ctx()), "vgs_features"); }  // VS:290 (sic)
+  void calcualteVoxelCloudAttributes(const PCXYZPtr&) { chk(vgs_features(ctx()), "vgs_features"); }  // VS:290 (sic)
   void findAllVoxelAdjacency(float graph_size) {                                         // VS:223
-    ensure_voxels();
     p_.graph_size = graph_size;
     chk(vgs_set_params(ctx(), &p_), "vgs_set_params");
     chk(vgs_adjacency(ctx()), "vgs_adjacency");
@@ -220,7 +217,6 @@ class VoxelBasedSegmentation {
   PCXYZPtr cloud_;
   bool drawn_ = false;
   float voxel_resolution_ = 0.0f;  // setVoxelSize's value (VS:127): stored, never binned with
-  void ensure_voxels() {}          // (the table is built by addPointsFromInputCloud; kept as the one place a lazy rebuild would go)
   std::vector<int64_t> adj_off_;   // getOneVoxelAdjacency's copy of the lists
   std::vector<int32_t> adj_idx_;
 };
