@@ -884,9 +884,9 @@ __global__ void k_pclt_init(int64_t V, const int32_t* __restrict__ owner, int32_
 }
 template <bool CLAIM>
 __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta, const uint2* __restrict__ halo,
-                                                   const uint16_t* __restrict__ cell, const int32_t* __restrict__ P_in, const float* __restrict__ dist0,
+                                                   const uint16_t* __restrict__ cell, const int32_t* P_in /* may be P_out: in-place sweeps */, const float* __restrict__ dist0,
                                                    const float* __restrict__ cen, const float* __restrict__ nrm, const VccsState* __restrict__ st,
-                                                   float w_s_over_seed, float w_n, int32_t* __restrict__ P_out, unsigned int* __restrict__ changed,
+                                                   float w_s_over_seed, float w_n, int32_t* P_out, unsigned int* __restrict__ changed,
                                                    int32_t* __restrict__ owner1, float* __restrict__ dist1, long long* __restrict__ sums,
                                                    unsigned int* __restrict__ count, const int32_t* __restrict__ nbr_tiles,
                                                    const uint32_t* __restrict__ tchg_in, uint32_t* __restrict__ tchg_out,
@@ -899,8 +899,10 @@ __global__ __launch_bounds__(64) void k_pclt_sweep(const uint32_t* __restrict__ 
     uint32_t f = 0u;
     if (lane < 27) { const int nt = lane == 13 ? t : nbr_tiles[(int64_t)t * 27 + lane]; if (nt >= 0) f = tchg_in[nt]; }
     if (__ballot(f != 0u) == 0ull) {
-      const uint32_t ts = tile_start[t], te = tile_start[t + 1];
-      for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) P_out[v] = P_in[v];
+      if (P_out != P_in) {   // (in place -- round 6 -- a quiet tile has nothing to copy)
+        const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+        for (uint32_t v = ts + (uint32_t)lane; v < te; v += 64u) P_out[v] = P_in[v];
+      }
       if (lane == 0) tchg_out[t] = 0u;
       return;
     }
@@ -1165,6 +1167,8 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   hipLaunchKernelGGL(k_pcl_plant_first, dim3(nbK), dim3(TB), 0, c->stream, seeds, K, cen.p, nrm.p, own[cur], state, c->vc_alive.p);
   if (tiles) hipLaunchKernelGGL(k_pclt_seed_sums, dim3(nbK), dim3(TB), 0, c->stream, K, (const int32_t*)seeds, (const unsigned long long*)nullptr, (const uint8_t*)nullptr,
                                 cen.p, nrm.p, c->vc_sums.p, c->vc_count.p, (const int32_t*)nullptr);
+  int dbg_settled[16] = {0};   // VGS_DEBUG: rounds by the index of their first sweep that changed nothing
+  const bool inplace = tiles && !c->K.vccs_pingpong;   // (VGS_VCCS_PINGPONG: the sweeps alternate between two flag arrays, as until round 5)
   for (int pass = 0; pass < 6; ++pass) {
     if (pass > 0) {
       // refineSupervoxels: refineNormals of every supervoxel (from its own leaves), reseedSupervoxels (nearest of all voxels), expansion
@@ -1195,8 +1199,13 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
         ring_at += nb;
         for (int k = 0; k < nb; ++k) {
           if (tiles)
+            // In place (round 6): a tile reads its window from the one flag array and writes its own voxels back into it.  Another tile may
+            // read them before or after -- an asynchronous iteration, and the fixed point of the live flags is unique (the recursion is on
+            // smaller labels), so it is reached whatever the order; the proof of arrival is unchanged (a sweep in which nobody wrote read only
+            // final values), and so is the quiet-tile test (a tile whose window tiles wrote nothing in the last sweep read what is there now).
+            // Quiet tiles then copy nothing, and news travels within a sweep.  The per-tile change flags still alternate.
             hipLaunchKernelGGL(k_pclt_sweep<false>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
-                               (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[lc ^ 1],
+                               (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[inplace ? 0 : lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, plive[inplace ? 0 : (lc ^ 1)],
                                d_chg + k, (int32_t*)nullptr, (float*)nullptr, (long long*)nullptr, (unsigned int*)nullptr,
                                (const int32_t*)c->vc_nbr_tiles.p, (const uint32_t*)tchg[lc], tchg[lc ^ 1]);
           else
@@ -1205,12 +1214,12 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
           lc ^= 1;
         }
         VGS_READBACK(c, ch, d_chg, 4 * (size_t)nb);
-        for (int k = 0; k < nb; ++k) settled = settled || !ch[k];   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
+        for (int k = 0; k < nb; ++k) { if (!settled && !ch[k] && c->K.debug) ++dbg_settled[std::min(sweep + k, 15)]; settled = settled || !ch[k]; }   // (after an unchanged sweep the two flag arrays are equal: either is the fixed point)
       }
       if (!settled) { c->err = "svgs_supervoxels (vccs_mode 1): the live flags did not reach their fixed point in 4096 sweeps"; return VGS_E_STATE; }
       if (tiles)
         hipLaunchKernelGGL(k_pclt_sweep<true>, dim3((unsigned)NT), dim3(64), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p,
-                           (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
+                           (const uint2*)c->vc_halo.p, c->vc_cell.p, plive[inplace ? 0 : lc], dst[cur], cen.p, nrm.p, state, w_s_over_seed, w_n, (int32_t*)nullptr,
                            (unsigned int*)nullptr, own[cur ^ 1], dst[cur ^ 1], c->vc_sums.p, c->vc_count.p, (const int32_t*)nullptr,
                            (const uint32_t*)nullptr, (uint32_t*)nullptr, dbg_moved ? dbg_moved + pass * 16 + it : (unsigned int*)nullptr);
       else
@@ -1231,6 +1240,11 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   unsigned int mx = 0;
   VGS_READBACK(c, &mx, d_changed, 4);
   VGS_HIP_TRY(c, hipGetLastError());
+  if (c->K.debug) {
+    fprintf(stderr, "[vgs] vccs_mode 1: rounds by the index of their first unchanged sweep:");
+    for (int k = 0; k < 16; ++k) if (dbg_settled[k]) fprintf(stderr, " %d:%d", k, dbg_settled[k]);
+    fprintf(stderr, "\n");
+  }
   if (dbg_moved) {
     unsigned int h[128];
     VGS_HIP_TRY(c, hipMemcpy(h, dbg_moved, sizeof(h), hipMemcpyDeviceToHost));

@@ -99,6 +99,7 @@ struct VgsKnobs {
                                  // of them a CU holds beside the hand-over kernel's workgroups, which need four wave slots at once
   bool no_vccs_tiles = false;    // VGS_NO_VCCS_TILES: the supervoxel expansion rounds gather their 26 labels through the neighbour table
   bool no_c0 = false;            // VGS_NO_C0: no separate class for neighbourhoods of 129..320 voxels
+  bool vccs_pingpong = false;    // VGS_VCCS_PINGPONG: (vccs_mode 1) the live-flag sweeps alternate between two arrays (A/B twin of round 6's in-place sweeps)
   bool no_adj_wide = false;      // VGS_NO_ADJ_WIDE: rows above 2048 used neighbours keep the one-wavefront general kernel (A/B twin of round 6's workgroup per row)
   bool no_grow_prefix = false;   // VGS_NO_GROW_PREFIX: the octree box grows by one scan launch and one adopt launch per step from the first point on
   bool no_sort32 = false;        // VGS_NO_SORT32: the one-wavefront classes of the local cut keep the 64-bit sort network (A/B twin of round 6's one-word keys)
