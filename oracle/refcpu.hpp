@@ -134,6 +134,8 @@ void vccs_supervoxels(const float* xyz, int64_t n, int stride_floats, const Para
 void vccs_supervoxels_refmath(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
 // vccs_mode 1: pcl::SupervoxelClustering's steps in PCL's order (sequential owners, 2-ring normals, seed rejection); unpinned
 void vccs_pcl_supervoxels(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
+// ... and its independent arithmetic leg (double, libm, own eigen-solver: refcpu_vccs_ref.cpp)
+void vccs_pcl_supervoxels_refmath(const float* xyz, int64_t n, int stride_floats, const Params& P, std::vector<int>& label, int& max_label);
 
 }  // namespace refcpu
 #endif

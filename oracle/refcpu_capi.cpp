@@ -91,6 +91,13 @@ int ref_vccs_pcl(const float* xyz, int64_t n, int stride_floats, const RefParams
   std::memcpy(labels, lab.data(), lab.size() * sizeof(int));
   return max_label;
 }
+int ref_vccs_pcl_refmath(const float* xyz, int64_t n, int stride_floats, const RefParamsC* p, int* labels) {
+  std::vector<int> lab;
+  int max_label = 0;
+  vccs_pcl_supervoxels_refmath(xyz, n, stride_floats, to_params(p), lab, max_label);
+  std::memcpy(labels, lab.data(), lab.size() * sizeof(int));
+  return max_label;
+}
 void ref_free(void* hv) { delete (RefHandle*)hv; }
 
 // out[0]=nodes V, [1]=sum adjacency, [2]=clusters_num, [3]=kept clusters, [4]=pair_evals, [5]=octree depth,

@@ -70,6 +70,8 @@ def lib():
         L.ref_vccs_refmath.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_vccs_pcl.restype = C.c_int
         L.ref_vccs_pcl.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
+        L.ref_vccs_pcl_refmath.restype = C.c_int
+        L.ref_vccs_pcl_refmath.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(RefParams), C.c_void_p]
         L.ref_free.argtypes = [C.c_void_p]
         L.ref_counts.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_vgs_bbox.argtypes = [C.c_void_p, C.c_void_p]
@@ -204,6 +206,15 @@ def vccs_pcl(xyz, params):
     xyz = _xyz(xyz)
     lab = np.zeros(xyz.shape[0], dtype=np.int32)
     mx = lib().ref_vccs_pcl(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
+    return lab, int(mx)
+
+
+def vccs_pcl_refmath(xyz, params):
+    """The PCL-order steps once more in double precision with libm and an eigen-solver of their own (refcpu_vccs_ref.cpp): the independent
+    leg of the engine's default supervoxel stage."""
+    xyz = _xyz(xyz)
+    lab = np.zeros(xyz.shape[0], dtype=np.int32)
+    mx = lib().ref_vccs_pcl_refmath(_p(xyz), xyz.shape[0], xyz.shape[1], C.byref(params), _p(lab))
     return lab, int(mx)
 
 

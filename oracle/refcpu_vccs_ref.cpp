@@ -193,4 +193,199 @@ void vccs_supervoxels_refmath(const float* xyz, int64_t n, int stride, const Par
   max_label = K;
 }
 
+
+// ==================================================================================================================
+// The independent leg of the PCL-ORDER stage (vccs_mode 1, the engine's default since round 6): the steps of
+// refcpu_vccs.cpp::vccs_pcl_supervoxels -- pcl::SupervoxelClustering 1.8.1 as recalled there (reference supervoxel_segmentation.h:265-284:
+// extract + refineSupervoxels(5)) -- written again in double precision with libm, the Jacobi solver above, two-pass covariances, plain
+// floating-point means, std::map lookups and a brute-force nearest-voxel search; no vccs_common.h, no vgs_math.h.  Shared with the other
+// leg: only the voxel table on the adjacency octree's own lattice (build_voxel_table_bbox, integer binning) and the parameters.  The
+// number of expansion rounds is the float expression of the product, (int)(1.8f * seed / res): parameter arithmetic, not data arithmetic.
+void vccs_pcl_supervoxels_refmath(const float* xyz, int64_t n, int stride, const Params& P, std::vector<int>& label, int& max_label) {
+  VoxelTable T;
+  build_voxel_table_bbox(xyz, n, stride, P.voxel_size, T);
+  const int V = T.V();
+  label.assign((size_t)n, 0);
+  max_label = 0;
+  if (V == 0) return;
+  std::vector<double> cen((size_t)V * 3), nrm((size_t)V * 3, 0.0);
+  for (int v = 0; v < V; ++v) {
+    double s[3] = {0, 0, 0};
+    for (int k = T.start[v]; k < T.start[v + 1]; ++k) {
+      const float* p = xyz + (int64_t)T.point_idx[k] * stride;
+      for (int a = 0; a < 3; ++a) s[a] += (double)p[a];
+    }
+    const double cnt = (double)(T.start[v + 1] - T.start[v]);
+    for (int a = 0; a < 3; ++a) cen[3 * (size_t)v + a] = s[a] / cnt;
+  }
+  std::map<std::tuple<uint32_t, uint32_t, uint32_t>, int> at;
+  for (int v = 0; v < V; ++v) at[std::make_tuple(T.key[3 * v], T.key[3 * v + 1], T.key[3 * v + 2])] = v;
+  auto find = [&](long long x, long long y, long long z) -> int {
+    if (x < 0 || y < 0 || z < 0) return -1;
+    auto it = at.find(std::make_tuple((uint32_t)x, (uint32_t)y, (uint32_t)z));
+    return it == at.end() ? -1 : it->second;
+  };
+  // the 27 cells around a leaf, the leaf itself included (computeNeighbors); their order does not matter here: sums and minima only
+  std::vector<std::vector<int>> n27((size_t)V);
+  for (int v = 0; v < V; ++v)
+    for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+      const int u = find((long long)T.key[3 * v] + dx, (long long)T.key[3 * v + 1] + dy, (long long)T.key[3 * v + 2] + dz);
+      if (u >= 0) n27[(size_t)v].push_back(u);
+    }
+  // normal of leaf v from the multiset  [v] + for every t of its 27 cells (owned by `want` when want >= 0): [t] + the cells u of t (likewise)
+  std::vector<int> owner((size_t)V, -1);
+  auto leaf_normal = [&](int v, int want, double* out) {
+    std::vector<int> idx;
+    if (want < 0) idx.push_back(v);
+    for (int t : n27[(size_t)v]) {
+      if (want >= 0 && owner[(size_t)t] != want) continue;
+      idx.push_back(t);
+      for (int u : n27[(size_t)t]) if (want < 0 || owner[(size_t)u] == want) idx.push_back(u);
+    }
+    out[0] = out[1] = out[2] = 0.0;
+    if (idx.size() < 3) return;
+    double m[3] = {0, 0, 0};
+    for (int u : idx) for (int a = 0; a < 3; ++a) m[a] += cen[3 * (size_t)u + a];
+    for (int a = 0; a < 3; ++a) m[a] /= (double)idx.size();
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int u : idx) {
+      const double d[3] = {cen[3 * (size_t)u] - m[0], cen[3 * (size_t)u + 1] - m[1], cen[3 * (size_t)u + 2] - m[2]};
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] += d[a] * d[b];
+    }
+    double e[3];
+    smallest_eigenvector(C, e);
+    const double* p0 = &cen[3 * (size_t)v];
+    if (e[0] * (0.0 - p0[0]) + e[1] * (0.0 - p0[1]) + e[2] * (0.0 - p0[2]) < 0.0) { e[0] = -e[0]; e[1] = -e[1]; e[2] = -e[2]; }
+    const double len = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (len > 0.0) for (int a = 0; a < 3; ++a) out[a] = e[a] / len;
+  };
+  for (int v = 0; v < V; ++v) leaf_normal(v, -1, &nrm[3 * (size_t)v]);
+  // seeds: the voxel nearest to the centre of every occupied seed cell (cells anchored at the lattice's corner), cells in ascending
+  // x-major Morton order of their indices; kept when more than 0.05 * (seed / 2)^2 * pi / res^2 voxels lie within seed / 2
+  const double seed = (double)P.seed_size, res = (double)P.voxel_size;
+  auto spread = [](uint64_t x) { uint64_t r = 0; for (int b = 0; b < 21; ++b) r |= ((x >> b) & 1ull) << (3 * b); return r; };
+  std::map<uint64_t, std::pair<double, int>> cells;   // Morton of the cell -> (squared distance to its centre, voxel)
+  for (int v = 0; v < V; ++v) {
+    long long ci[3];
+    double d2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      ci[a] = (long long)((cen[3 * (size_t)v + a] - (double)(float)T.min[a]) / seed);
+      if (ci[a] < 0) ci[a] = 0;
+      const double cc = (double)(float)T.min[a] + ((double)ci[a] + 0.5) * seed;
+      d2 += (cen[3 * (size_t)v + a] - cc) * (cen[3 * (size_t)v + a] - cc);
+    }
+    const uint64_t code = (spread((uint64_t)ci[0]) << 2) | (spread((uint64_t)ci[1]) << 1) | spread((uint64_t)ci[2]);
+    auto it = cells.find(code);
+    if (it == cells.end() || d2 < it->second.first) cells[code] = std::make_pair(d2, v);
+  }
+  const double rad = 0.5 * seed, min_points = 0.05 * rad * rad * 3.14159265358979323846 / (res * res);
+  const int R = (int)(rad / res) + 1;
+  std::vector<int> seeds;
+  for (const auto& kv : cells) {
+    const int s0 = kv.second.second;
+    int num = 0;
+    for (int dz = -R; dz <= R; ++dz) for (int dy = -R; dy <= R; ++dy) for (int dx = -R; dx <= R; ++dx) {
+      const int u = find((long long)T.key[3 * s0] + dx, (long long)T.key[3 * s0 + 1] + dy, (long long)T.key[3 * s0 + 2] + dz);
+      if (u < 0) continue;
+      double e2 = 0.0;
+      for (int a = 0; a < 3; ++a) e2 += (cen[3 * (size_t)u + a] - cen[3 * (size_t)s0 + a]) * (cen[3 * (size_t)u + a] - cen[3 * (size_t)s0 + a]);
+      if (e2 < rad * rad) ++num;
+    }
+    if ((double)num > min_points) seeds.push_back(s0);
+  }
+  const int K = (int)seeds.size();
+  if (K == 0) return;
+  const int depth = (int)(1.8f * P.seed_size / P.voxel_size);
+  const double w_s_over_seed = (double)P.spatial_impt / seed, w_n = (double)P.normal_impt;
+  std::vector<double> dist((size_t)V, 1.0e300), sc((size_t)K * 3), sn((size_t)K * 3);
+  std::vector<char> alive((size_t)K, 1);
+  auto distance = [&](int v, int k) {
+    double d2 = 0.0, dot = 0.0;
+    for (int a = 0; a < 3; ++a) { const double e = cen[3 * (size_t)v + a] - sc[3 * (size_t)k + a]; d2 += e * e; dot += nrm[3 * (size_t)v + a] * sn[3 * (size_t)k + a]; }
+    return std::sqrt(d2) * w_s_over_seed + w_n * (1.0 - std::fabs(dot));
+  };
+  auto update_centroids = [&]() {
+    std::vector<double> sum((size_t)K * 6, 0.0);
+    std::vector<int> cnt((size_t)K, 0);
+    for (int v = 0; v < V; ++v) {
+      const int l = owner[(size_t)v];
+      if (l < 0) continue;
+      for (int a = 0; a < 3; ++a) { sum[6 * (size_t)l + a] += cen[3 * (size_t)v + a]; sum[6 * (size_t)l + 3 + a] += nrm[3 * (size_t)v + a]; }
+      cnt[(size_t)l]++;
+    }
+    for (int k = 0; k < K; ++k) {
+      if (!alive[(size_t)k]) continue;
+      if (cnt[(size_t)k] == 0) { alive[(size_t)k] = 0; continue; }
+      double m[3];
+      for (int a = 0; a < 3; ++a) { sc[3 * (size_t)k + a] = sum[6 * (size_t)k + a] / cnt[(size_t)k]; m[a] = sum[6 * (size_t)k + 3 + a] / cnt[(size_t)k]; }
+      const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+      for (int a = 0; a < 3; ++a) sn[3 * (size_t)k + a] = len > 0.0 ? m[a] / len : 0.0;
+    }
+  };
+  auto expand_all = [&]() {
+    std::vector<std::vector<int>> leaves((size_t)K);
+    std::vector<char> taken((size_t)V);
+    for (int i = 1; i < depth; ++i) {
+      for (int k = 0; k < K; ++k) leaves[(size_t)k].clear();
+      for (int v = 0; v < V; ++v) if (owner[(size_t)v] >= 0) leaves[(size_t)owner[(size_t)v]].push_back(v);
+      std::fill(taken.begin(), taken.end(), 0);
+      for (int k = 0; k < K; ++k) {   // the supervoxels take their turns one after the other
+        if (!alive[(size_t)k]) continue;
+        for (int leaf : leaves[(size_t)k]) {
+          if (taken[(size_t)leaf]) continue;   // lost to an earlier supervoxel of this round
+          for (int nb : n27[(size_t)leaf]) {
+            if (owner[(size_t)nb] == k) continue;
+            const double d = distance(nb, k);
+            if (d < dist[(size_t)nb]) { dist[(size_t)nb] = d; owner[(size_t)nb] = k; taken[(size_t)nb] = 1; }
+          }
+        }
+      }
+      update_centroids();
+    }
+  };
+  for (int k = 0; k < K; ++k) {
+    owner[(size_t)seeds[(size_t)k]] = k;
+    for (int a = 0; a < 3; ++a) { sc[3 * (size_t)k + a] = cen[3 * (size_t)seeds[(size_t)k] + a]; sn[3 * (size_t)k + a] = nrm[3 * (size_t)seeds[(size_t)k] + a]; }
+  }
+  expand_all();
+  for (int pass = 0; pass < 5; ++pass) {
+    // refineNormals: every owned leaf's normal again, from the leaves of its own supervoxel in its two rings
+    {
+      std::vector<double> fresh(nrm);
+      for (int v = 0; v < V; ++v) if (owner[(size_t)v] >= 0) leaf_normal(v, owner[(size_t)v], &fresh[3 * (size_t)v]);
+      nrm.swap(fresh);
+    }
+    // reseedSupervoxels: the voxel nearest to the supervoxel's centroid among ALL voxels, ties to the smaller voxel id; a search over
+    // growing boxes of lattice cells around the centroid's cell until the best distance is inside the searched box
+    std::vector<int> reseed((size_t)K, -1);
+    for (int k = 0; k < K; ++k) {
+      if (!alive[(size_t)k]) continue;
+      long long c0[3];
+      for (int a = 0; a < 3; ++a) c0[a] = (long long)std::floor((sc[3 * (size_t)k + a] - T.min[a]) / T.resolution);
+      double best = 1.0e300;
+      int bv = -1;
+      for (int r = 1; r < 64; ++r) {
+        for (long long z = c0[2] - r; z <= c0[2] + r; ++z) for (long long y = c0[1] - r; y <= c0[1] + r; ++y) for (long long x = c0[0] - r; x <= c0[0] + r; ++x) {
+          const int v = find(x, y, z);
+          if (v < 0) continue;
+          double e2 = 0.0;
+          for (int a = 0; a < 3; ++a) e2 += (cen[3 * (size_t)v + a] - sc[3 * (size_t)k + a]) * (cen[3 * (size_t)v + a] - sc[3 * (size_t)k + a]);
+          if (e2 < best || (e2 == best && v < bv)) { best = e2; bv = v; }
+        }
+        if (bv >= 0 && std::sqrt(best) < (double)(r - 1) * res) break;   // nothing outside the box can be nearer
+      }
+      reseed[(size_t)k] = bv;
+    }
+    std::fill(owner.begin(), owner.end(), -1);
+    std::fill(dist.begin(), dist.end(), 1.0e300);
+    for (int k = 0; k < K; ++k) if (alive[(size_t)k] && reseed[(size_t)k] >= 0) owner[(size_t)reseed[(size_t)k]] = k;   // a contested voxel goes to the later one
+    expand_all();
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const int v = T.point_voxel[(size_t)i];
+    label[(size_t)i] = (v < 0 || owner[(size_t)v] < 0) ? 0 : owner[(size_t)v] + 1;
+  }
+  for (int k = 0; k < K; ++k) if (alive[(size_t)k]) max_label = k + 1;
+}
+
 }  // namespace refcpu
