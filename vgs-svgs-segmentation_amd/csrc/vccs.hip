@@ -673,28 +673,32 @@ __global__ void k_pcl_pick_seeds(const uint64_t* __restrict__ mcode, const uint3
 }
 
 // selectInitialSupervoxelSeeds: a seed voxel stays if more than min_points voxel centroids lie within seed / 2 of its own
-__global__ void k_pcl_seed_filter(const unsigned long long* __restrict__ seed_key, int K0, const uint64_t* __restrict__ vox_code, int depth,
+// (round 6: sixteen lanes per seed -- the 343 probes of a cube of seven cells were one thread's dependent chain, 0.66 ms for 115 k seeds)
+__global__ __launch_bounds__(256) void k_pcl_seed_filter(const unsigned long long* __restrict__ seed_key, int K0, const uint64_t* __restrict__ vox_code, int depth,
                                   const Brick* __restrict__ bricks, uint32_t hbits, const float* __restrict__ cen, float rad2, int R,
                                   float min_points, uint32_t* __restrict__ keep) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K0) return;
-  const uint32_t s = (uint32_t)seed_key[k];
-  const uint64_t code = vox_code[s];
-  const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
-  const uint32_t lim = 1u << depth;
+  const int k = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), sub = (int)(threadIdx.x & 15u);
   int num = 0;
-  for (int dz = -R; dz <= R; ++dz)
-    for (int dy = -R; dy <= R; ++dy)
-      for (int dx = -R; dx <= R; ++dx) {
-        const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;
-        if (!(nx < lim && ny < lim && nz < lim)) continue;
-        bool unused_flag;
-        const int u = brick_find(bricks, hbits, nx, ny, nz, &unused_flag);
-        if (u < 0) continue;
-        const float ex = cen[3 * (int64_t)u] - cen[3 * (int64_t)s], ey = cen[3 * (int64_t)u + 1] - cen[3 * (int64_t)s + 1], ez = cen[3 * (int64_t)u + 2] - cen[3 * (int64_t)s + 2];
-        if ((ex * ex + ey * ey) + ez * ez < rad2) ++num;
-      }
-  keep[k] = ((float)num > min_points) ? 1u : 0u;
+  if (k < K0) {
+    const uint32_t s = (uint32_t)seed_key[k];
+    const uint64_t code = vox_code[s];
+    const uint32_t kx = vm_compact21(code >> 2), ky = vm_compact21(code >> 1), kz = vm_compact21(code);
+    const uint32_t lim = 1u << depth;
+    const float sx = cen[3 * (int64_t)s], sy = cen[3 * (int64_t)s + 1], sz = cen[3 * (int64_t)s + 2];
+    const int D = 2 * R + 1, cells = D * D * D;
+    for (int ci = sub; ci < cells; ci += 16) {
+      const int dx = ci % D - R, dy = (ci / D) % D - R, dz = ci / (D * D) - R;
+      const uint32_t nx = kx + (uint32_t)dx, ny = ky + (uint32_t)dy, nz = kz + (uint32_t)dz;
+      if (!(nx < lim && ny < lim && nz < lim)) continue;
+      bool unused_flag;
+      const int u = brick_find(bricks, hbits, nx, ny, nz, &unused_flag);
+      if (u < 0) continue;
+      const float ex = cen[3 * (int64_t)u] - sx, ey = cen[3 * (int64_t)u + 1] - sy, ez = cen[3 * (int64_t)u + 2] - sz;
+      if ((ex * ex + ey * ey) + ez * ez < rad2) ++num;
+    }
+  }
+  for (int o = 8; o > 0; o >>= 1) num += __shfl_xor(num, o, 64);   // (a count: any order)
+  if (k < K0 && sub == 0) keep[k] = ((float)num > min_points) ? 1u : 0u;
 }
 
 __global__ void k_pcl_compact_seeds(const unsigned long long* __restrict__ seed_key, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keep_scan_excl,
@@ -722,18 +726,47 @@ __global__ void k_pcl_plant_first(const uint32_t* __restrict__ seeds, int K, con
 // reseedSupervoxels (round 5): the voxel nearest to the supervoxel's centroid among ALL voxels -- PCL asks its kd-tree; here the lattice
 // cells around the centroid's own cell, shell by shell, through the brick table (vccs_common.h: vccs_nearest_voxel).  One thread per
 // supervoxel: three or four shells, a couple of hundred probes.
-__global__ void k_pcl_reseed_nearest(int K, const uint8_t* __restrict__ alive, const VccsState* __restrict__ st, const float* __restrict__ cen,
+__global__ __launch_bounds__(256) void k_pcl_reseed_nearest(int K, const uint8_t* __restrict__ alive, const VccsState* __restrict__ st, const float* __restrict__ cen,
                                      const Brick* __restrict__ bricks, uint32_t hbits, int depth, double min_x, double min_y, double min_z, double res_d,
                                      float res, unsigned long long* __restrict__ seed_key) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  seed_key[k] = ~0ull;
-  if (!alive[k]) return;
-  const float c[3] = {st[k].c[0], st[k].c[1], st[k].c[2]};
-  const uint32_t kx = vm_axis_key(c[0], min_x, res_d), ky = vm_axis_key(c[1], min_y, res_d), kz = vm_axis_key(c[2], min_z, res_d);
-  seed_key[k] = vccs_nearest_voxel(c, kx, ky, kz, 1u << depth, res,
-                                   [&](uint32_t x, uint32_t y, uint32_t z) { bool unused_flag; return brick_find(bricks, hbits, x, y, z, &unused_flag); },
-                                   [&](int v) { return cen + 3 * (int64_t)v; });
+  // (round 6: sixteen lanes per supervoxel share the cells of every shell; the minimum of a shell's keys and the test behind it are those of
+  // vccs_nearest_voxel -- the oracle's one-thread form -- whatever lane found them)
+  const int k = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), sub = (int)(threadIdx.x & 15u);
+  const bool on = k < K && alive[k < K ? k : 0] != 0;
+  float c[3] = {0.f, 0.f, 0.f};
+  uint32_t kx = 0, ky = 0, kz = 0;
+  if (on) {
+    c[0] = st[k].c[0]; c[1] = st[k].c[1]; c[2] = st[k].c[2];
+    kx = vm_axis_key(c[0], min_x, res_d); ky = vm_axis_key(c[1], min_y, res_d); kz = vm_axis_key(c[2], min_z, res_d);
+  }
+  const uint32_t lim = 1u << depth;
+  unsigned long long best = ~0ull;
+  bool done = !on;
+  for (int r = 0; ; ++r) {
+    if (!done) {
+      const int D = 2 * r + 1, cells = D * D * D;
+      for (int ci = sub; ci < cells; ci += 16) {
+        const int dx = ci % D - r, dy = (ci / D) % D - r, dz = ci / (D * D) - r;
+        if (dx != -r && dx != r && dy != -r && dy != r && dz != -r && dz != r) continue;   // the shell only
+        const uint32_t x = kx + (uint32_t)dx, y = ky + (uint32_t)dy, z = kz + (uint32_t)dz;
+        if (!(x < lim && y < lim && z < lim)) continue;
+        bool unused_flag;
+        const int v = brick_find(bricks, hbits, x, y, z, &unused_flag);
+        if (v < 0) continue;
+        const float* p = cen + 3 * (int64_t)v;
+        const float ex = p[0] - c[0], ey = p[1] - c[1], ez = p[2] - c[2];
+        const unsigned long long key = ((unsigned long long)vm_bits((ex * ex + ey * ey) + ez * ez) << 32) | (unsigned long long)(uint32_t)v;
+        best = key < best ? key : best;
+      }
+    }
+    for (int o = 8; o > 0; o >>= 1) {
+      const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(best >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, o, 64);
+      best = other < best ? other : best;
+    }
+    if (!done && ((best != ~0ull && vccs_shell_settles(vm_from_bits((uint32_t)(best >> 32)), r, res)) || (uint32_t)r >= lim)) done = true;
+    if (__ballot(!done) == 0ull) break;
+  }
+  if (k < K && sub == 0) seed_key[k] = on ? best : ~0ull;
 }
 // the supervoxel keeps its centroid; its new only leaf is that voxel.  Supervoxels take their seeds in label order: a voxel that two of them
 // name goes to the later one (atomicMax = the sequential overwrite), the earlier one starts the pass without a voxel
@@ -1123,7 +1156,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   hipLaunchKernelGGL(k_pcl_pick_seeds, dim3(nbV), dim3(TB), 0, c->stream, c->cell_code_b.p, c->cell_id_b.p, scan, V, cen.p, mnx, mny, mnz, seed, seed_key);
   // rejection + compaction (the scan buffers are free again: keep flags in head_flag, their exclusive scan in perm_a, seeds in cell_id_a)
   const float rad = 0.5f * seed;
-  hipLaunchKernelGGL(k_pcl_seed_filter, dim3(nbK0), dim3(TB), 0, c->stream, seed_key, K0, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+  hipLaunchKernelGGL(k_pcl_seed_filter, dim3((unsigned)(((int64_t)K0 * 16 + TB - 1) / TB)), dim3(TB), 0, c->stream, seed_key, K0, c->vox_code.p, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
                      rad * rad, (int)(rad / res) + 1, vccs_seed_min_points(seed, res), c->head_flag.p);
   VGS_HIP_TRY(c, rocprim::exclusive_scan(c->sort_tmp.p, scan2_bytes, c->head_flag.p, c->perm_a.p, 0u, (size_t)K0, rocprim::plus<uint32_t>(), c->stream));
   uint32_t tail[2] = {0, 0};
@@ -1174,7 +1207,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
       // refineSupervoxels: refineNormals of every supervoxel (from its own leaves), reseedSupervoxels (nearest of all voxels), expansion
       hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, (const int32_t*)own[cur]);
       hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, (const int32_t*)own[cur]);
-      hipLaunchKernelGGL(k_pcl_reseed_nearest, dim3(nbK), dim3(TB), 0, c->stream, K, (const uint8_t*)c->vc_alive.p, (const VccsState*)state, cen.p,
+      hipLaunchKernelGGL(k_pcl_reseed_nearest, dim3((unsigned)(((int64_t)K * 16 + TB - 1) / TB)), dim3(TB), 0, c->stream, K, (const uint8_t*)c->vc_alive.p, (const VccsState*)state, cen.p,
                          (const Brick*)c->hkey.p, c->hbits, c->box.depth, c->box.min[0], c->box.min[1], c->box.min[2], c->box.res, res, seed_key);
       hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);
       hipLaunchKernelGGL(k_pcl_plant_again, dim3(nbK), dim3(TB), 0, c->stream, seed_key, K, c->vc_alive.p, own[cur]);
