@@ -116,11 +116,12 @@ def test_labels_identical(case):
     np.testing.assert_array_equal(eng.point_labels(), pl_ref)
 
 
-@pytest.mark.parametrize("knob", ["VGS_NO_NEAR", "VGS_NO_ADJMASKS", "VGS_A1MAX", "VGS_NO_DENSE"])
+@pytest.mark.parametrize("knob", ["VGS_NO_NEAR", "VGS_NO_ADJMASKS", "VGS_A1MAX", "VGS_NO_DENSE", "VGS_HO_GRID=0", "VGS_HO_GRID=3"])
 def test_same_result_with_the_schedule_off(case, gpu, knob):
     """The knobs only schedule: rows, connect lists and labels are identical bit for bit (pair-evaluation counts may differ)."""
+    knob, _, value = knob.partition("=")   # (VGS_HO_GRID: a workgroup per handed-over row as before round 6 / three workgroups striding over them all)
     old = os.environ.get(knob)
-    os.environ[knob] = "-1" if knob == "VGS_A1MAX" else "1"
+    os.environ[knob] = value or ("-1" if knob == "VGS_A1MAX" else "1")
     try:
         e2 = gpu.Engine(case["p"])
         e2.set_points(case["xyz"])

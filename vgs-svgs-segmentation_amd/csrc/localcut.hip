@@ -1085,7 +1085,18 @@ vgs_status vgs_stage_localcut(vgs_ctx* c) {
   // workgroup kernel and still hands half of them over.)
   const unsigned int nab = nabc[0] + nabc[1] + nabc[4] + nabc[6];
   // about 1.4 % of the A/B voxels are handed over on the urban scenes; idle workgroups of this kernel are not free
-  const unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
+  unsigned int grid_f = std::min<unsigned int>(nab, std::min<unsigned int>(GRID_F, nab / 32 + 256));
+  // Not more workgroups than the device holds at once (LD_SMALL_WG_PER_CU per CU; the pair-list kernel's fit as many): they are all resident
+  // when the merge stage's first kernels start on the main stream a few microseconds later, and keep their CUs' LDS and registers until the
+  // lists are done.  With a workgroup per row the one-wavefront workgroups of k_cross and k_union_mutual take every slot a finished
+  // workgroup leaves -- a four-wavefront workgroup with 30 KB needs a slot on every SIMD at once and never finds one, whatever its stream's
+  // priority: on URB10M the kernel took 1.05 ms beside them and 0.41 ms alone (round 6 timeline).
+  if (c->K.ho_grid != 0) {
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned int fit = c->K.ho_grid > 0 ? (unsigned int)c->K.ho_grid : (unsigned int)n_cu * LD_SMALL_WG_PER_CU;
+    grid_f = std::min(grid_f, fit);
+  }
   {
     VGS_HIP_TRY(c, hipStreamWaitEvent(c->stream3, c->ev[11], 0));
     if (dense && nab > 0)
@@ -1344,9 +1355,18 @@ vgs_status vgs_localcut_finish(vgs_ctx* c, unsigned int* n_deferred) {
     for (int j = 0; j < 16; ++j) if (dn[j][0]) fprintf(stderr, " %s=%.4g", dn[j], j == 8 ? (double)(dp[j] & 0xffffffffull) : (double)dp[j]);
     fprintf(stderr, "\n");
     VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_dn_prof), z, sizeof(dp)));
+    if (getenv("VGS_DN_TRACE")) {
+      std::vector<unsigned long long> tr(4 * 16384 + 1);
+      VGS_HIP_TRY(c, hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_dn_trace), tr.size() * 8));
+      const size_t n = std::min<size_t>(tr[4 * 16384], 16384);
+      FILE* f = fopen(getenv("VGS_DN_TRACE"), "w");
+      if (f) { for (size_t k = 0; k < n; ++k) fprintf(f, "%llu %llu %llx %llu %llu\n", tr[4*k], tr[4*k+1], tr[4*k+2], tr[4*k+3] & 0xffffffffull, tr[4*k+3] >> 32); fclose(f); }
+      const unsigned long long z1 = 0;
+      VGS_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_dn_trace), &z1, 8, (4 * 16384) * 8));
+    }
     unsigned long long pg[24];
     VGS_HIP_TRY(c, hipMemcpyFromSymbol(pg, HIP_SYMBOL(g_pg_prof), sizeof(pg)));
-    const char* pn[24] = {"stage", "read", "sort", "merge", "carry", "ring", "phaseB", "result", "", "", "sum_edges", "ring_edges", "bands", "nB", "voxels", "", "", "", "", "", "", "", "", ""};
+    const char* pn[24] = {"stage", "read", "sort", "merge", "carry", "ring", "phaseB", "result", "", "", "sum_edges", "ring_edges", "bands", "nB", "voxels", "rounds", "alive_at_round", "star_at_round", "chain_members", "cyc_walk", "cyc_claim", "cyc_commit", "cyc_flatten", "cyc_merge_wave0"};
     fprintf(stderr, "[vgs-prof] k_localcut_pg:");
     for (int j = 0; j < 24; ++j) if (pn[j][0]) fprintf(stderr, " %s=%.4g", pn[j], (double)pg[j]);
     fprintf(stderr, "\n");

@@ -37,6 +37,7 @@
 
 #ifdef VGS_PROF
 __device__ unsigned long long g_dn_prof[16];
+__device__ unsigned long long g_dn_trace[4 * 16384 + 1];   // per row: wall begin, wall end, HW_ID | XCC_ID << 32, m | MAXM << 32
 #define DNP_T0() long long _dt0 = clock64()
 #define DNP_ACC(slot) do { long long _dt1 = clock64(); if (tid == 0) atomicAdd(&g_dn_prof[slot], (unsigned long long)(_dt1 - _dt0)); _dt0 = _dt1; } while (0)
 #else
@@ -574,6 +575,12 @@ __global__ __launch_bounds__(TB, (MAXM <= 255 ? LD_SMALL_WG_PER_CU : 4)) void k_
     atomicMax(&g_dn_prof[14], tt);
     atomicMax(&g_dn_prof[9], (unsigned long long)(wall_clock64() - w_begin));
     if (tt > 400000ull) atomicAdd(&g_dn_prof[15], 1ull);
+    const unsigned long long slot = atomicAdd(&g_dn_trace[4 * 16384], 1ull);
+    if (slot < 16384ull) {
+      g_dn_trace[4 * slot] = (unsigned long long)w_begin; g_dn_trace[4 * slot + 1] = (unsigned long long)wall_clock64();
+      g_dn_trace[4 * slot + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+      g_dn_trace[4 * slot + 3] = (unsigned long long)m | ((unsigned long long)MAXM << 32);
+    }
   }
 #endif
   };   // process

@@ -43,15 +43,32 @@ __device__ __forceinline__ void pg_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifndef PG_CHAIN
+#define PG_CHAIN 1
+#endif
+
+// inclusive prefix sum over the 64 lanes of a wavefront (all lanes active): four DPP shifts inside each row of 16, then the rows' totals
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
 #ifdef VGS_PROF
 __device__ unsigned long long g_pg_prof[24];
 #define PGP_T0() long long _pt0 = clock64()
 #define PGP_ACC(slot) do { long long _pt1 = clock64(); if (tid == 0) atomicAdd(&g_pg_prof[slot], (unsigned long long)(_pt1 - _pt0)); _pt0 = _pt1; } while (0)
 #define PGP_CNT(slot, v) do { if (tid == 0) atomicAdd(&g_pg_prof[slot], (unsigned long long)(v)); } while (0)
+#define PGP_CNTL(slot, v) do { if (lane == 0) atomicAdd(&g_pg_prof[slot], (unsigned long long)(v)); } while (0)
 #else
 #define PGP_T0() do {} while (0)
 #define PGP_ACC(slot) do {} while (0)
 #define PGP_CNT(slot, v) do {} while (0)
+#define PGP_CNTL(slot, v) do {} while (0)
 #endif
 
 // MAXM vertices, LCAP edges in flight (<= 512 * NW: the sort's block size), NW wavefronts, OCC workgroups per CU the registers allow;
@@ -187,6 +204,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
         int merges = s_i[S_MERGES];
         int pos = 0;
         bool reached = false;
+#ifdef VGS_PROF
+        int pr_rounds = 0, pr_alive = 0, pr_star = 0, pr_members = 0;
+        long long pr_walk = 0, pr_claim = 0, pr_commit = 0, pr_t0 = clock64(), pr_flat = 0;
+#endif
         while (pos < cnt && !reached) {
           const int e = pos + lane;
           float w = 0.f;
@@ -201,6 +222,108 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             sb = seg[pid & PMASK];
           }
           const int nproc = __popcll(__ballot(alive));   // sorted: the processable edges are a prefix of the step
+          if constexpr (PG_CHAIN != 0 && !RING_LDS) {
+          // One iteration decides (a) every edge no earlier undecided edge of the step touches on either side -- the rule of
+          // localcut_wave.hpp -- (b) every edge that is the first at ONE of its segments and too light for that segment (its
+          // state is the one the edge will find; a rejected edge changes nothing), and (c) a whole CHAIN of edges into one
+          // segment X (the larger side of the first undecided edge), which rule (a) would take one iteration each.  Chain members
+          // are the edges X--Y that are the first to touch their Y and heavy enough for it, up to the first edge whose order
+          // against the chain the claims cannot show (an X--Y edge whose Y an edge outside the chain touched first; an edge
+          // outside the chain touching a member's Y: once Y is inside X it is an edge of X).  A later X--Y edge with a member's Y
+          // is skipped: it lies inside X once the member has merged, and a member that does not merge ends the chain (below).
+          // What a merge leaves behind depends on its own weight and the size only (thr = w - cut / size), so with every earlier
+          // member presumed to merge each member's test against X is a prefix sum away; the first member that fails it is
+          // rejected for good (its presumption held) and so is every member behind it.
+          while (true) {
+            float ta = 0.f, tb = 0.f;
+            int za = 0, zb = 0;
+#ifdef VGS_PROF
+            long long q0 = clock64();
+#endif
+            if (alive) {
+              int r = rep[sa], rb = rep[sb];
+              za = (int)ssz[sa]; zb = (int)ssz[sb]; ta = thr[sa]; tb = thr[sb];
+              while (r != sa || rb != sb) { sa = r; sb = rb; r = rep[sa]; rb = rep[sb]; za = (int)ssz[sa]; zb = (int)ssz[sb]; ta = thr[sa]; tb = thr[sb]; }
+              alive = sa != sb;
+            }
+            const unsigned long long am = __ballot(alive);
+#ifdef VGS_PROF
+            { const long long q1 = clock64(); pr_walk += q1 - q0; q0 = q1; }
+#endif
+            if (am == 0ull) break;
+            const int f = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
+            const int X = __builtin_amdgcn_readlane(za >= zb ? sa : sb, f);
+            const bool xa = sa == X, xb = sb == X;
+            const bool star = alive && (xa | xb);
+            const unsigned long long xm = __ballot(star);
+#ifdef VGS_PROF
+            ++pr_rounds; pr_alive += __popcll(am); pr_star += __popcll(xm);
+#endif
+            if (alive) { if (!xa) atomicMin(&claim[sa], (uint32_t)lane); if (!xb) atomicMin(&claim[sb], (uint32_t)lane); }
+            wave_sync();
+            uint32_t ca = (uint32_t)lane, cb = (uint32_t)lane;
+            if (alive) { if (!xa) ca = claim[sa]; if (!xb) cb = claim[sb]; }
+            wave_sync();
+            if (alive) { if (!xa) claim[sa] = 0xffffffffu; if (!xb) claim[sb] = 0xffffffffu; }
+            const bool fa = ca == (uint32_t)lane, fb = cb == (uint32_t)lane;   // (the side that is X counts as first here)
+#ifdef VGS_PROF
+            { const long long q1 = clock64(); pr_claim += q1 - q0; q0 = q1; }
+#endif
+            const bool ca_star = ((xm >> (ca & 63u)) & 1ull) != 0ull, cb_star = ((xm >> (cb & 63u)) & 1ull) != 0ull;
+            const bool stop = alive && ((!fa && ca_star != star) || (!fb && cb_star != star));
+            const unsigned long long sm = __ballot(stop);
+            const unsigned long long open = sm == 0ull ? ~0ull : ((1ull << (__ffsll((long long)sm) - 1)) - 1ull);   // the lanes in front of the first stop
+            // first at a segment other than X, that segment's state is the one the edge will find: rejected there, it is rejected
+            const bool rej = alive && ((fa && !xa && !(w > ta)) || (fb && !xb && !(w > tb)));
+            const bool first = alive && fa && fb && !rej;
+            bool member = first && star && ((open >> lane) & 1ull) != 0ull;
+            unsigned long long P = __ballot(member);   // the members presumed to merge
+            const bool chain = (P & (P - 1ull)) != 0ull;   // (no two of them: the first undecided edge is decided like the others)
+            if (!chain) { P = 0ull; member = false; }
+            const bool decided = first && (!star || (!chain && lane == f));
+            // ---- the chain ----
+#ifdef VGS_PROF
+            pr_members += __popcll(P);
+#endif
+            if (chain) {
+              const float tX0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa ? ta : tb), f));   // (lane f holds X's state whether it is a member or not)
+              const int zX0 = __builtin_amdgcn_readlane(xa ? za : zb, f);
+              const int zz = member ? (xa ? zb : za) : 0;
+              const int incl = wave_incl_scan(zz);
+              const unsigned long long before = P & lt_mask;
+              const int pl = before == 0ull ? lane : 63 - __clzll((long long)before);
+              const float w_prev = __shfl(w, pl, 64);
+              const float tXb = before == 0ull ? tX0 : vm_cut_threshold(w_prev, cut, zX0 + incl - zz);
+              // (a member's own Y has accepted it above.)  Rejected by X, a member shows X frozen: the weights only fall from here
+              // and X's threshold changes with a merge only, so every member behind it is rejected too
+              const unsigned long long bad = __ballot(member && !(w > tXb));
+              if (bad != 0ull) P &= (1ull << (__ffsll((long long)bad) - 1)) - 1ull;
+              if (((P >> lane) & 1ull) != 0ull) {
+                const int Y = xa ? sb : sa;
+                rep[Y] = (uint16_t)X;
+                ssz[Y] = 0;
+                if ((P >> lane) >> 1 == 0ull) { thr[X] = vm_cut_threshold(w, cut, zX0 + incl); ssz[X] = (uint16_t)(zX0 + incl); }   // the last one leaves X's state
+              }
+            }
+            // ---- the edges decided on their own ----
+            const bool pass = decided && (w > ta) && (w > tb);
+            if (pass) {
+              const int keep = (ta >= tb) ? sa : sb;   // VS:1972-1983: the segment with the larger threshold survives
+              const int gone = sa ^ sb ^ keep;
+              const int nsz = za + zb;
+              rep[gone] = (uint16_t)keep;
+              thr[keep] = vm_cut_threshold(w, cut, nsz);   // seg_int = w (VS:1988)
+              ssz[keep] = (uint16_t)nsz;
+              ssz[gone] = 0;
+            }
+            merges += __popcll(P) + __popcll(__ballot(pass));
+            alive = alive && !decided && !member && !rej;
+            wave_sync();
+#ifdef VGS_PROF
+            { const long long q1 = clock64(); pr_commit += q1 - q0; q0 = q1; }
+#endif
+          }
+          } else {
           while (true) {
             float ta = 0.f, tb = 0.f;
             int nsz = 1;
@@ -212,6 +335,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
               alive = sa != sb;
             }
             if (__ballot(alive) == 0ull) break;
+#ifdef VGS_PROF
+            {
+              const unsigned long long am = __ballot(alive);
+              const int f = __ffsll((long long)am) - 1;
+              const int fa = __shfl(sa, f, 64), fb = __shfl(sb, f, 64);
+              const int X = ssz[fa] >= ssz[fb] ? fa : fb;
+              const unsigned long long xm = __ballot(alive && (sa == X || sb == X));
+              ++pr_rounds; pr_alive += __popcll(am); pr_star += __popcll(xm);
+            }
+#endif
             if (alive) { atomicMin(&claim[sa], (uint32_t)lane); atomicMin(&claim[sb], (uint32_t)lane); }
             wave_sync();
             bool decided = false;
@@ -234,6 +367,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             alive = alive && !decided;
             wave_sync();
           }
+          }
           if (nproc < 64) { pos += nproc; reached = true; } else pos += 64;
           if (merges >= m - 1) break;
           if (!reached && pos < cnt) {
@@ -244,12 +378,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_localcut_pg(const uint32_t* __
             if (!(thr[s0] < wn)) { pos = cnt; break; }   // (what is left of the list is dead for the voxel: nothing to carry)
           }
         }
+#ifdef VGS_PROF
+        pr_flat = clock64();
+#endif
         for (int c = lane; c < m; c += 64) {
           int s = seg[c];
           while (rep[s] != s) s = rep[s];
           seg[c] = (uint16_t)s;
         }
         if (lane == 0) { s_i[S_POS] = pos; s_i[S_MERGES] = merges; }
+#ifdef VGS_PROF
+        { const long long q1 = clock64(); PGP_CNTL(22, q1 - pr_flat); PGP_CNTL(23, q1 - pr_t0); }
+        PGP_CNTL(19, pr_walk); PGP_CNTL(20, pr_claim); PGP_CNTL(21, pr_commit);
+        PGP_CNTL(15, pr_rounds); PGP_CNTL(16, pr_alive); PGP_CNTL(17, pr_star); PGP_CNTL(18, pr_members);
+#endif
       }
       pg_barrier();
     };

@@ -243,9 +243,11 @@ __global__ __launch_bounds__(256) void k_pl_mark(PlWho who, const uint64_t* __re
   }
 }
 // ... and of those the ones without a list so far, as a work list of rows (used-voxel indices) in voxel order
-__global__ __launch_bounds__(1024) void k_pl_worklist(const uint32_t* __restrict__ used_ids, int64_t U, const uint8_t* __restrict__ need,
+// (256 threads: a closed gate makes this an empty launch beside the dense kernel's hand-overs, and a 16-wavefront workgroup waits for a
+// CU to drain before it can find that out -- with the dispatcher holding the CU for it meanwhile: round 6 timeline, 0.5 ms)
+__global__ __launch_bounds__(256) void k_pl_worklist(const uint32_t* __restrict__ used_ids, int64_t U, const uint8_t* __restrict__ need,
                                                       const uint2* __restrict__ idx, uint32_t* __restrict__ work, unsigned int* __restrict__ n_work, LcGate gate) {
-  __shared__ unsigned int s_cnt[16], s_base;
+  __shared__ unsigned int s_cnt[4], s_base;
   if (!lc_gate_open(gate)) return;   // (the work list stays empty: the builders behind this launch find nothing to do)
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_pl_worklist(const uint32_t* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned int tot = 0;
-    for (int w = 0; w < 16; ++w) { const unsigned int x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
+    for (int w = 0; w < 4; ++w) { const unsigned int x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
     s_base = tot ? atomicAdd(n_work, tot) : 0u;
   }
   __syncthreads();
@@ -340,7 +342,7 @@ vgs_status vgs_pairlists_build(vgs_ctx* c, hipStream_t strm, const uint32_t* con
     const unsigned int grid = std::min<unsigned int>(4096u, std::max<unsigned int>(1u, (upper + 3u) / 4u));
     hipLaunchKernelGGL(k_pl_mark, dim3(grid), dim3(256), 0, strm, who, c->adj_key.p, c->adj_cnt.p, c->adj_stride, need, gate);
   }
-  hipLaunchKernelGGL(k_pl_worklist, dim3((unsigned)((U + 1023) / 1024)), dim3(1024), 0, strm, c->used_ids.p, U, all_rows ? (const uint8_t*)nullptr : need, idx,
+  hipLaunchKernelGGL(k_pl_worklist, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, strm, c->used_ids.p, U, all_rows ? (const uint8_t*)nullptr : need, idx,
                      wl, n_work, gate);
   PlParams P;
   P.W.inv_sig_p = 1.0f / c->P.sig_p; P.W.inv_sig_n = 1.0f / c->P.sig_n; P.W.inv_sig_o = 1.0f / c->P.sig_o; P.W.inv_sig_e = 1.0f / c->P.sig_e;
