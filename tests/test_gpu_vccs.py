@@ -197,3 +197,26 @@ def test_pcl_order_switch_rolls_the_labels_back(gpu):
     e2.set_points(xyz)
     e2.run()
     np.testing.assert_array_equal(b, e2.supervoxel_labels()[0])
+
+
+@pytest.mark.parametrize("knob", ["VGS_VCCS_NBR_NORMALS", "VGS_VCCS_PINGPONG", "VGS_NO_VCCS_TILES"])
+def test_pcl_order_schedule_knobs_change_nothing(gpu, knob):
+    """The two-ring normals over the tiles' LDS arrays (round 6) against the [26][V] neighbour table, the live sweeps in place against two
+    flag arrays, tiles against whole-cloud kernels: the same supervoxels, label for label."""
+    import os
+    xyz = gpu.scenes.town_scene(90_000)
+    p = gpu.default_params(3)
+    a = gpu.Engine(p); a.set_points(xyz); a.supervoxels()
+    la, ma = a.supervoxel_labels()
+    old = os.environ.get(knob)
+    os.environ[knob] = "1"
+    try:
+        b = gpu.Engine(p); b.set_points(xyz); b.supervoxels()
+        lb, mb = b.supervoxel_labels()
+    finally:
+        if old is None:
+            del os.environ[knob]
+        else:
+            os.environ[knob] = old
+    assert ma == mb
+    np.testing.assert_array_equal(la, lb)

@@ -81,7 +81,7 @@ void vgs_read_env_knobs(vgs_ctx* c) {
   k.a1_max = geti("VGS_A1MAX", k.a1_max); k.shell0 = getf("VGS_SHELL0", k.shell0); k.cap_frac = getf("VGS_CAPFRAC", k.cap_frac);
   k.dbg_stop = geti("VGS_DBG_STOP", k.dbg_stop); k.max_rounds = geti("VGS_ROUNDS", k.max_rounds); k.dbg_max_m = geti("VGS_DBG_MAXM", k.dbg_max_m); k.dbg_xl_from = geti("VGS_DBG_XL_FROM", k.dbg_xl_from);
   k.near_min_own = geti("VGS_NEARMINOWN", k.near_min_own); k.fv_blocks = geti("VGS_FV_BLOCKS", k.fv_blocks); k.only_class = geti("VGS_ONLY_CLASS", k.only_class);
-  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_pg_xl = has("VGS_NO_PG_XL"); k.no_sort32 = has("VGS_NO_SORT32"); k.no_grow_prefix = has("VGS_NO_GROW_PREFIX"); k.no_adj_wide = has("VGS_NO_ADJ_WIDE"); k.vccs_pingpong = has("VGS_VCCS_PINGPONG"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.cross_lds_kb = geti("VGS_CROSS_LDS", k.cross_lds_kb); k.no_tile_early = has("VGS_NO_TILE_EARLY"); { int vp = geti("VGS_VOTE_PERIOD", k.vote_period); if (vp >= 2 && vp <= 4096 && (vp & (vp - 1)) == 0) k.vote_period = vp; } k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac); k.ho_grid = geti("VGS_HO_GRID", k.ho_grid);
+  k.no_dense = has("VGS_NO_DENSE"); k.no_overlap = has("VGS_NO_OVERLAP"); k.no_near = has("VGS_NO_NEAR"); k.no_adjmasks = has("VGS_NO_ADJMASKS"); k.no_connbits = has("VGS_NO_CONNBITS"); k.no_c0 = has("VGS_NO_C0"); k.no_pg_xl = has("VGS_NO_PG_XL"); k.no_sort32 = has("VGS_NO_SORT32"); k.no_grow_prefix = has("VGS_NO_GROW_PREFIX"); k.no_adj_wide = has("VGS_NO_ADJ_WIDE"); k.vccs_pingpong = has("VGS_VCCS_PINGPONG"); k.no_vccs_tiles = has("VGS_NO_VCCS_TILES"); k.no_early_union = has("VGS_NO_EARLY_UNION"); k.no_packed_sort = has("VGS_NO_PACKED_SORT"); k.no_pairlists = has("VGS_NO_PAIRLISTS"); k.no_vote = has("VGS_NO_VOTE"); k.vote_force = geti("VGS_VOTE_FORCE", 0); k.cross_lds_kb = geti("VGS_CROSS_LDS", k.cross_lds_kb); k.no_tile_early = has("VGS_NO_TILE_EARLY"); { int vp = geti("VGS_VOTE_PERIOD", k.vote_period); if (vp >= 2 && vp <= 4096 && (vp & (vp - 1)) == 0) k.vote_period = vp; } k.pg_wide = geti("VGS_PG_WIDE", k.pg_wide); k.pg_wide_frac = geti("VGS_PG_WIDEFRAC", k.pg_wide_frac); k.pg_min_frac = geti("VGS_PG_MINFRAC", k.pg_min_frac); k.ho_grid = geti("VGS_HO_GRID", k.ho_grid); k.vccs_nbr_normals = has("VGS_VCCS_NBR_NORMALS");
   k.debug = has("VGS_DEBUG");
 }
 

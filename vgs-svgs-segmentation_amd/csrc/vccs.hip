@@ -649,6 +649,85 @@ __global__ void k_pcl_normals(int64_t V, const int32_t* __restrict__ nbr, const 
   nrm[3 * v] = n[0]; nrm[3 * v + 1] = n[1]; nrm[3 * v + 2] = n[2];
 }
 
+// The same two kernels over the tiles of k_vccs_tile_setup (round 6): the tile's 10^3 array of voxel ids -- its own voxels and the shell, from
+// the lists the live sweeps use -- answers "who is my neighbour at offset o", so the [26][V] table (26 x 4 bytes per voxel and kernel: three
+// quarters of either kernel's traffic) is neither read nor, over tiles, built.  Same neighbours in the same order (vccs_offset27: dx outermost),
+// same operations: the accumulators and normals are bit for bit those of k_pcl_accu1 / k_pcl_normals.
+// What the neighbours contribute to both kernels -- owner and centroid -- is staged in LDS once per tile as well (entry = the tile's voxels, then
+// its shell); the second kernel reads the first one's 40-byte accumulators from L2, a kilobyte per voxel, and that is what it waits for with or
+// without the table.  A tile with more entries than the arrays hold (a solid block: up to 1000) reads everything from memory as before.
+#define VTN_TB 128
+#ifndef VTN_CAP
+#define VTN_CAP 448
+#endif
+template <bool NORMALS>
+__global__ __launch_bounds__(VTN_TB) void k_pclt_normals(const uint32_t* __restrict__ tile_start, const uint2* __restrict__ meta, const uint2* __restrict__ halo,
+                                                         const uint16_t* __restrict__ cell, const float* __restrict__ cen, VccsAccu* __restrict__ A1 /* NORMALS: read */,
+                                                         float* __restrict__ nrm, const int32_t* __restrict__ owner) {
+  __shared__ __attribute__((aligned(16))) int I[VT_CELLS];   // cell -> entry (staged tiles) or voxel id, -1: no voxel
+  __shared__ float4 s_pc[VTN_CAP];                                   // centroid, owner (bits)
+  __shared__ int s_id[NORMALS ? VTN_CAP : 1];                        // NORMALS: entry -> voxel, for the first kernel's accumulators (from L2: staging
+                                                                     // them as well -- 31 KB a tile, five workgroups per CU -- was measured slower, 388 against 275 us)
+  const int tid = threadIdx.x;
+  const int t = (int)blockIdx.x;
+  for (int i = tid; i < VT_CELLS / 4; i += VTN_TB) ((int4*)I)[i] = make_int4(-1, -1, -1, -1);
+  const uint32_t ts = tile_start[t], te = tile_start[t + 1];
+  const uint2 m = meta[t];
+  const uint32_t n_own = te - ts, n_ent = n_own + m.y;
+  const bool staged = n_ent <= (uint32_t)VTN_CAP;   // (uniform)
+  __syncthreads();
+  for (uint32_t e = (uint32_t)tid; e < n_ent; e += VTN_TB) {
+    uint32_t id, ci;
+    if (e < n_own) { id = ts + e; ci = cell[id]; } else { const uint2 h = halo[m.x + (e - n_own)]; id = h.x; ci = h.y; }
+    I[ci] = staged ? (int)e : (int)id;
+    if (staged) {
+      s_pc[e] = make_float4(cen[3 * (int64_t)id], cen[3 * (int64_t)id + 1], cen[3 * (int64_t)id + 2], __int_as_float(owner ? owner[id] : 0));
+      if (NORMALS) s_id[e] = (int)id;
+    }
+  }
+  __syncthreads();
+  for (uint32_t e = (uint32_t)tid; e < n_own; e += VTN_TB) {
+    const uint32_t v = ts + e;
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (staged) me = s_pc[e];
+    const int k = owner ? (staged ? __float_as_int(me.w) : owner[v]) : 0;
+    if (k < 0) continue;
+    const int ci = (int)cell[v];
+    VccsAccu A;
+    vccs_accu_zero(&A);
+    float pv[3];
+    if (staged) { pv[0] = me.x; pv[1] = me.y; pv[2] = me.z; }
+    else { pv[0] = cen[3 * (int64_t)v]; pv[1] = cen[3 * (int64_t)v + 1]; pv[2] = cen[3 * (int64_t)v + 2]; }
+    if (NORMALS && !owner) vccs_accu_point(&A, pv);
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+      const int u = I[ci + (o / 9 - 1) + 10 * ((o / 3) % 3 - 1) + 100 * (o % 3 - 1)];   // vccs_offset27(o); o == 13 is the voxel itself
+      if (u < 0) continue;
+      float pu[3];
+      VccsAccu B;
+      if (staged) {
+        const float4 q = s_pc[u];
+        if (owner && __float_as_int(q.w) != k) continue;
+        pu[0] = q.x; pu[1] = q.y; pu[2] = q.z;
+        if (NORMALS) B = A1[s_id[u]];
+      } else {
+        if (owner && owner[u] != k) continue;
+        pu[0] = cen[3 * (int64_t)u]; pu[1] = cen[3 * (int64_t)u + 1]; pu[2] = cen[3 * (int64_t)u + 2];
+        if (NORMALS) B = A1[u];
+      }
+      vccs_accu_point(&A, pu);
+      if (NORMALS) vccs_accu_add(&A, &B);
+    }
+    if (NORMALS) {
+      float n[3];
+      vccs_accu_normal(&A, pv, n);
+      nrm[3 * (int64_t)v] = n[0]; nrm[3 * (int64_t)v + 1] = n[1]; nrm[3 * (int64_t)v + 2] = n[2];
+    } else {
+      A1[v] = A;
+    }
+  }
+}
+
 // seed cells in Morton order: sort key = Morton code of the cell's integer coordinates
 __global__ void k_pcl_cell_codes(const float* __restrict__ cen, int64_t V, float min_x, float min_y, float min_z, float seed,
                                  uint64_t* __restrict__ code, uint32_t* __restrict__ id) {
@@ -1093,17 +1172,20 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   const unsigned nbV = (unsigned)((V + TB - 1) / TB);
   DevBuf<float>& cen = c->vc_cen; DevBuf<float>& nrm = c->vc_nrm; DevBuf<float>& dist = c->vc_dist;
   VGS_HIP_TRY(c, cen.ensure(3 * V)); VGS_HIP_TRY(c, nrm.ensure(3 * V)); VGS_HIP_TRY(c, dist.ensure(2 * V));
-  VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V)); VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
+  const bool tiles = !c->K.no_vccs_tiles;
+  const bool tile_normals = tiles && !c->K.vccs_nbr_normals;   // (round 6) the two-ring normals over the tiles: no [26][V] neighbour table
+  if (!tile_normals) VGS_HIP_TRY(c, c->vc_nbr.ensure(26 * V));
+  VGS_HIP_TRY(c, c->vc_label.ensure(2 * V));
   static_assert(sizeof(VccsAccu) == 40, "VccsAccu");
   VGS_HIP_TRY(c, c->vc_accu.ensure(10 * (size_t)V)); VGS_HIP_TRY(c, c->vc_live.ensure(2 * (size_t)V));
   VGS_HIP_TRY(c, c->counters.ensure(64));
   hipLaunchKernelGGL(k_vccs_centroid, dim3(nbV), dim3(TB), 0, c->stream, c->xs.p, c->ys.p, c->zs.p, c->vox_start.p, V, cen.p);
   { vgs_status bs = vgs_build_bricks(c, nullptr); if (bs != VGS_OK) return bs; }
   // the 26-neighbour table (no 1-ring normals: the 2-ring ones follow)
-  hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
-                     c->vc_nbr.p, (float*)nullptr, (int4*)nullptr);
+  if (!tile_normals)
+    hipLaunchKernelGGL(k_vccs_neighbours, dim3(nbV), dim3(TB), 0, c->stream, c->vox_code.p, V, c->box.depth, (const Brick*)c->hkey.p, c->hbits, cen.p,
+                       c->vc_nbr.p, (float*)nullptr, (int4*)nullptr);
   // tiles for the live sweeps and the claim (k_pclt_sweep)
-  const bool tiles = !c->K.no_vccs_tiles;
   int NT = 0;
   if (tiles) {
     VGS_HIP_TRY(c, c->head_flag.ensure(V + 1)); VGS_HIP_TRY(c, c->perm_a.ensure(V + 1));
@@ -1127,8 +1209,18 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
                        c->vc_tile_start.p, c->vc_cell.p, (float*)nullptr, (uint2*)c->vc_halo.p, pool_cap, (unsigned long long*)c->vc_pool.p,
                        (uint2*)c->vc_tile_meta.p, (const uint32_t*)c->vc_tile_of.p, c->vc_nbr_tiles.p);
   }
-  hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, (const int32_t*)nullptr);
-  hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, (const int32_t*)nullptr);
+  auto two_ring_normals = [&](const int32_t* owner) {   // computeVoxelData (owner == null) / SupervoxelHelper::refineNormals
+    if (tile_normals) {
+      hipLaunchKernelGGL(k_pclt_normals<false>, dim3((unsigned)NT), dim3(VTN_TB), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p, (const uint2*)c->vc_halo.p,
+                         c->vc_cell.p, cen.p, (VccsAccu*)c->vc_accu.p, (float*)nullptr, owner);
+      hipLaunchKernelGGL(k_pclt_normals<true>, dim3((unsigned)NT), dim3(VTN_TB), 0, c->stream, c->vc_tile_start.p, (const uint2*)c->vc_tile_meta.p, (const uint2*)c->vc_halo.p,
+                         c->vc_cell.p, cen.p, (VccsAccu*)c->vc_accu.p, nrm.p, owner);
+    } else {
+      hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, owner);
+      hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, owner);
+    }
+  };
+  two_ring_normals(nullptr);
   // ---- seeds ----
   const float seed = c->P.seed_size, res = c->P.voxel_size;
   const float mnx = (float)c->box.min[0], mny = (float)c->box.min[1], mnz = (float)c->box.min[2];
@@ -1205,8 +1297,7 @@ static vgs_status vgs_stage_vccs_pcl(vgs_ctx* c) {
   for (int pass = 0; pass < 6; ++pass) {
     if (pass > 0) {
       // refineSupervoxels: refineNormals of every supervoxel (from its own leaves), reseedSupervoxels (nearest of all voxels), expansion
-      hipLaunchKernelGGL(k_pcl_accu1, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (VccsAccu*)c->vc_accu.p, (const int32_t*)own[cur]);
-      hipLaunchKernelGGL(k_pcl_normals, dim3(nbV), dim3(TB), 0, c->stream, V, c->vc_nbr.p, cen.p, (const VccsAccu*)c->vc_accu.p, nrm.p, (const int32_t*)own[cur]);
+      two_ring_normals((const int32_t*)own[cur]);
       hipLaunchKernelGGL(k_pcl_reseed_nearest, dim3((unsigned)(((int64_t)K * 16 + TB - 1) / TB)), dim3(TB), 0, c->stream, K, (const uint8_t*)c->vc_alive.p, (const VccsState*)state, cen.p,
                          (const Brick*)c->hkey.p, c->hbits, c->box.depth, c->box.min[0], c->box.min[1], c->box.min[2], c->box.res, res, seed_key);
       hipLaunchKernelGGL(k_pcl_reset, dim3(nbV), dim3(TB), 0, c->stream, V, own[cur], dst[cur]);

@@ -108,6 +108,7 @@ struct VgsKnobs {
   bool no_pairlists = false; // VGS_NO_PAIRLISTS: no pair lists (pairlist.hpp); hand-overs and wide classes take the kernels of round 4
   bool no_vote = false;      // VGS_NO_VOTE: every one-wavefront voxel tries the lazy schedule (LwParams::vote off)
   int vote_force = 0;        // VGS_VOTE_FORCE (diagnostics): every one-wavefront voxel that is not a sample is handed over
+  bool vccs_nbr_normals = false; // VGS_VCCS_NBR_NORMALS: vccs_mode 1's two-ring normals from the [26][V] neighbour table, as until round 6
   int ho_grid = -1;          // VGS_HO_GRID: workgroups of the hand-over kernels of the one-wavefront classes (-1: as many as the device holds at once; 0: one per row up to 16384)
   int pg_min_frac = 8;       // VGS_PG_MINFRAC: hand-overs go through the pair lists when they are more than 1/N of the used voxels (0: never)
   int pg_wide = 1;           // VGS_PG_WIDE: neighbourhoods above 128 voxels are cut from the pair lists (0: the multi-wavefront shell classes)
