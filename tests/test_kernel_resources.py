@@ -53,7 +53,8 @@ def test_one_wavefront_local_cut_keeps_its_registers_without_scratch(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_supervoxel_round_kernels_do_not_spill(tmp_path):
     k = _usage("vccs.hip", tmp_path)
-    hot = {n: v for n, v in k.items() if "k_vccs_expand_tiles" in n or "k_pclt_sweep" in n}
-    assert len(hot) == 3, sorted(k)
+    # ... and the two-ring normals over the tiles (round 6: k_pclt_normals<false / true>, six calls of each per step)
+    hot = {n: v for n, v in k.items() if "k_vccs_expand_tiles" in n or "k_pclt_sweep" in n or "k_pclt_normals" in n}
+    assert len(hot) == 5, sorted(k)
     for name, u in hot.items():
         assert u["ScratchSize"] == 0, (name, u)
